@@ -1,0 +1,239 @@
+"""ctypes binding of libdsmi.so (include/dsmi.h).
+
+The HIP library is the product: there is no CPU or eager-PyTorch fallback.  If the
+shared object is missing, importing this module's users works (so that pure-host
+logic can be tested without a GPU) but the first call that needs a kernel raises
+``NativeLibraryMissing`` with the build command.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdsmi.so")
+
+RNN_TYPES = {"gru": 0, "lstm": 1, "rnn": 2}
+WINDOWS = {"hamming": 0, "hann": 1, "blackman": 2, "bartlett": 3}
+PCM_DTYPES = {np.dtype(np.int16): 0, np.dtype(np.float32): 1, np.dtype(np.float64): 2}
+PAD_MODES = {"reflect": 0, "constant": 1}
+
+DSMI_ERR_CONV = -2
+DSMI_ERR_NOT_READY = -3
+DSMI_ERR_UNSORTED = -4
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+class DsmiError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libdsmi error %d: %s" % (code, msg))
+        self.code = code
+        self.msg = msg
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [
+        ("conv_layers", C.c_int32), ("rnn_type", C.c_int32), ("rnn_hidden_size", C.c_int32),
+        ("rnn_layers", C.c_int32), ("bidirectional", C.c_int32), ("context", C.c_int32),
+        ("n_labels", C.c_int32), ("sample_rate", C.c_int32), ("window_size", C.c_float),
+        ("window_stride", C.c_float), ("window", C.c_int32), ("normalize", C.c_int32),
+        ("pad_mode", C.c_int32),
+    ]
+
+
+_lib = None
+
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+_f32p = C.POINTER(C.c_float)
+_vp = C.c_void_p
+
+_PROTOS = {
+    "dsmi_model_create": (C.c_int, [C.POINTER(ModelDesc), C.c_int, C.POINTER(_vp)]),
+    "dsmi_model_load_tensor": (C.c_int, [_vp, C.c_char_p, _vp, _i64p, C.c_int]),
+    "dsmi_model_finalize": (C.c_int, [_vp]),
+    "dsmi_reserve": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "dsmi_model_destroy": (None, [_vp]),
+    "dsmi_last_error": (C.c_char_p, [_vp]),
+    "dsmi_seq_lens": (C.c_int, [_vp, _vp, C.c_int, _vp]),
+    "dsmi_features": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _vp]),
+    "dsmi_forward": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "dsmi_conv_stack": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
+    "dsmi_rnn_layer": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
+    "dsmi_greedy": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
+    "dsmi_set_profiling": (C.c_int, [_vp, C.c_int]),
+    "dsmi_stage_time_us": (C.c_double, [_vp, C.c_int]),
+    "dsmi_last_forward_stats": (C.c_int, [_vp, _i64p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+}
+
+
+def declared_symbols():
+    """Every function include/dsmi.h declares (used by the CPU-side export test)."""
+    return sorted(_PROTOS)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeLibraryMissing(
+                "%s not found: build it with `make -C danspeech_amd/csrc` (hipcc, gfx950) or "
+                "`python -c 'import __graft_entry__ as g; g.build()'`. There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(_vp)
+
+
+class NativeModel:
+    """Owns one dsmi_model handle (one GPU)."""
+
+    def __init__(self, cfg, state_dict, device=0, audio_conf=None, n_labels=33, pad_mode="reflect"):
+        L = lib()
+        ac = audio_conf or {}
+        d = ModelDesc()
+        d.conv_layers = int(cfg["conv_layers"])
+        d.rnn_type = RNN_TYPES[cfg["rnn_type"]]
+        d.rnn_hidden_size = int(cfg["rnn_hidden_size"])
+        d.rnn_layers = int(cfg["rnn_layers"])
+        d.bidirectional = int(bool(cfg["bidirectional"]))
+        d.context = int(cfg.get("context", 20))
+        d.n_labels = int(n_labels)
+        d.sample_rate = int(ac.get("sampling_rate", 16000))
+        d.window_size = float(ac.get("window_size", 0.02))
+        d.window_stride = float(ac.get("window_stride", 0.01))
+        d.window = WINDOWS[ac.get("window", "hamming")]
+        d.normalize = int(bool(ac.get("normalize", True)))
+        d.pad_mode = PAD_MODES[pad_mode]
+        self.desc = d
+        self.n_labels = int(n_labels)
+        self.device = device
+        h = _vp()
+        rc = L.dsmi_model_create(C.byref(d), device, C.byref(h))
+        if rc != 0:
+            raise DsmiError(rc, (L.dsmi_last_error(None) or b"").decode())
+        self._h = h
+        for name, t in state_dict.items():
+            a = t.detach().cpu().numpy() if hasattr(t, "detach") else np.asarray(t)
+            if a.dtype == np.int64:   # num_batches_tracked
+                continue
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            shape = (C.c_int64 * max(a.ndim, 1))(*a.shape)
+            self._check(L.dsmi_model_load_tensor(self._h, name.encode(), _np_ptr(a), shape, a.ndim))
+        self._check(L.dsmi_model_finalize(self._h))
+
+    def _check(self, rc):
+        if rc != 0:
+            raise DsmiError(rc, (lib().dsmi_last_error(self._h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().dsmi_model_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- host arithmetic
+    def seq_lens(self, lens):
+        lens = np.ascontiguousarray(lens, dtype=np.int32)
+        out = np.empty_like(lens)
+        self._check(lib().dsmi_seq_lens(self._h, _np_ptr(lens), len(lens), _np_ptr(out)))
+        return out
+
+    def reserve(self, max_batch, max_frames):
+        self._check(lib().dsmi_reserve(self._h, int(max_batch), int(max_frames)))
+
+    # ---- device entry points (torch tensors only as containers)
+    @staticmethod
+    def _stream():
+        import torch
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def features(self, pcm_dev, n_samples, t_stride=None):
+        """pcm_dev: 1-D CUDA tensor (int16/float32/float64) with the clips back to back."""
+        import torch
+        n_samples = np.ascontiguousarray(n_samples, dtype=np.int64)
+        B = len(n_samples)
+        hop = int(self.desc.sample_rate * self.desc.window_stride)
+        n_freq = int(self.desc.sample_rate * self.desc.window_size) // 2 + 1
+        frames = 1 + n_samples // hop
+        if t_stride is None:
+            t_stride = int(frames.max())
+        dt = {torch.int16: 0, torch.float32: 1, torch.float64: 2}[pcm_dev.dtype]
+        feat = torch.empty((B, 1, n_freq, t_stride), dtype=torch.float32, device=pcm_dev.device)
+        fr = np.empty(B, dtype=np.int32)
+        self._check(lib().dsmi_features(self._h, pcm_dev.data_ptr(), dt, _np_ptr(n_samples), B, feat.data_ptr(),
+                                        int(t_stride), _np_ptr(fr), self._stream()))
+        return feat, fr
+
+    def forward(self, feat, lens, out=None):
+        """feat: CUDA float32 [B,1,F,T] contiguous; lens sorted descending. -> (probs [B,T',C], out_lens)."""
+        import torch
+        assert feat.is_cuda and feat.dtype == torch.float32 and feat.is_contiguous()
+        B, T = feat.shape[0], feat.shape[-1]
+        lens = np.ascontiguousarray(lens, dtype=np.int32)
+        To = int(self.seq_lens(np.array([T], dtype=np.int32))[0])
+        probs = out if out is not None else torch.empty((B, To, self.n_labels), dtype=torch.float32, device=feat.device)
+        out_lens = np.empty(B, dtype=np.int32)
+        self._check(lib().dsmi_forward(self._h, feat.data_ptr(), _np_ptr(lens), B, T, probs.data_ptr(),
+                                       _np_ptr(out_lens), self._stream()))
+        return probs, out_lens
+
+    def conv_stack(self, feat, lens):
+        import torch
+        B, T = feat.shape[0], feat.shape[-1]
+        lens = np.ascontiguousarray(lens, dtype=np.int32)
+        To = int(self.seq_lens(np.array([T], dtype=np.int32))[0])
+        from .synthetic import CONV_SPECS, conv_out_freq
+        cl = self.desc.conv_layers
+        n_freq = int(self.desc.sample_rate * self.desc.window_size) // 2 + 1
+        C_ = CONV_SPECS[cl - 1][1]
+        F_ = conv_out_freq(n_freq, cl)
+        out = torch.empty((B, C_, F_, To), dtype=torch.float32, device=feat.device)
+        self._check(lib().dsmi_conv_stack(self._h, feat.data_ptr(), _np_ptr(lens), B, T, out.data_ptr(), self._stream()))
+        return out
+
+    def rnn_layer(self, layer, x, out_lens):
+        """x: CUDA [T,B,I] -> [T,B,H] (one BatchRNN of the model)."""
+        import torch
+        T, B = x.shape[0], x.shape[1]
+        out_lens = np.ascontiguousarray(out_lens, dtype=np.int32)
+        y = torch.empty((T, B, self.desc.rnn_hidden_size), dtype=torch.float32, device=x.device)
+        self._check(lib().dsmi_rnn_layer(self._h, int(layer), x.data_ptr(), _np_ptr(out_lens), B, T, y.data_ptr(), self._stream()))
+        return y
+
+    def greedy(self, probs, sizes=None, blank_index=0):
+        """probs: CUDA [B,T,C] -> list of (ids, offsets) int32 arrays per utterance."""
+        B, T = probs.shape[0], probs.shape[1]
+        ids = np.empty((B, T), dtype=np.int32)
+        offs = np.empty((B, T), dtype=np.int32)
+        n = np.empty(B, dtype=np.int32)
+        sz = None if sizes is None else np.ascontiguousarray(sizes, dtype=np.int32)
+        self._check(lib().dsmi_greedy(self._h, probs.data_ptr(), None if sz is None else _np_ptr(sz), B, T,
+                                      int(blank_index), _np_ptr(ids), _np_ptr(offs), _np_ptr(n), self._stream()))
+        return [(ids[b, :n[b]].copy(), offs[b, :n[b]].copy()) for b in range(B)]
+
+    def set_profiling(self, on):
+        self._check(lib().dsmi_set_profiling(self._h, int(bool(on))))
+
+    def stage_time_us(self, stage):
+        return float(lib().dsmi_stage_time_us(self._h, int(stage)))
+
+    def last_forward_stats(self):
+        n = C.c_int64(); a = C.c_double(); b = C.c_double()
+        self._check(lib().dsmi_last_forward_stats(self._h, C.byref(n), C.byref(a), C.byref(b)))
+        return n.value, a.value, b.value

@@ -1,0 +1,510 @@
+// C ABI of libdsmi.so (see include/dsmi.h): handle lifecycle, weight repacking, workspace
+// management and the orchestration of the forward pass.  Host code only; kernels live in
+// conv.hip / gemm.hip / rnn_step.hip / head.hip / features.hip / beam.hip.
+#include "common.h"
+#include "model.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+using namespace dsmi;
+
+static thread_local std::string g_create_error;
+
+#define HIP_OK(m, expr)                                                                   \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            (m)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                 \
+            return DSMI_ERR_HIP;                                                          \
+        }                                                                                 \
+    } while (0)
+
+static int fail(dsmi_model* m, int code, const std::string& msg) {
+    m->err = msg;
+    return code;
+}
+
+// ------------------------------------------------------------------------------------------
+extern "C" int dsmi_model_create(const dsmi_model_desc* d, int device, dsmi_model** out) {
+    if (!d || !out) { g_create_error = "null argument"; return DSMI_ERR_INVALID; }
+    // reference model.py:344-348
+    if (d->conv_layers == 0) { g_create_error = "0 convolutional layers configuration not supported by DanSpeech"; return DSMI_ERR_CONV; }
+    if (d->conv_layers > 3 || d->conv_layers < 0) { g_create_error = "Maximum amount of convolutional layers supported by DanSpeech is 3"; return DSMI_ERR_CONV; }
+    if (d->rnn_type < 0 || d->rnn_type > 2 || d->rnn_hidden_size < 1 || d->rnn_layers < 1 || d->n_labels < 1 ||
+        d->n_labels > 128 || (!d->bidirectional && d->context < 1)) {
+        g_create_error = "invalid model description";
+        return DSMI_ERR_INVALID;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+        g_create_error = "no such HIP device";
+        return DSMI_ERR_HIP;
+    }
+    dsmi_model* m = new dsmi_model();
+    m->desc = *d;
+    m->device = device;
+    m->n_fft = (int)(d->sample_rate * d->window_size);      // parsers.py:47
+    m->hop = (int)(d->sample_rate * d->window_stride);      // parsers.py:48
+    m->n_freq = m->n_fft / 2 + 1;                            // model.py:354
+    int f = m->n_freq;
+    for (int l = 0; l < d->conv_layers; ++l) {
+        const ConvSpec& s = kConvSpecs[l];
+        m->conv_fi[l] = f;
+        f = (f + 2 * s.pf - s.kf) / s.sf + 1;
+        m->conv_fo[l] = f;
+    }
+    m->I0 = kConvSpecs[d->conv_layers - 1].co * f;           // model.py:365,379,396
+    m->geom = make_rnn_geom(d->rnn_type, d->rnn_hidden_size, d->bidirectional ? 2 : 1);
+    m->Hs = m->geom.Kp;
+    m->rnn.resize(d->rnn_layers);
+    *out = m;
+    return DSMI_OK;
+}
+
+extern "C" const char* dsmi_last_error(const dsmi_model* m) { return m ? m->err.c_str() : g_create_error.c_str(); }
+
+extern "C" int dsmi_model_load_tensor(dsmi_model* m, const char* name, const float* data, const int64_t* shape, int ndim) {
+    if (!m || !name || !data || ndim < 0 || ndim > 4) return m ? fail(m, DSMI_ERR_INVALID, "bad tensor argument") : DSMI_ERR_INVALID;
+    if (m->finalized) return fail(m, DSMI_ERR_INVALID, "model already finalized");
+    HostTensor t;
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
+    t.data.assign(data, data + n);
+    m->tensors[name] = std::move(t);
+    return DSMI_OK;
+}
+
+static const HostTensor* need(dsmi_model* m, const std::string& name, std::initializer_list<int64_t> shape) {
+    auto it = m->tensors.find(name);
+    if (it == m->tensors.end()) { m->err = "missing tensor " + name; return nullptr; }
+    if (it->second.shape != std::vector<int64_t>(shape)) { m->err = "bad shape for tensor " + name; return nullptr; }
+    return &it->second;
+}
+
+template <typename T>
+static int upload(dsmi_model* m, const std::vector<T>& h, T** dev) {
+    HIP_OK(m, hipMalloc((void**)dev, std::max<size_t>(h.size(), 1) * sizeof(T)));
+    m->owned.push_back(*dev);
+    if (!h.empty()) HIP_OK(m, hipMemcpy(*dev, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return DSMI_OK;
+}
+
+// eval-mode BatchNorm as y = x*a + b, computed as ATen's CPU kernel does:
+// invstd = 1/sqrt(var+eps); a = weight*invstd; b = bias - mean*a.
+static bool bn_affine(dsmi_model* m, const std::string& prefix, int n, int n_pad, std::vector<float>& a, std::vector<float>& b) {
+    const HostTensor *w = need(m, prefix + ".weight", {n}), *bi = need(m, prefix + ".bias", {n}),
+                     *mu = need(m, prefix + ".running_mean", {n}), *var = need(m, prefix + ".running_var", {n});
+    if (!w || !bi || !mu || !var) return false;
+    a.assign(n_pad, 0.f); b.assign(n_pad, 0.f);
+    for (int i = 0; i < n; ++i) {
+        const float invstd = 1.f / std::sqrt(var->data[i] + 1e-5f);
+        a[i] = w->data[i] * invstd;
+        b[i] = bi->data[i] - mu->data[i] * a[i];
+    }
+    return true;
+}
+
+extern "C" int dsmi_model_finalize(dsmi_model* m) {
+    if (!m) return DSMI_ERR_INVALID;
+    if (m->finalized) return DSMI_OK;
+    HIP_OK(m, hipSetDevice(m->device));
+    const dsmi_model_desc& d = m->desc;
+    const RnnGeom& g = m->geom;
+    const int H = d.rnn_hidden_size, G = g.G;
+    // ---- conv stack
+    for (int l = 0; l < d.conv_layers; ++l) {
+        const ConvSpec& s = kConvSpecs[l];
+        const std::string p = "conv.seq_module." + std::to_string(3 * l);
+        const HostTensor* w = need(m, p + ".weight", {s.co, s.ci, s.kf, s.kt});
+        const HostTensor* b = need(m, p + ".bias", {s.co});
+        std::vector<float> a, bb;
+        if (!w || !b || !bn_affine(m, "conv.seq_module." + std::to_string(3 * l + 1), s.co, s.co, a, bb)) return DSMI_ERR_NOT_READY;
+        int rc;
+        if ((rc = upload(m, pack_conv_weights(w->data.data(), l), &m->conv[l].wp))) return rc;
+        if ((rc = upload(m, b->data, &m->conv[l].bias))) return rc;
+        if ((rc = upload(m, a, &m->conv[l].bn_a))) return rc;
+        if ((rc = upload(m, bb, &m->conv[l].bn_b))) return rc;
+    }
+    // ---- recurrent layers
+    for (int l = 0; l < d.rnn_layers; ++l) {
+        RnnW& r = m->rnn[l];
+        const int I = l == 0 ? m->I0 : H;
+        r.K = l == 0 ? I : m->Hs;
+        r.ldw = round_up(r.K, 4);
+        std::vector<float> wih((size_t)g.Np * r.ldw, 0.f), bih(g.Np, 0.f);
+        const std::string p = "rnns." + std::to_string(l) + ".rnn.";
+        const HostTensor *wi[2], *wh[2], *bi[2], *bh[2];
+        for (int dd = 0; dd < g.D; ++dd) {
+            const std::string sfx = dd ? "_reverse" : "";
+            wi[dd] = need(m, p + "weight_ih_l0" + sfx, {G * H, I});
+            wh[dd] = need(m, p + "weight_hh_l0" + sfx, {G * H, H});
+            bi[dd] = need(m, p + "bias_ih_l0" + sfx, {G * H});
+            bh[dd] = need(m, p + "bias_hh_l0" + sfx, {G * H});
+            if (!wi[dd] || !wh[dd] || !bi[dd] || !bh[dd]) return DSMI_ERR_NOT_READY;
+        }
+        for (int col = 0; col < g.Np; ++col) {
+            int dd;
+            const int src = rnn_src_row(g, col, &dd);
+            if (src < 0) continue;
+            std::memcpy(&wih[(size_t)col * r.ldw], &wi[dd]->data[(size_t)src * I], sizeof(float) * I);
+            bih[col] = bi[dd]->data[src];
+        }
+        int rc;
+        if ((rc = upload(m, wih, &r.wih))) return rc;
+        if ((rc = upload(m, bih, &r.bih))) return rc;
+        for (int dd = 0; dd < g.D; ++dd) {
+            if ((rc = upload(m, pack_whh(g, wh[dd]->data.data()), &r.whh[dd]))) return rc;
+            if ((rc = upload(m, bh[dd]->data, &r.bhh[dd]))) return rc;
+        }
+        if (l > 0) {  // model.py:403-404: BatchNorm1d(H) in front of layers >= 1
+            std::vector<float> a, b;
+            if (!bn_affine(m, "rnns." + std::to_string(l) + ".batch_norm.module", H, m->Hs, a, b)) return DSMI_ERR_NOT_READY;
+            if ((rc = upload(m, a, &r.bn_a))) return rc;
+            if ((rc = upload(m, b, &r.bn_b))) return rc;
+        }
+    }
+    int rc;
+    if (!d.bidirectional) {
+        const HostTensor* lw = need(m, "lookahead.0.conv.weight", {H, 1, d.context});
+        if (!lw) return DSMI_ERR_NOT_READY;
+        if ((rc = upload(m, lw->data, &m->look_w))) return rc;
+    }
+    {
+        std::vector<float> a, b;
+        const HostTensor* fw = need(m, "fc.0.module.1.weight", {d.n_labels, H});
+        if (!fw || !bn_affine(m, "fc.0.module.0", H, m->Hs, a, b)) return DSMI_ERR_NOT_READY;
+        if ((rc = upload(m, a, &m->fc_a))) return rc;
+        if ((rc = upload(m, b, &m->fc_b))) return rc;
+        if ((rc = upload(m, pack_fc(fw->data.data(), d.n_labels, H), &m->fc_wp))) return rc;
+    }
+    if ((rc = features_init(m))) return rc;
+    m->tensors.clear();
+    for (int i = 0; i < 8; ++i) HIP_OK(m, hipEventCreate(&m->ev[i]));
+    m->finalized = true;
+    return DSMI_OK;
+}
+
+static int seq_len(const dsmi_model* m, int L) {  // model.py:540-551
+    for (int l = 0; l < m->desc.conv_layers; ++l) {
+        const ConvSpec& s = kConvSpecs[l];
+        L = (L + 2 * s.pt - (s.kt - 1) - 1) / s.st + 1;
+    }
+    return L;
+}
+
+extern "C" int dsmi_seq_lens(const dsmi_model* m, const int32_t* lens, int n, int32_t* out) {
+    if (!m || !lens || !out) return DSMI_ERR_INVALID;
+    for (int i = 0; i < n; ++i) out[i] = seq_len(m, lens[i]);
+    return DSMI_OK;
+}
+
+static void free_ws(dsmi_model* m) {
+    for (void* p : m->ws) (void)hipFree(p);
+    m->ws.clear();
+    m->cap_B = m->cap_T = 0;
+}
+
+template <typename T>
+static int ws_alloc(dsmi_model* m, T** p, size_t n) {
+    HIP_OK(m, hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(T)));
+    m->ws.push_back(*p);
+    return DSMI_OK;
+}
+
+extern "C" int dsmi_reserve(dsmi_model* m, int max_B, int max_T) {
+    if (!m || max_B < 1 || max_T < 1) return m ? fail(m, DSMI_ERR_INVALID, "bad reserve size") : DSMI_ERR_INVALID;
+    if (!m->finalized) return fail(m, DSMI_ERR_NOT_READY, "dsmi_model_finalize has not been called");
+    if (max_B <= m->cap_B && max_T <= m->cap_T) return DSMI_OK;
+    HIP_OK(m, hipSetDevice(m->device));
+    HIP_OK(m, hipDeviceSynchronize());
+    max_B = std::max(max_B, m->cap_B);
+    max_T = std::max(max_T, m->cap_T);
+    free_ws(m);
+    const dsmi_model_desc& d = m->desc;
+    const int To = seq_len(m, max_T);
+    const int ys = round_up(std::max(To, 1), 4);
+    size_t conv_max = 0;
+    for (int l = 0; l < d.conv_layers; ++l)
+        conv_max = std::max(conv_max, (size_t)max_B * kConvSpecs[l].co * m->conv_fo[l] * ys);
+    int rc;
+    if ((rc = ws_alloc(m, &m->conv_buf[0], conv_max))) return rc;
+    if ((rc = ws_alloc(m, &m->conv_buf[1], d.conv_layers > 1 ? conv_max : 1))) return rc;
+    const size_t rows = (size_t)To * max_B;
+    if ((rc = ws_alloc(m, &m->xp, rows * m->geom.Np))) return rc;
+    for (int i = 0; i < 2; ++i)
+        for (int dd = 0; dd < 2; ++dd) {
+            m->hbuf[i][dd] = nullptr;
+            if (dd < m->geom.D && (rc = ws_alloc(m, &m->hbuf[i][dd], rows * m->Hs))) return rc;
+        }
+    for (int dd = 0; dd < 2; ++dd) {
+        m->cst[dd] = nullptr;
+        if (d.rnn_type == DSMI_RNN_LSTM && dd < m->geom.D && (rc = ws_alloc(m, &m->cst[dd], (size_t)max_B * m->Hs))) return rc;
+    }
+    m->look_buf = nullptr;
+    if (!d.bidirectional && (rc = ws_alloc(m, &m->look_buf, rows * m->Hs))) return rc;
+    if ((rc = ws_alloc(m, &m->xin, rows * round_up(std::max(m->I0, m->Hs), 4)))) return rc;
+    if ((rc = ws_alloc(m, &m->lens_dev, (size_t)max_B))) return rc;
+    if ((rc = ws_alloc(m, &m->sizes_dev, (size_t)max_B))) return rc;
+    if ((rc = ws_alloc(m, &m->raw_ids, rows))) return rc;
+    if ((rc = ws_alloc(m, &m->ids, rows))) return rc;
+    if ((rc = ws_alloc(m, &m->offs, rows))) return rc;
+    if ((rc = ws_alloc(m, &m->nout, (size_t)max_B))) return rc;
+    m->cap_B = max_B;
+    m->cap_T = max_T;
+    return DSMI_OK;
+}
+
+extern "C" void dsmi_model_destroy(dsmi_model* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    (void)hipDeviceSynchronize();
+    free_ws(m);
+    for (void* p : m->owned) (void)hipFree(p);
+    if (m->finalized)
+        for (int i = 0; i < 8; ++i) (void)hipEventDestroy(m->ev[i]);
+    features_destroy(m);
+    delete m;
+}
+
+// ------------------------------------------------------------------------------------------
+static int check_batch(dsmi_model* m, const int32_t* lens, int B, int T) {
+    if (!m->finalized) return fail(m, DSMI_ERR_NOT_READY, "dsmi_model_finalize has not been called");
+    if (!lens || B < 1 || T < 1) return fail(m, DSMI_ERR_INVALID, "bad batch arguments");
+    for (int i = 0; i < B; ++i) {
+        if (lens[i] < 1 || lens[i] > T) return fail(m, DSMI_ERR_INVALID, "length outside 1..T");
+        // pack_padded_sequence(enforce_sorted=True), model.py:117
+        if (i && lens[i] > lens[i - 1]) return fail(m, DSMI_ERR_UNSORTED, "`lengths` array must be sorted in decreasing order");
+    }
+    return DSMI_OK;
+}
+
+static int run_conv(dsmi_model* m, const float* feat, int B, int T, int To, int ys, hipStream_t s, const float** out) {
+    const float* x = feat;
+    int ti = T, xs = T;
+    for (int l = 0; l < m->desc.conv_layers; ++l) {
+        const ConvSpec& sp = kConvSpecs[l];
+        ConvLaunch c;
+        c.x = x; c.y = m->conv_buf[l & 1]; c.wp = m->conv[l].wp; c.bias = m->conv[l].bias;
+        c.bn_a = m->conv[l].bn_a; c.bn_b = m->conv[l].bn_b; c.out_lens_dev = m->lens_dev;
+        c.B = B; c.ci = sp.ci; c.co = sp.co; c.fi = m->conv_fi[l]; c.fo = m->conv_fo[l];
+        c.ti = ti; c.to = To; c.xs = xs; c.ys = ys; c.layer = l;
+        launch_conv(c, s);
+        x = c.y; ti = To; xs = ys;
+    }
+    *out = x;
+    return DSMI_OK;
+}
+
+// One BatchRNN layer on the internal buffers: x-projection GEMM + To recurrent step launches.
+static void run_rnn_layer(dsmi_model* m, int l, const GemmLaunch& gl, int B, int To, int dst, hipStream_t s) {
+    launch_gemm(gl, s);
+    RnnStepLaunch st;
+    st.g = m->geom;
+    for (int dd = 0; dd < 2; ++dd) {
+        st.whh_packed[dd] = m->rnn[l].whh[dd]; st.bhh[dd] = m->rnn[l].bhh[dd];
+        st.out[dd] = m->hbuf[dst][dd]; st.cstate[dd] = m->cst[dd];
+    }
+    st.xp = m->xp; st.lens_dev = m->lens_dev; st.B = B; st.T = To;
+    if (m->profiling) (void)hipEventRecord(m->ev[6], s);
+    for (int step = 0; step < To; ++step) {
+        st.step = step;
+        launch_rnn_step(st, s);
+    }
+}
+
+static GemmLaunch xproj_gemm(dsmi_model* m, int l, int B, int To) {
+    GemmLaunch gl{};
+    const RnnW& r = m->rnn[l];
+    gl.w = r.wih; gl.bias = r.bih; gl.c = m->xp;
+    gl.M = To * B; gl.N = m->geom.Np; gl.K = r.K; gl.ldw = r.ldw; gl.ldc = m->geom.Np;
+    gl.B = B; gl.T = To;
+    return gl;
+}
+
+extern "C" int dsmi_forward(dsmi_model* m, const float* feat, const int32_t* lens, int B, int T, float* probs,
+                            int32_t* out_lens, void* stream) {
+    if (!m) return DSMI_ERR_INVALID;
+    int rc = check_batch(m, lens, B, T);
+    if (rc) return rc;
+    if (!feat || !probs || !out_lens) return fail(m, DSMI_ERR_INVALID, "null buffer");
+    if ((rc = dsmi_reserve(m, B, T))) return rc;
+    HIP_OK(m, hipSetDevice(m->device));
+    hipStream_t s = (hipStream_t)stream;
+    const dsmi_model_desc& d = m->desc;
+    const int To = seq_len(m, T), ys = round_up(To, 4);
+    for (int i = 0; i < B; ++i) out_lens[i] = seq_len(m, lens[i]);
+    HIP_OK(m, hipMemcpyAsync(m->lens_dev, out_lens, sizeof(int32_t) * B, hipMemcpyHostToDevice, s));
+    if (m->Hs != d.rnn_hidden_size)
+        for (int i = 0; i < 2; ++i)
+            for (int dd = 0; dd < m->geom.D; ++dd)
+                HIP_OK(m, hipMemsetAsync(m->hbuf[i][dd], 0, sizeof(float) * (size_t)To * B * m->Hs, s));
+
+    if (m->profiling) HIP_OK(m, hipEventRecord(m->ev[0], s));
+    const float* cx;
+    run_conv(m, feat, B, T, To, ys, s, &cx);
+    if (m->profiling) HIP_OK(m, hipEventRecord(m->ev[1], s));
+
+    for (int l = 0; l < d.rnn_layers; ++l) {
+        GemmLaunch gl = xproj_gemm(m, l, B, To);
+        if (l == 0) {
+            gl.mode = GEMM_A_CONV; gl.a = cx; gl.ys = ys;
+        } else {
+            gl.mode = GEMM_A_SUM_BN;
+            gl.a = m->hbuf[(l - 1) & 1][0]; gl.a2 = m->geom.D == 2 ? m->hbuf[(l - 1) & 1][1] : nullptr;
+            gl.alpha = m->rnn[l].bn_a; gl.beta = m->rnn[l].bn_b; gl.lda = m->Hs;
+        }
+        run_rnn_layer(m, l, gl, B, To, l & 1, s);
+    }
+    if (m->profiling) HIP_OK(m, hipEventRecord(m->ev[2], s));
+    const int last = (d.rnn_layers - 1) & 1;
+    HeadLaunch h;
+    h.bn_a = m->fc_a; h.bn_b = m->fc_b; h.w_packed = m->fc_wp; h.H = d.rnn_hidden_size; h.C = d.n_labels;
+    h.T = To; h.B = B; h.probs = probs;
+    if (!d.bidirectional) {   // model.py:508-509
+        launch_lookahead(m->hbuf[last][0], m->look_w, m->look_buf, To, B, d.rnn_hidden_size, d.context, s);
+        h.x1 = m->look_buf; h.x2 = nullptr;
+    } else {
+        h.x1 = m->hbuf[last][0]; h.x2 = m->hbuf[last][1];
+    }
+    launch_head(h, s);
+    if (m->profiling) HIP_OK(m, hipEventRecord(m->ev[3], s));
+    HIP_OK(m, hipGetLastError());
+
+    // bookkeeping for roofline maths: recurrent and total algorithmic FLOPs
+    m->n_step_launches = (int64_t)To * d.rnn_layers;
+    double rec = 0, tot = 0;
+    for (int i = 0; i < B; ++i) {
+        const double t = out_lens[i];
+        double conv = 0;
+        for (int l = 0; l < d.conv_layers; ++l) {
+            const ConvSpec& sp = kConvSpecs[l];
+            conv += (double)sp.co * m->conv_fo[l] * t * sp.ci * sp.kf * sp.kt;
+        }
+        const double H = d.rnn_hidden_size, G = m->geom.G, D = m->geom.D;
+        double r = 0, ip = 0;
+        for (int l = 0; l < d.rnn_layers; ++l) {
+            r += D * t * G * H * H;
+            ip += D * t * G * H * (l == 0 ? m->I0 : H);
+        }
+        rec += 2 * r;
+        tot += 2 * (conv + r + ip + t * H * d.n_labels);
+    }
+    m->step_flops = rec;
+    m->total_flops = tot;
+    if (m->profiling) {
+        HIP_OK(m, hipStreamSynchronize(s));
+        float ms;
+        HIP_OK(m, hipEventElapsedTime(&ms, m->ev[0], m->ev[1])); m->stage_us[0] = ms * 1e3;
+        HIP_OK(m, hipEventElapsedTime(&ms, m->ev[1], m->ev[2])); m->stage_us[2] = ms * 1e3;  // GEMMs + steps
+        HIP_OK(m, hipEventElapsedTime(&ms, m->ev[2], m->ev[3])); m->stage_us[3] = ms * 1e3;
+        HIP_OK(m, hipEventElapsedTime(&ms, m->ev[0], m->ev[3])); m->stage_us[4] = ms * 1e3;
+        m->stage_us[1] = 0;
+    }
+    return DSMI_OK;
+}
+
+extern "C" int dsmi_conv_stack(dsmi_model* m, const float* feat, const int32_t* lens, int B, int T, float* out, void* stream) {
+    if (!m) return DSMI_ERR_INVALID;
+    int rc = check_batch(m, lens, B, T);
+    if (rc) return rc;
+    if ((rc = dsmi_reserve(m, B, T))) return rc;
+    HIP_OK(m, hipSetDevice(m->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int To = seq_len(m, T), ys = round_up(To, 4);
+    std::vector<int32_t> ol(B);
+    for (int i = 0; i < B; ++i) ol[i] = seq_len(m, lens[i]);
+    HIP_OK(m, hipMemcpyAsync(m->lens_dev, ol.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice, s));
+    const float* cx;
+    run_conv(m, feat, B, T, To, ys, s, &cx);
+    // strip the time-stride padding: [B][C*F][ys] -> [B][C*F][To]
+    const int cl = m->desc.conv_layers - 1;
+    const size_t rows = (size_t)B * kConvSpecs[cl].co * m->conv_fo[cl];
+    HIP_OK(m, hipMemcpy2DAsync(out, sizeof(float) * To, cx, sizeof(float) * ys, sizeof(float) * To, rows, hipMemcpyDeviceToDevice, s));
+    HIP_OK(m, hipStreamSynchronize(s));
+    HIP_OK(m, hipGetLastError());
+    return DSMI_OK;
+}
+
+extern "C" int dsmi_rnn_layer(dsmi_model* m, int layer, const float* x, const int32_t* out_lens, int B, int To, float* y, void* stream) {
+    if (!m) return DSMI_ERR_INVALID;
+    if (!m->finalized) return fail(m, DSMI_ERR_NOT_READY, "dsmi_model_finalize has not been called");
+    if (layer < 0 || layer >= m->desc.rnn_layers || !x || !y || !out_lens || B < 1 || To < 1) return fail(m, DSMI_ERR_INVALID, "bad rnn_layer arguments");
+    for (int i = 0; i < B; ++i) {
+        if (out_lens[i] < 1 || out_lens[i] > To) return fail(m, DSMI_ERR_INVALID, "length outside 1..T");
+        if (i && out_lens[i] > out_lens[i - 1]) return fail(m, DSMI_ERR_UNSORTED, "`lengths` array must be sorted in decreasing order");
+    }
+    // workspaces are sized by input frames; find a T whose seq_len covers To
+    int Tin = To;
+    while (seq_len(m, Tin) < To) Tin += 1;
+    int rc;
+    if ((rc = dsmi_reserve(m, B, Tin))) return rc;
+    HIP_OK(m, hipSetDevice(m->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int H = m->desc.rnn_hidden_size;
+    HIP_OK(m, hipMemcpyAsync(m->lens_dev, out_lens, sizeof(int32_t) * B, hipMemcpyHostToDevice, s));
+    for (int dd = 0; dd < m->geom.D; ++dd)
+        HIP_OK(m, hipMemsetAsync(m->hbuf[0][dd], 0, sizeof(float) * (size_t)To * B * m->Hs, s));
+    const RnnW& r = m->rnn[layer];
+    const int I = layer == 0 ? m->I0 : H;
+    launch_pad_rows(x, m->xin, (size_t)To * B, I, r.ldw, s);
+    GemmLaunch gl = xproj_gemm(m, layer, B, To);
+    if (layer == 0) {
+        gl.mode = GEMM_A_ROWMAJOR; gl.a = m->xin; gl.lda = r.ldw;
+    } else {
+        gl.mode = GEMM_A_SUM_BN; gl.a = m->xin; gl.a2 = nullptr; gl.alpha = r.bn_a; gl.beta = r.bn_b; gl.lda = r.ldw;
+    }
+    run_rnn_layer(m, layer, gl, B, To, 0, s);
+    launch_add2(m->hbuf[0][0], m->geom.D == 2 ? m->hbuf[0][1] : nullptr, y, (size_t)To * B, H, m->Hs, s);
+    HIP_OK(m, hipStreamSynchronize(s));
+    HIP_OK(m, hipGetLastError());
+    return DSMI_OK;
+}
+
+extern "C" int dsmi_greedy(dsmi_model* m, const float* probs, const int32_t* sizes, int B, int To, int blank,
+                           int32_t* ids, int32_t* offsets, int32_t* n_out, void* stream) {
+    if (!m) return DSMI_ERR_INVALID;
+    if (!m->finalized) return fail(m, DSMI_ERR_NOT_READY, "dsmi_model_finalize has not been called");
+    if (!probs || !ids || !offsets || !n_out || B < 1 || To < 1) return fail(m, DSMI_ERR_INVALID, "bad greedy arguments");
+    HIP_OK(m, hipSetDevice(m->device));
+    hipStream_t s = (hipStream_t)stream;
+    // scratch independent of dsmi_reserve (probs may come from anywhere)
+    if ((size_t)B * To > m->greedy_cap) {
+        HIP_OK(m, hipDeviceSynchronize());
+        for (void* p : {(void*)m->g_raw, (void*)m->g_ids, (void*)m->g_offs, (void*)m->g_nout, (void*)m->g_sizes}) if (p) (void)hipFree(p);
+        m->greedy_cap = (size_t)B * To;
+        HIP_OK(m, hipMalloc((void**)&m->g_raw, sizeof(int32_t) * m->greedy_cap));
+        HIP_OK(m, hipMalloc((void**)&m->g_ids, sizeof(int32_t) * m->greedy_cap));
+        HIP_OK(m, hipMalloc((void**)&m->g_offs, sizeof(int32_t) * m->greedy_cap));
+        HIP_OK(m, hipMalloc((void**)&m->g_nout, sizeof(int32_t) * m->greedy_cap));
+        HIP_OK(m, hipMalloc((void**)&m->g_sizes, sizeof(int32_t) * m->greedy_cap));
+    }
+    if (sizes) HIP_OK(m, hipMemcpyAsync(m->g_sizes, sizes, sizeof(int32_t) * B, hipMemcpyHostToDevice, s));
+    launch_greedy(probs, sizes ? m->g_sizes : nullptr, B, To, m->desc.n_labels, blank, m->g_raw, m->g_ids, m->g_offs, m->g_nout, s);
+    HIP_OK(m, hipMemcpyAsync(ids, m->g_ids, sizeof(int32_t) * (size_t)B * To, hipMemcpyDeviceToHost, s));
+    HIP_OK(m, hipMemcpyAsync(offsets, m->g_offs, sizeof(int32_t) * (size_t)B * To, hipMemcpyDeviceToHost, s));
+    HIP_OK(m, hipMemcpyAsync(n_out, m->g_nout, sizeof(int32_t) * B, hipMemcpyDeviceToHost, s));
+    HIP_OK(m, hipStreamSynchronize(s));
+    HIP_OK(m, hipGetLastError());
+    return DSMI_OK;
+}
+
+extern "C" int dsmi_set_profiling(dsmi_model* m, int on) {
+    if (!m) return DSMI_ERR_INVALID;
+    m->profiling = on != 0;
+    return DSMI_OK;
+}
+
+extern "C" double dsmi_stage_time_us(const dsmi_model* m, int stage) {
+    if (!m || stage < 0 || stage > 4) return -1.0;
+    return m->stage_us[stage];
+}
+
+extern "C" int dsmi_last_forward_stats(const dsmi_model* m, int64_t* n_step, double* step_flops, double* total_flops) {
+    if (!m) return DSMI_ERR_INVALID;
+    if (n_step) *n_step = m->n_step_launches;
+    if (step_flops) *step_flops = m->step_flops;
+    if (total_flops) *total_flops = m->total_flops;
+    return DSMI_OK;
+}

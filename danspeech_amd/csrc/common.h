@@ -1,0 +1,111 @@
+// Internal declarations shared by the libdsmi translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+#include <map>
+
+#include "../../include/dsmi.h"
+
+namespace dsmi {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int kWave = 64;  // gfx950 wavefront
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
+
+// ---- conv geometry: reference model.py:359,372,389 ------------------------------
+struct ConvSpec { int ci, co, kf, kt, sf, st, pf, pt; };
+static const ConvSpec kConvSpecs[3] = {
+    {1, 32, 41, 11, 2, 2, 20, 5},
+    {32, 32, 21, 11, 2, 1, 10, 5},
+    {32, 96, 21, 11, 2, 1, 10, 5},
+};
+
+// ---- launch wrappers (one per .hip file) ----------------------------------------
+
+// conv.hip: fused Conv2d + bias + BatchNorm2d(eval) + Hardtanh(0,20) + time mask.
+//   x  [B][ci][fi][xs]      (xs = time stride of the input rows)
+//   y  [B][co][fo][ys]
+//   wp packed weights (see pack_conv_weights), bias/bn_a/bn_b [co]
+//   out_lens_dev[B]: output frames t >= out_lens[b] are written as 0.
+struct ConvLaunch {
+    const float* x; float* y; const float* wp; const float* bias; const float* bn_a; const float* bn_b;
+    const int32_t* out_lens_dev;
+    int B, ci, co, fi, fo, ti, to, xs, ys, layer;  // layer index selects the compile-time geometry
+};
+void launch_conv(const ConvLaunch& p, hipStream_t s);
+// Host-side weight packer: w [co][ci][kf][kt] -> kernel layout. Returns packed floats.
+std::vector<float> pack_conv_weights(const float* w, int layer);
+
+// gemm.hip: C[m][n] = sum_k A[m][k] * W[n][k] + bias[n]   (fp32 MFMA 32x32x2)
+enum GemmAMode {
+    GEMM_A_ROWMAJOR = 0,   // A [M][K] row-major
+    GEMM_A_SUM_BN = 1,     // A = (A1[m][k] + A2[m][k]) * alpha[k] + beta[k]   (A2 may be null)
+    GEMM_A_CONV = 2        // A[(b,t)][k] = Y[b][k][t]  (conv layout, time stride ys); C row = t*B + b
+};
+struct GemmLaunch {
+    int mode;
+    const float* a; const float* a2; const float* alpha; const float* beta;
+    const float* w; const float* bias; float* c;
+    int M, N, K;       // N, K as stored (W is [N][K] row-major, K % 4 == 0 guaranteed by packing)
+    int lda, ldw, ldc;
+    int B, T, ys;      // GEMM_A_CONV: batch, frames per clip, time stride
+};
+void launch_gemm(const GemmLaunch& p, hipStream_t s);
+
+// rnn_step.hip: one time step of both directions of one recurrent layer.
+struct RnnGeom {
+    int kind;      // DSMI_RNN_*
+    int G;         // gates per unit: 3 / 4 / 1
+    int H;
+    int U;         // hidden units per workgroup: floor(32 / G)
+    int nwg;       // ceil(H / U) workgroups per direction
+    int Kp;        // H rounded up to 8
+    int nq;        // Kp / 8 k-blocks
+    int D;         // directions
+    int Np;        // D * nwg * G * U : permuted + padded gate columns of the x-projection
+};
+RnnGeom make_rnn_geom(int kind, int H, int D);
+// Row r of the packed x-projection weight / bias  <->  (dir, gate, unit) of torch's [G*H][I].
+// returns -1 for padding rows.
+int rnn_src_row(const RnnGeom& g, int packed_col, int* dir_out);
+// w_hh [G*H][H] (torch layout) for one direction -> packed MFMA operand stream.
+std::vector<float> pack_whh(const RnnGeom& g, const float* w_hh);
+struct RnnStepLaunch {
+    RnnGeom g;
+    const float* whh_packed[2];  // per direction
+    const float* bhh[2];         // per direction, torch layout [G*H]
+    const float* xp;             // [T][B][Np]
+    float* out[2];               // per direction [T][B][H]
+    float* cstate[2];            // LSTM cell state [B][H] per direction (else null)
+    const int32_t* lens_dev;     // [B] output lengths
+    int B, T, step;
+};
+void launch_rnn_step(const RnnStepLaunch& p, hipStream_t s);
+
+// head.hip
+//   lookahead: y[t][b][h] = clip(sum_k w[h][k] * x[t+k][b][h], 0, 20)
+void launch_lookahead(const float* x, const float* w, float* y, int T, int B, int H, int context, hipStream_t s);
+//   FC head: probs[b][t][c] = softmax_c( W[c][:] . ((x1[t][b][:] + x2[t][b][:]) * a + b) )
+struct HeadLaunch {
+    const float* x1; const float* x2; const float* bn_a; const float* bn_b;
+    const float* w_packed; int H, C, T, B; float* probs;
+};
+std::vector<float> pack_fc(const float* w, int C, int H);
+void launch_head(const HeadLaunch& p, hipStream_t s);
+//   greedy: argmax + CTC collapse, one workgroup per utterance
+//   raw: [B][T] scratch for the per-frame argmax
+void launch_greedy(const float* probs, const int32_t* sizes_dev, int B, int T, int C, int blank,
+                   int32_t* raw, int32_t* ids, int32_t* offsets, int32_t* n_out, hipStream_t s);
+//   y[r][h] = a[r][h] (+ b[r][h]) for h < H, inputs with row stride Hs (stage-level API only)
+void launch_add2(const float* a, const float* b, float* y, size_t rows, int H, int Hs, hipStream_t s);
+//   y[r][0..Is) = x[r][0..I) zero-padded
+void launch_pad_rows(const float* x, float* y, size_t rows, int I, int Is, hipStream_t s);
+
+}  // namespace dsmi

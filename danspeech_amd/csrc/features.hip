@@ -1,0 +1,195 @@
+// Batched spectrogram front end on the GPU (gfx950).
+//
+// Replaces SpectrogramAudioParser.parse_audio (reference danspeech/audio/parsers.py:50-72):
+//   D = librosa.stft(y, n_fft, hop, win_length=n_fft, window=scipy window, center=True)
+//   spect = log1p(|D|)  ->  (spect - mean) / std       (torch mean / unbiased std over F*T)
+// librosa computes the rFFT of the float64 windowed frame in float64 and stores complex64;
+// |.| and log1p then run in float32.  The kernel keeps that precision ladder: the DFT sums
+// are float64 (direct O(n_fft^2) DFT against a host-computed float64 twiddle table: 161 bins
+// x 320 taps, far below an FFT's break-even on this machine and free of any library), the
+// real/imaginary parts are rounded to float32, then hypotf and log1pf.
+// Mean and unbiased std are accumulated in float64 per clip (two passes, fixed order).
+#include "common.h"
+#include "model.h"
+
+#include <cmath>
+
+using namespace dsmi;
+
+struct FeatState {
+    double* tw = nullptr;    // [n_fft][2] cos, sin
+    double* win = nullptr;   // [n_fft]
+    int64_t* offs = nullptr; // device: per-clip sample offset, n_samples  [2][cap]
+    int32_t* frames = nullptr;
+    int cap = 0;
+};
+
+namespace {
+
+constexpr int FT = 8;   // frames per workgroup
+
+template <typename T> __device__ __forceinline__ double ld(const void* p, int64_t i) { return (double)((const T*)p)[i]; }
+
+__global__ __launch_bounds__(256) void stft_logmag_kernel(const void* pcm, int dtype, const int64_t* offs, const int64_t* nsamp,
+                                                          const double* tw, const double* win, int n_fft, int hop, int n_freq,
+                                                          int pad_mode, float* feat, int t_stride) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double* s_tw = sm;                 // [n_fft][2]
+    double* s_x = sm + 2 * n_fft;      // [n_fft][FT]  (frame fastest: one broadcast b128-friendly row per tap)
+    const int b = blockIdx.y, t0 = blockIdx.x * FT, tid = threadIdx.x;
+    const int64_t N = nsamp[b], off = offs[b];
+    const int nfr = 1 + (int)(N / hop);
+    if (t0 >= nfr) return;
+    for (int i = tid; i < 2 * n_fft; i += 256) s_tw[i] = tw[i];
+    const int half = n_fft / 2;
+    for (int i = tid; i < n_fft * FT; i += 256) {
+        const int f = i % FT, n = i / FT;
+        const int t = t0 + f;
+        double v = 0.0;
+        if (t < nfr) {
+            int64_t s = (int64_t)t * hop + n - half;
+            bool ok = true;
+            if (s < 0) { if (pad_mode == DSMI_PAD_REFLECT) s = -s; else ok = false; }
+            else if (s >= N) { if (pad_mode == DSMI_PAD_REFLECT) s = 2 * (N - 1) - s; else ok = false; }
+            if (ok) {
+                v = dtype == DSMI_PCM_I16 ? ld<int16_t>(pcm, off + s) : (dtype == DSMI_PCM_F32 ? ld<float>(pcm, off + s) : ld<double>(pcm, off + s));
+                v *= win[n];
+            }
+        }
+        s_x[i] = v;
+    }
+    __syncthreads();
+    for (int k = tid; k < n_freq; k += 256) {
+        double re[FT], im[FT];
+#pragma unroll
+        for (int f = 0; f < FT; ++f) { re[f] = 0.0; im[f] = 0.0; }
+        int idx = 0;
+        for (int n = 0; n < n_fft; ++n) {
+            const double c = s_tw[2 * idx], s = s_tw[2 * idx + 1];
+#pragma unroll
+            for (int f = 0; f < FT; ++f) {
+                const double x = s_x[n * FT + f];
+                re[f] = fma(x, c, re[f]);
+                im[f] = fma(-x, s, im[f]);
+            }
+            idx += k;
+            if (idx >= n_fft) idx -= n_fft;
+        }
+#pragma unroll
+        for (int f = 0; f < FT; ++f) {
+            const int t = t0 + f;
+            if (t < nfr) feat[((size_t)b * n_freq + k) * t_stride + t] = log1pf(hypotf((float)re[f], (float)im[f]));
+        }
+    }
+}
+
+__device__ double block_sum(double v, double* sh) {
+    const int tid = threadIdx.x;
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((tid & 63) == 0) sh[tid >> 6] = v;
+    __syncthreads();
+    double tot = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += sh[w];
+    return tot;
+}
+
+// one workgroup per clip: mean, unbiased std, normalise in place, zero the tail frames
+__global__ __launch_bounds__(1024) void normalize_kernel(float* feat, const int64_t* nsamp, int hop, int n_freq, int t_stride, int normalize) {
+    __shared__ double sh[16];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int nfr = 1 + (int)(nsamp[b] / hop);
+    float* fb = feat + (size_t)b * n_freq * t_stride;
+    const int total = n_freq * t_stride;
+    if (normalize) {
+        double s = 0.0;
+        for (int i = tid; i < total; i += 1024) if (i % t_stride < nfr) s += (double)fb[i];
+        const double cnt = (double)n_freq * nfr;
+        const double mean = block_sum(s, sh) / cnt;
+        double q = 0.0;
+        for (int i = tid; i < total; i += 1024) if (i % t_stride < nfr) { const double dlt = (double)fb[i] - mean; q += dlt * dlt; }
+        const double var = block_sum(q, sh) / (cnt - 1.0);
+        const float meanf = (float)mean, stdf = (float)sqrt(var);
+        for (int i = tid; i < total; i += 1024) fb[i] = (i % t_stride < nfr) ? (fb[i] - meanf) / stdf : 0.f;
+    } else {
+        for (int i = tid; i < total; i += 1024) if (i % t_stride >= nfr) fb[i] = 0.f;
+    }
+}
+
+}  // namespace
+
+int features_init(dsmi_model* m) {
+    FeatState* f = new FeatState();
+    m->feat = f;
+    const int n = m->n_fft;
+    if (n < 2) return DSMI_OK;   // degenerate audio_conf: features unavailable, forward still usable
+    std::vector<double> tw(2 * (size_t)n), win(n);
+    const double pi = 3.14159265358979323846;
+    for (int j = 0; j < n; ++j) { tw[2 * j] = std::cos(2.0 * pi * j / n); tw[2 * j + 1] = std::sin(2.0 * pi * j / n); }
+    for (int j = 0; j < n; ++j) {   // scipy.signal.windows.* with sym=True (parsers.py:9-10, 27: a callable window)
+        const double x = n > 1 ? (double)j / (n - 1) : 0.0;
+        switch (m->desc.window) {
+            case DSMI_WIN_HANN: win[j] = 0.5 - 0.5 * std::cos(2 * pi * x); break;
+            case DSMI_WIN_BLACKMAN: win[j] = 0.42 - 0.5 * std::cos(2 * pi * x) + 0.08 * std::cos(4 * pi * x); break;
+            case DSMI_WIN_BARTLETT: win[j] = 1.0 - std::fabs(2.0 * x - 1.0); break;
+            default: win[j] = 0.54 - 0.46 * std::cos(2 * pi * x); break;
+        }
+    }
+    if (hipMalloc((void**)&f->tw, sizeof(double) * tw.size()) != hipSuccess ||
+        hipMalloc((void**)&f->win, sizeof(double) * win.size()) != hipSuccess ||
+        hipMemcpy(f->tw, tw.data(), sizeof(double) * tw.size(), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(f->win, win.data(), sizeof(double) * win.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        m->err = "features_init: HIP allocation failed";
+        return DSMI_ERR_HIP;
+    }
+    return DSMI_OK;
+}
+
+void features_destroy(dsmi_model* m) {
+    if (!m->feat) return;
+    FeatState* f = m->feat;
+    if (f->tw) (void)hipFree(f->tw);
+    if (f->win) (void)hipFree(f->win);
+    if (f->offs) (void)hipFree(f->offs);
+    delete f;
+    m->feat = nullptr;
+}
+
+extern "C" int dsmi_features(dsmi_model* m, const void* pcm, int dtype, const int64_t* n_samples, int B, float* feat,
+                             int t_stride, int32_t* frames, void* stream) {
+    if (!m) return DSMI_ERR_INVALID;
+    auto bad = [&](int code, const char* msg) { m->err = msg; return code; };
+    if (!m->finalized) return bad(DSMI_ERR_NOT_READY, "dsmi_model_finalize has not been called");
+    if (!pcm || !n_samples || !feat || B < 1 || dtype < 0 || dtype > 2) return bad(DSMI_ERR_INVALID, "bad features arguments");
+    if (m->n_fft < 2 || m->hop < 1) return bad(DSMI_ERR_INVALID, "audio_conf gives n_fft < 2");
+    FeatState* f = m->feat;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipSetDevice(m->device) != hipSuccess) return bad(DSMI_ERR_HIP, "hipSetDevice failed");
+    std::vector<int64_t> host(2 * (size_t)B);
+    int64_t off = 0;
+    int maxfr = 0;
+    for (int b = 0; b < B; ++b) {
+        const int64_t N = n_samples[b];
+        if (N < 1) return bad(DSMI_ERR_INVALID, "empty clip");
+        if (m->desc.pad_mode == DSMI_PAD_REFLECT && N <= m->n_fft / 2) return bad(DSMI_ERR_INVALID, "clip shorter than the reflect padding (n_fft/2)");
+        host[b] = off; host[B + b] = N; off += N;
+        const int nf = 1 + (int)(N / m->hop);
+        if (nf > t_stride) return bad(DSMI_ERR_INVALID, "t_stride smaller than a clip's frame count");
+        if (frames) frames[b] = nf;
+        maxfr = std::max(maxfr, nf);
+    }
+    if (B > f->cap) {
+        if (f->offs) { (void)hipStreamSynchronize(s); (void)hipFree(f->offs); }
+        if (hipMalloc((void**)&f->offs, sizeof(int64_t) * 2 * B) != hipSuccess) return bad(DSMI_ERR_NOMEM, "hipMalloc failed");
+        f->cap = B;
+    }
+    if (hipMemcpyAsync(f->offs, host.data(), sizeof(int64_t) * B, hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(f->offs + f->cap, host.data() + B, sizeof(int64_t) * B, hipMemcpyHostToDevice, s) != hipSuccess)
+        return bad(DSMI_ERR_HIP, "hipMemcpyAsync failed");
+    const size_t lds = sizeof(double) * ((size_t)2 * m->n_fft + (size_t)m->n_fft * FT);
+    hipLaunchKernelGGL(stft_logmag_kernel, dim3(ceil_div(maxfr, FT), B), dim3(256), lds, s, pcm, dtype, f->offs, f->offs + f->cap,
+                       f->tw, f->win, m->n_fft, m->hop, m->n_freq, m->desc.pad_mode, feat, t_stride);
+    hipLaunchKernelGGL(normalize_kernel, dim3(B), dim3(1024), 0, s, feat, f->offs + f->cap, m->hop, m->n_freq, t_stride, m->desc.normalize);
+    if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) return bad(DSMI_ERR_HIP, "feature kernels failed");
+    return DSMI_OK;
+}

@@ -1,0 +1,70 @@
+// The opaque handle behind dsmi_model* (include/dsmi.h).
+#pragma once
+#include "common.h"
+
+struct HostTensor {
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+};
+
+struct ConvW { float *wp = nullptr, *bias = nullptr, *bn_a = nullptr, *bn_b = nullptr; };
+
+struct RnnW {
+    float* wih = nullptr;   // [Np][ldw] gate-permuted (see rnn_src_row), zero padded
+    float* bih = nullptr;   // [Np]
+    float* whh[2] = {nullptr, nullptr};  // packed MFMA operand stream per direction
+    float* bhh[2] = {nullptr, nullptr};  // torch layout [G*H]
+    float* bn_a = nullptr;  // [Hs] BatchNorm1d in front of layers >= 1
+    float* bn_b = nullptr;
+    int K = 0, ldw = 0;
+};
+
+struct FeatState;   // features.hip
+
+struct dsmi_model {
+    dsmi_model_desc desc{};
+    int device = 0;
+    bool finalized = false;
+    std::string err;
+    std::map<std::string, HostTensor> tensors;
+
+    // geometry
+    int n_fft = 0, hop = 0, n_freq = 0;
+    int conv_fi[3] = {0, 0, 0}, conv_fo[3] = {0, 0, 0};
+    int I0 = 0, Hs = 0;
+    dsmi::RnnGeom geom{};
+
+    // weights (device)
+    ConvW conv[3];
+    std::vector<RnnW> rnn;
+    float* look_w = nullptr;
+    float *fc_a = nullptr, *fc_b = nullptr, *fc_wp = nullptr;
+    std::vector<void*> owned;
+
+    // workspaces (device), sized by dsmi_reserve
+    int cap_B = 0, cap_T = 0;
+    std::vector<void*> ws;
+    float* conv_buf[2] = {nullptr, nullptr};
+    float* xp = nullptr;
+    float* hbuf[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    float* cst[2] = {nullptr, nullptr};
+    float* look_buf = nullptr;
+    float* xin = nullptr;
+    int32_t *lens_dev = nullptr, *sizes_dev = nullptr, *raw_ids = nullptr, *ids = nullptr, *offs = nullptr, *nout = nullptr;
+
+    // greedy scratch
+    size_t greedy_cap = 0;
+    int32_t *g_raw = nullptr, *g_ids = nullptr, *g_offs = nullptr, *g_nout = nullptr, *g_sizes = nullptr;
+
+    FeatState* feat = nullptr;
+
+    // profiling
+    bool profiling = false;
+    hipEvent_t ev[8];
+    double stage_us[5] = {0, 0, 0, 0, 0};
+    int64_t n_step_launches = 0;
+    double step_flops = 0, total_flops = 0;
+};
+
+int features_init(dsmi_model* m);
+void features_destroy(dsmi_model* m);

@@ -1,0 +1,141 @@
+/*
+ * dsmi.h -- C ABI of libdsmi.so: the MI355X-native (gfx950) implementation of the
+ * DanSpeech recognize() hot path.
+ *
+ * The reference (danspeech/danspeech, pure Python) has no FFI of its own; its only
+ * boundary for this path is the Python call chain
+ *     Recognizer.recognize            danspeech/Recognizer.py:82-95
+ *       -> DanSpeechRecognizer.transcribe   danspeech/DanSpeechRecognizer.py:218-231
+ *            -> SpectrogramAudioParser.parse_audio  danspeech/audio/parsers.py:50-72
+ *            -> DeepSpeech.forward                  danspeech/deepspeech/model.py:496-515
+ *            -> {Greedy,BeamCTC}Decoder.decode      danspeech/deepspeech/decoder.py:129-144,183-198
+ * Each entry point below names the reference interface it replaces.  The Python
+ * mirror of those classes (package danspeech_amd) binds these symbols with ctypes;
+ * INTEGRATION.md shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - every function returns 0 on success and a negative dsmi_status on failure;
+ *    dsmi_last_error() gives the message of the last failure on that handle
+ *    (NULL handle: last failure of a create call on this thread).
+ *  - "dev" pointers are HIP device pointers on the handle's device; "host" pointers
+ *    are ordinary host memory.  The caller owns every buffer passed in; the library
+ *    owns weights and workspaces inside the handle.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Work is
+ *    enqueued on it; functions that return host data synchronise that stream.
+ *  - one handle = one GPU; distinct handles may be used from distinct threads, one
+ *    handle is not re-entrant (same contract as a reference Recognizer instance).
+ */
+#ifndef DSMI_H
+#define DSMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    DSMI_OK = 0,
+    DSMI_ERR_INVALID = -1,     /* bad argument / shape                               */
+    DSMI_ERR_CONV = -2,        /* conv_layers outside 1..3 (reference ConvError, model.py:344-348) */
+    DSMI_ERR_NOT_READY = -3,   /* tensor missing / finalize not called (ModelNotInitialized) */
+    DSMI_ERR_UNSORTED = -4,    /* lengths not sorted descending (torch RuntimeError from
+                                  pack_padded_sequence, model.py:117)                */
+    DSMI_ERR_HIP = -5,         /* HIP runtime failure                                */
+    DSMI_ERR_NOMEM = -6,
+    DSMI_ERR_IO = -7,          /* LM file unreadable / malformed                     */
+    DSMI_ERR_CAPACITY = -8     /* batch/time exceeds dsmi_reserve()                  */
+} dsmi_status;
+
+enum { DSMI_RNN_GRU = 0, DSMI_RNN_LSTM = 1, DSMI_RNN_TANH = 2 };
+enum { DSMI_WIN_HAMMING = 0, DSMI_WIN_HANN = 1, DSMI_WIN_BLACKMAN = 2, DSMI_WIN_BARTLETT = 3 };
+enum { DSMI_PCM_I16 = 0, DSMI_PCM_F32 = 1, DSMI_PCM_F64 = 2 };
+enum { DSMI_PAD_REFLECT = 0, DSMI_PAD_CONSTANT = 1 };
+
+/* Mirrors the arguments of DeepSpeech.__init__ (model.py:293-294) plus audio_conf
+ * (danspeech/deepspeech/utils.py:1-8). */
+typedef struct {
+    int32_t conv_layers;        /* 1..3                                   */
+    int32_t rnn_type;           /* DSMI_RNN_*                             */
+    int32_t rnn_hidden_size;
+    int32_t rnn_layers;
+    int32_t bidirectional;      /* 0/1                                    */
+    int32_t context;            /* Lookahead context (unidirectional)     */
+    int32_t n_labels;           /* len(labels)                            */
+    int32_t sample_rate;        /* audio_conf["sampling_rate"]            */
+    float   window_size;        /* seconds                                */
+    float   window_stride;      /* seconds                                */
+    int32_t window;             /* DSMI_WIN_*                             */
+    int32_t normalize;          /* 0/1                                    */
+    int32_t pad_mode;           /* DSMI_PAD_* (librosa center padding)    */
+} dsmi_model_desc;
+
+typedef struct dsmi_model dsmi_model;
+typedef struct dsmi_lm dsmi_lm;
+
+/* ---- lifecycle: replaces DeepSpeech.__init__ / load_model (model.py:293-425, 599-624) */
+int dsmi_model_create(const dsmi_model_desc* desc, int device, dsmi_model** out);
+/* One call per state_dict entry, reference names ("rnns.0.rnn.weight_ih_l0_reverse", ...);
+ * `data` is host float32, row-major, `shape[ndim]`.  Unknown names are ignored
+ * (num_batches_tracked). */
+int dsmi_model_load_tensor(dsmi_model* m, const char* name, const float* data_host,
+                           const int64_t* shape, int ndim);
+/* Checks completeness, repacks weights into kernel layouts, uploads.  After this the
+ * handle is immutable apart from workspaces. */
+int dsmi_model_finalize(dsmi_model* m);
+/* Pre-sizes workspaces so that no allocation happens on the timed path for
+ * batches <= max_batch of <= max_frames spectrogram frames. */
+int dsmi_reserve(dsmi_model* m, int max_batch, int max_frames);
+void dsmi_model_destroy(dsmi_model* m);
+const char* dsmi_last_error(const dsmi_model* m);
+
+/* ---- DeepSpeech.get_seq_lens (model.py:540-551); pure host arithmetic */
+int dsmi_seq_lens(const dsmi_model* m, const int32_t* lens_host, int n, int32_t* out_lens_host);
+
+/* ---- SpectrogramAudioParser.parse_audio (parsers.py:50-72), batched.
+ * pcm_dev: B clips back to back, clip b has n_samples_host[b] samples starting at
+ * sample offset sum(n_samples_host[:b]); dtype DSMI_PCM_*.
+ * feat_dev: [B][n_freq][t_stride] float32, frames past a clip's own count are zero.
+ * frames_host[b] = 1 + n_samples[b] / hop. */
+int dsmi_features(dsmi_model* m, const void* pcm_dev, int pcm_dtype, const int64_t* n_samples_host,
+                  int B, float* feat_dev, int t_stride, int32_t* frames_host, void* stream);
+
+/* ---- DeepSpeech.forward (model.py:496-515), eval mode.
+ * feat_dev [B][1][n_freq][T] float32 (T = max frames, zero past each clip's length),
+ * lens_host[B] sorted descending.  probs_dev [B][T_out][n_labels] float32 softmax
+ * probabilities where T_out = seq_lens(T); out_lens_host[B]. */
+int dsmi_forward(dsmi_model* m, const float* feat_dev, const int32_t* lens_host, int B, int T,
+                 float* probs_dev, int32_t* out_lens_host, void* stream);
+
+/* Stage-level entry points (same arithmetic as inside dsmi_forward), used by the
+ * parity tests against the reference's MaskConv (model.py:65-81) and BatchRNN
+ * (model.py:114-122) golden vectors.
+ * conv_out_dev: [B][C_out*F_out][T_out] float32.
+ * rnn layer: x_dev/y_dev are [T][B][I] / [T][B][H] float32 (reference T x N x H). */
+int dsmi_conv_stack(dsmi_model* m, const float* feat_dev, const int32_t* lens_host, int B, int T,
+                    float* conv_out_dev, void* stream);
+int dsmi_rnn_layer(dsmi_model* m, int layer, const float* x_dev, const int32_t* out_lens_host,
+                   int B, int T_out, float* y_dev, void* stream);
+
+/* ---- GreedyDecoder.decode (decoder.py:183-198 + 151-181).
+ * probs_dev [B][T_out][C]; sizes_host[B] or NULL (= T_out for all).
+ * ids_host/offsets_host: [B][T_out] int32, first n_out_host[b] entries valid. */
+int dsmi_greedy(dsmi_model* m, const float* probs_dev, const int32_t* sizes_host, int B, int T_out,
+                int blank_index, int32_t* ids_host, int32_t* offsets_host, int32_t* n_out_host,
+                void* stream);
+
+/* ---- timing of the last dsmi_forward on this handle, per stage, microseconds
+ * (hipEvent on the call's stream).  stage: 0 conv, 1 input GEMMs, 2 recurrent steps,
+ * 3 head, 4 total.  Enabled by dsmi_set_profiling(m, 1). */
+int dsmi_set_profiling(dsmi_model* m, int on);
+double dsmi_stage_time_us(const dsmi_model* m, int stage);
+/* Kernel launches the last dsmi_forward issued for stage 2 (recurrent steps) and their
+ * summed algorithmic FLOPs (SURVEY 8d formula, recurrent part), for roofline maths. */
+int dsmi_last_forward_stats(const dsmi_model* m, int64_t* n_step_launches, double* step_flops,
+                            double* total_flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSMI_H */

@@ -1,0 +1,196 @@
+"""GPU parity tests: the HIP path (through the C ABI, include/dsmi.h) against the golden
+vectors captured from the reference and against the CPU oracle on seeded inputs.
+
+Tolerances: the forward pass is fp32 end to end on both sides but sums in a different order
+(MFMA k-chains vs BLAS), so stage outputs agree to ~1e-5 and softmax probabilities are held
+to 1e-4 (BASELINE.json north_star); greedy transcripts and offsets must be identical.
+"""
+import numpy as np
+import pytest
+
+from danspeech_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def native():
+    from danspeech_amd import _native
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    _native.lib()  # fail loudly if libdsmi.so is missing
+    return _native
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _cfg(cl, kind, H, L, bidir=True, context=20):
+    return dict(conv_layers=cl, rnn_type=kind, rnn_hidden_size=H, rnn_layers=L, bidirectional=bidir, context=context)
+
+
+def test_seq_lens_g1(native, golden):
+    g = golden("g1_seq_lens")
+    for cl in (1, 2, 3):
+        m = native.NativeModel(_cfg(cl, "gru", 8, 1), syn.make_state_dict(cl, "gru", 8, 1, seed=1))
+        assert np.array_equal(m.seq_lens(g["T"]), g["conv%d" % cl])
+        m.close()
+
+
+@pytest.mark.parametrize("cl", [1, 2, 3])
+def test_conv_stack_g2(native, golden, cl):
+    g = golden("g2_conv%d" % cl)
+    sd = syn.make_state_dict(cl, "gru", 8, 1, seed=int(g["seed"]))
+    m = native.NativeModel(_cfg(cl, "gru", 8, 1), sd)
+    lens = g["lens"]
+    x = syn.make_features(len(lens), int(lens[0]), seed=int(g["x_seed"]))
+    for i, L in enumerate(lens):
+        x[i, :, :, L:] = 0
+    y = m.conv_stack(_dev(x), lens).cpu().numpy()
+    assert y.shape == g["y"].shape
+    np.testing.assert_allclose(y, g["y"], rtol=0, atol=3e-5)
+    for i, L in enumerate(g["out_lens"]):
+        assert not y[i, :, :, L:].any()
+    m.close()
+
+
+def test_conv_stack_long_ragged_vs_oracle(native):
+    """Several time tiles, tiles fully past a clip's length, odd T."""
+    from oracle import model as om
+    cl = 2
+    sd = syn.make_state_dict(cl, "gru", 8, 1, seed=5)
+    m = native.NativeModel(_cfg(cl, "gru", 8, 1), sd)
+    lens = np.array([333, 150, 20], dtype=np.int32)
+    x = syn.make_features(3, 333, seed=6)
+    for i, L in enumerate(lens):
+        x[i, :, :, L:] = 0
+    y = m.conv_stack(_dev(x), lens).cpu().numpy()
+    ref = om.conv_stack(sd, x, om.get_seq_lens(lens, cl), cl)
+    np.testing.assert_allclose(y, ref, rtol=0, atol=3e-5)
+    m.close()
+
+
+@pytest.mark.parametrize("kind", ["gru", "lstm", "rnn"])
+@pytest.mark.parametrize("bidir", [1, 0])
+def test_batch_rnn_g3(native, golden, kind, bidir):
+    """BatchRNN golden vectors driven through dsmi_rnn_layer: layer 0 (no BN, I=32) and
+    layer 1 (BN, I=H=16) of a 1-conv model whose audio_conf gives n_freq=2."""
+    g = golden("g3_batch_rnn")
+    H = 16
+    audio_conf = dict(sampling_rate=100, window_size=0.02, window_stride=0.01, window="hamming", normalize=True)
+    sd = syn.make_state_dict(1, kind, H, 2, bidirectional=bool(bidir), context=3, seed=2)
+    for bn in (0, 1):
+        tag = "%s_bn%d_bi%d" % (kind, bn, bidir)
+        for k in g.files:
+            if k.startswith("w_%s__" % tag):
+                sd["rnns.%d.%s" % (bn, k.split("__", 1)[1])] = g[k]
+    m = native.NativeModel(_cfg(1, kind, H, 2, bool(bidir), 3), sd, audio_conf=audio_conf)
+    for bn in (0, 1):
+        tag = "%s_bn%d_bi%d" % (kind, bn, bidir)
+        y = m.rnn_layer(bn, _dev(g["x_bn%d" % bn]), g["lens"]).cpu().numpy()
+        np.testing.assert_allclose(y, g["y_" + tag], rtol=0, atol=5e-6)
+        for b, L in enumerate(g["lens"]):
+            assert not y[L:, b].any()
+    m.close()
+
+
+def _small_cases():
+    for kind in ("gru", "lstm", "rnn"):
+        for bidir in (True, False):
+            for cl in (1, 2, 3):
+                if cl != 2 and not (kind == "gru" and bidir):
+                    continue
+                yield kind, bidir, cl
+
+
+@pytest.mark.parametrize("kind,bidir,cl", list(_small_cases()))
+def test_forward_small_g4(native, golden, kind, bidir, cl):
+    g = golden("g4_forward_small")
+    tag = "%s_bi%d_c%d" % (kind, bidir, cl)
+    wseed, xseed = [int(v) for v in g["seeds_" + tag]]
+    sd = syn.make_state_dict(cl, kind, 32, 3, bidirectional=bidir, context=6, seed=wseed)
+    m = native.NativeModel(_cfg(cl, kind, 32, 3, bidir, 6), sd)
+    lens = g["lens"]
+    x = syn.make_features(3, 120, seed=xseed)
+    for b, L in enumerate(lens):
+        x[b, :, :, L:] = 0
+    p, ol = m.forward(_dev(x), lens)
+    assert np.array_equal(ol, g["outlens_" + tag])
+    np.testing.assert_allclose(p.cpu().numpy(), g["probs_" + tag], rtol=0, atol=1e-4)
+    m.close()
+
+
+def test_forward_full_cfgA_and_greedy_g4_g7(native, golden):
+    """Full-size cfgA (2 conv, 5 x BiGRU 800), ragged B=2: probs within 1e-4 of the reference,
+    greedy transcript + offsets identical (sharpened logits, margin >= 1e-3)."""
+    g = golden("g4_forward_full")
+    sd = syn.make_state_dict(2, "gru", 800, 5, seed=0, fc_gain=8.0)
+    m = native.NativeModel(_cfg(2, "gru", 800, 5), sd)
+    lens = g["lens"]
+    x = syn.make_features(2, 1001, seed=7)
+    x[1, :, :, 777:] = 0
+    p, ol = m.forward(_dev(x), lens)
+    assert np.array_equal(ol, g["out_lens"])
+    pn = p.cpu().numpy()
+    err = np.abs(pn - g["probs"]).max()
+    print("cfgA max |probs - reference| = %.3g" % err)
+    assert err < 1e-4
+    dec = m.greedy(p, ol, blank_index=0)
+    labels = syn.DANSPEECH_LABELS
+    strings = ["".join(labels[i] for i in ids) for ids, _ in dec]
+    assert strings == [str(s) for s in g["strings"]]
+    assert np.array_equal(dec[0][1], g["off0"]) and np.array_equal(dec[1][1], g["off1"])
+    # batch invariance: clip 1 alone gives the same probabilities (MaskConv's purpose, model.py:57-58)
+    p1, _ = m.forward(_dev(x[1:2, :, :, :777].copy()), lens[1:2])
+    np.testing.assert_allclose(p1.cpu().numpy()[0, :ol[1]], pn[1, :ol[1]], rtol=0, atol=2e-6)
+    m.close()
+
+
+def test_greedy_g5(native, golden):
+    g = golden("g5_greedy")
+    labels = syn.DANSPEECH_LABELS
+    m = native.NativeModel(_cfg(2, "gru", 8, 1), syn.make_state_dict(2, "gru", 8, 1, seed=1))
+    for sizes, skey, okey in ((g["sizes"], "strings", "offsets"), (None, "strings_nosize", "offsets_nosize")):
+        dec = m.greedy(_dev(g["probs"]), sizes, blank_index=labels.index("_"))
+        strings = ["".join(labels[i] for i in ids) for ids, _ in dec]
+        assert strings == [str(s) for s in g[skey]]
+        for b, (_, off) in enumerate(dec):
+            ref = g[okey][b]
+            assert np.array_equal(off, ref[ref >= 0])
+    m.close()
+
+
+def test_features_vs_oracle(native):
+    from oracle import features as of
+    m = native.NativeModel(_cfg(2, "gru", 8, 1), syn.make_state_dict(2, "gru", 8, 1, seed=1))
+    clips = [syn.make_clip(0, 160000), syn.make_clip(1, 66944), syn.make_clip(2, 4000), syn.make_clip(3, 161)]
+    n = np.array([len(c) for c in clips], dtype=np.int64)
+    for dtype in (np.float64, np.float32, np.int16):
+        pcm = _dev(np.concatenate(clips).astype(dtype))
+        feat, frames = m.features(pcm, n)
+        feat = feat.cpu().numpy()
+        for b, c in enumerate(clips):
+            ref = of.spectrogram(c)
+            assert frames[b] == ref.shape[1]
+            np.testing.assert_allclose(feat[b, 0, :, :frames[b]], ref, rtol=0, atol=2e-5)
+            assert not feat[b, 0, :, frames[b]:].any()
+    m.close()
+
+
+def test_errors(native):
+    with pytest.raises(native.DsmiError) as e:
+        native.NativeModel(_cfg(4, "gru", 8, 1), {})
+    assert e.value.code == native.DSMI_ERR_CONV
+    with pytest.raises(native.DsmiError) as e:
+        native.NativeModel(_cfg(0, "gru", 8, 1), {})
+    assert e.value.code == native.DSMI_ERR_CONV and "0 convolutional layers" in e.value.msg
+    with pytest.raises(native.DsmiError) as e:
+        native.NativeModel(_cfg(2, "gru", 8, 1), {})
+    assert e.value.code == native.DSMI_ERR_NOT_READY
+    m = native.NativeModel(_cfg(2, "gru", 8, 1), syn.make_state_dict(2, "gru", 8, 1, seed=1))
+    with pytest.raises(native.DsmiError) as e:
+        m.forward(_dev(syn.make_features(2, 30)), [20, 30])
+    assert e.value.code == native.DSMI_ERR_UNSORTED
+    m.close()

@@ -55,7 +55,7 @@ def test_g3_batch_rnn(golden, kind, bn, bidir):
         if k.startswith("w_%s__" % tag):
             name = k.split("__", 1)[1]
             sd["rnns.0." + name] = g[k]
-    y = om.batch_rnn(sd, 0, kind, g["x"], g["lens"], bool(bidir), bool(bn))
+    y = om.batch_rnn(sd, 0, kind, g["x_bn%d" % bn], g["lens"], bool(bidir), bool(bn))
     ref = g["y_" + tag]
     if not bidir:
         assert ref.shape[2] == 16

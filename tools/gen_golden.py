@@ -94,17 +94,24 @@ def g2_conv():
 
 
 def g3_batch_rnn():
+    """BatchRNN alone.  Shapes are chosen so that the layer also exists inside a DeepSpeech
+    model (needed to drive it through the C ABI): bn=0 is a layer 0 with I = 32 (1 conv layer at
+    n_freq = 2 gives rnn_input_size 32), bn=1 is a layer >= 1 with I = H = 16."""
     rng = np.random.default_rng(5)
-    T, B, I, H = 12, 3, 24, 16
+    T, B, H = 12, 3, 16
     lens = np.array([12, 9, 4], dtype=np.int32)
-    x = rng.standard_normal((T, B, I)).astype(np.float32)
-    for b, L in enumerate(lens):
-        x[L:, b] = 0
-    out = {"x": x, "lens": lens}
+    xs = {}
+    for I in (32, 16):
+        x = rng.standard_normal((T, B, I)).astype(np.float32)
+        for b, L in enumerate(lens):
+            x[L:, b] = 0
+        xs[I] = x
+    out = {"x_bn0": xs[32], "x_bn1": xs[16], "lens": lens}
     for kind in ("gru", "lstm", "rnn"):
         for bn in (False, True):
             for bidir in (True, False):
                 torch.manual_seed(3)
+                I = 16 if bn else 32
                 r = BatchRNN(I, H, rnn_type=supported_rnns[kind], bidirectional=bidir, batch_norm=bn)
                 if bn:
                     bnm = r.batch_norm.module
@@ -113,7 +120,7 @@ def g3_batch_rnn():
                         bnm.running_mean.normal_(0, 0.1); bnm.running_var.uniform_(0.5, 1.5)
                 r.eval()
                 with torch.no_grad():
-                    y = r(torch.from_numpy(x), torch.from_numpy(lens))
+                    y = r(torch.from_numpy(xs[I]), torch.from_numpy(lens))
                 tag = "%s_bn%d_bi%d" % (kind, bn, bidir)
                 out["y_" + tag] = y.numpy()
                 for k, v in r.state_dict().items():

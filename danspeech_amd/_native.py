@@ -38,8 +38,8 @@ class ModelDesc(C.Structure):
     _fields_ = [
         ("conv_layers", C.c_int32), ("rnn_type", C.c_int32), ("rnn_hidden_size", C.c_int32),
         ("rnn_layers", C.c_int32), ("bidirectional", C.c_int32), ("context", C.c_int32),
-        ("n_labels", C.c_int32), ("sample_rate", C.c_int32), ("window_size", C.c_float),
-        ("window_stride", C.c_float), ("window", C.c_int32), ("normalize", C.c_int32),
+        ("n_labels", C.c_int32), ("sample_rate", C.c_int32), ("window_size", C.c_double),
+        ("window_stride", C.c_double), ("window", C.c_int32), ("normalize", C.c_int32),
         ("pad_mode", C.c_int32),
     ]
 

@@ -64,8 +64,8 @@ typedef struct {
     int32_t context;            /* Lookahead context (unidirectional)     */
     int32_t n_labels;           /* len(labels)                            */
     int32_t sample_rate;        /* audio_conf["sampling_rate"]            */
-    float   window_size;        /* seconds                                */
-    float   window_stride;      /* seconds                                */
+    double  window_size;        /* seconds (double: n_fft = int(rate * size) as Python computes it, parsers.py:47) */
+    double  window_stride;      /* seconds                                */
     int32_t window;             /* DSMI_WIN_*                             */
     int32_t normalize;          /* 0/1                                    */
     int32_t pad_mode;           /* DSMI_PAD_* (librosa center padding)    */

@@ -66,6 +66,8 @@ _PROTOS = {
     "dsmi_greedy": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "dsmi_set_profiling": (C.c_int, [_vp, C.c_int]),
     "dsmi_stage_time_us": (C.c_double, [_vp, C.c_int]),
+    "dsmi_kernel_stats": (C.c_int, [_vp, C.c_int, _i64p, _i64p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "dsmi_reset_kernel_stats": (C.c_int, [_vp]),
     "dsmi_last_forward_stats": (C.c_int, [_vp, _i64p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 
@@ -227,8 +229,24 @@ class NativeModel:
                                       int(blank_index), _np_ptr(ids), _np_ptr(offs), _np_ptr(n), self._stream()))
         return [(ids[b, :n[b]].copy(), offs[b, :n[b]].copy()) for b in range(B)]
 
-    def set_profiling(self, on):
-        self._check(lib().dsmi_set_profiling(self._h, int(bool(on))))
+    KERNEL_KINDS = ["stft", "conv1", "conv2", "conv3", "gemm_l0", "gemm", "rnn_step", "head", "greedy", "beam"]
+
+    def set_profiling(self, level):
+        self._check(lib().dsmi_set_profiling(self._h, int(level)))
+
+    def kernel_stats(self):
+        """dict kind -> dict(launches, samples, avg_us, flops_per_launch, bytes_per_launch)."""
+        out = {}
+        for k, name in enumerate(self.KERNEL_KINDS):
+            n = C.c_int64(); sm = C.c_int64(); us = C.c_double(); fl = C.c_double(); by = C.c_double()
+            self._check(lib().dsmi_kernel_stats(self._h, k, C.byref(n), C.byref(sm), C.byref(us), C.byref(fl), C.byref(by)))
+            if n.value:
+                out[name] = dict(launches=n.value, samples=sm.value, avg_us=us.value,
+                                 flops_per_launch=fl.value, bytes_per_launch=by.value)
+        return out
+
+    def reset_kernel_stats(self):
+        self._check(lib().dsmi_reset_kernel_stats(self._h))
 
     def stage_time_us(self, stage):
         return float(lib().dsmi_stage_time_us(self._h, int(stage)))

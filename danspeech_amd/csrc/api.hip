@@ -21,6 +21,42 @@ static thread_local std::string g_create_error;
         }                                                                                 \
     } while (0)
 
+// Count one launch of `kind`; when profiling level 2 is on and `sample` is set, hand out an
+// event pair for hipExtLaunchKernelGGL.
+EvPair timer_arm(dsmi_model* m, int kind, bool sample, double flops, double bytes) {
+    EvPair ev;
+    if (m->profiling < 2) return ev;
+    KernelTimer& t = m->kt;
+    t.launches[kind] += 1;
+    t.flops[kind] += flops;
+    t.bytes[kind] += bytes;
+    if (!sample) return ev;
+    hipEvent_t e[2];
+    for (int i = 0; i < 2; ++i) {
+        if (!t.free_events.empty()) { e[i] = t.free_events.back(); t.free_events.pop_back(); }
+        else if (hipEventCreate(&e[i]) != hipSuccess) return EvPair();
+    }
+    ev.start = e[0]; ev.stop = e[1];
+    t.pending[kind].push_back({e[0], e[1]});
+    return ev;
+}
+
+static void timer_resolve(dsmi_model* m) {
+    KernelTimer& t = m->kt;
+    for (int k = 0; k < KK_COUNT; ++k) {
+        for (auto& pr : t.pending[k]) {
+            float ms = 0.f;
+            if (hipEventSynchronize(pr.second) == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+                t.sum_us[k] += ms * 1e3;
+                t.samples[k] += 1;
+            }
+            t.free_events.push_back(pr.first);
+            t.free_events.push_back(pr.second);
+        }
+        t.pending[k].clear();
+    }
+}
+
 static int fail(dsmi_model* m, int code, const std::string& msg) {
     m->err = msg;
     return code;
@@ -264,6 +300,8 @@ extern "C" void dsmi_model_destroy(dsmi_model* m) {
     for (void* p : m->owned) (void)hipFree(p);
     if (m->finalized)
         for (int i = 0; i < 8; ++i) (void)hipEventDestroy(m->ev[i]);
+    timer_resolve(m);
+    for (hipEvent_t e : m->kt.free_events) (void)hipEventDestroy(e);
     features_destroy(m);
     delete m;
 }
@@ -290,6 +328,12 @@ static int run_conv(dsmi_model* m, const float* feat, int B, int T, int To, int 
         c.bn_a = m->conv[l].bn_a; c.bn_b = m->conv[l].bn_b; c.out_lens_dev = m->lens_dev;
         c.B = B; c.ci = sp.ci; c.co = sp.co; c.fi = m->conv_fi[l]; c.fo = m->conv_fo[l];
         c.ti = ti; c.to = To; c.xs = xs; c.ys = ys; c.layer = l;
+        {
+            double fl = 0, by = 0;
+            for (int i = 0; i < B; ++i) fl += 2.0 * sp.co * m->conv_fo[l] * (double)m->host_out_lens[i] * sp.ci * sp.kf * sp.kt;
+            by = 4.0 * B * ((double)sp.ci * m->conv_fi[l] * ti + (double)sp.co * m->conv_fo[l] * To);
+            c.ev = timer_arm(m, KK_CONV1 + l, true, fl, by);
+        }
         launch_conv(c, s);
         x = c.y; ti = To; xs = ys;
     }
@@ -298,7 +342,12 @@ static int run_conv(dsmi_model* m, const float* feat, int B, int T, int To, int 
 }
 
 // One BatchRNN layer on the internal buffers: x-projection GEMM + To recurrent step launches.
-static void run_rnn_layer(dsmi_model* m, int l, const GemmLaunch& gl, int B, int To, int dst, hipStream_t s) {
+static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, int dst, hipStream_t s) {
+    double sumlen = 0;
+    for (int i = 0; i < B; ++i) sumlen += m->host_out_lens[i];
+    const double GH = (double)m->geom.G * m->desc.rnn_hidden_size, Dd = m->geom.D;
+    gl.ev = timer_arm(m, gl.mode == GEMM_A_CONV ? KK_GEMM0 : KK_GEMM, true, 2.0 * Dd * GH * gl.K * sumlen,
+                      4.0 * ((double)gl.M * gl.K * (gl.a2 ? 2 : 1) + (double)gl.N * gl.K + (double)gl.M * gl.N));
     launch_gemm(gl, s);
     RnnStepLaunch st;
     st.g = m->geom;
@@ -307,9 +356,13 @@ static void run_rnn_layer(dsmi_model* m, int l, const GemmLaunch& gl, int B, int
         st.out[dd] = m->hbuf[dst][dd]; st.cstate[dd] = m->cst[dd];
     }
     st.xp = m->xp; st.lens_dev = m->lens_dev; st.B = B; st.T = To;
-    if (m->profiling) (void)hipEventRecord(m->ev[6], s);
     for (int step = 0; step < To; ++step) {
         st.step = step;
+        // algorithmic FLOPs of this launch: clips still running at this step (both directions)
+        int act = 0;
+        for (int i = 0; i < B; ++i) act += step < m->host_out_lens[i] ? 1 : 0;
+        st.ev = timer_arm(m, KK_STEP, (step & 7) == 3, 2.0 * Dd * GH * m->desc.rnn_hidden_size * act,
+                          4.0 * Dd * (GH * m->desc.rnn_hidden_size + (double)B * (GH + 2.0 * m->desc.rnn_hidden_size)));
         launch_rnn_step(st, s);
     }
 }
@@ -335,7 +388,8 @@ extern "C" int dsmi_forward(dsmi_model* m, const float* feat, const int32_t* len
     const dsmi_model_desc& d = m->desc;
     const int To = seq_len(m, T), ys = round_up(To, 4);
     for (int i = 0; i < B; ++i) out_lens[i] = seq_len(m, lens[i]);
-    HIP_OK(m, hipMemcpyAsync(m->lens_dev, out_lens, sizeof(int32_t) * B, hipMemcpyHostToDevice, s));
+    m->host_out_lens.assign(out_lens, out_lens + B);
+    HIP_OK(m, hipMemcpyAsync(m->lens_dev, m->host_out_lens.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice, s));
     if (m->Hs != d.rnn_hidden_size)
         for (int i = 0; i < 2; ++i)
             for (int dd = 0; dd < m->geom.D; ++dd)
@@ -368,6 +422,12 @@ extern "C" int dsmi_forward(dsmi_model* m, const float* feat, const int32_t* len
     } else {
         h.x1 = m->hbuf[last][0]; h.x2 = m->hbuf[last][1];
     }
+    {
+        double sumlen = 0;
+        for (int i = 0; i < B; ++i) sumlen += out_lens[i];
+        h.ev = timer_arm(m, KK_HEAD, true, 2.0 * sumlen * d.rnn_hidden_size * d.n_labels,
+                         4.0 * To * B * ((d.bidirectional ? 2.0 : 1.0) * m->Hs + d.n_labels));
+    }
     launch_head(h, s);
     if (m->profiling) HIP_OK(m, hipEventRecord(m->ev[3], s));
     HIP_OK(m, hipGetLastError());
@@ -393,7 +453,7 @@ extern "C" int dsmi_forward(dsmi_model* m, const float* feat, const int32_t* len
     }
     m->step_flops = rec;
     m->total_flops = tot;
-    if (m->profiling) {
+    if (m->profiling == 1) {
         HIP_OK(m, hipStreamSynchronize(s));
         float ms;
         HIP_OK(m, hipEventElapsedTime(&ms, m->ev[0], m->ev[1])); m->stage_us[0] = ms * 1e3;
@@ -413,9 +473,9 @@ extern "C" int dsmi_conv_stack(dsmi_model* m, const float* feat, const int32_t* 
     HIP_OK(m, hipSetDevice(m->device));
     hipStream_t s = (hipStream_t)stream;
     const int To = seq_len(m, T), ys = round_up(To, 4);
-    std::vector<int32_t> ol(B);
-    for (int i = 0; i < B; ++i) ol[i] = seq_len(m, lens[i]);
-    HIP_OK(m, hipMemcpyAsync(m->lens_dev, ol.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice, s));
+    m->host_out_lens.resize(B);
+    for (int i = 0; i < B; ++i) m->host_out_lens[i] = seq_len(m, lens[i]);
+    HIP_OK(m, hipMemcpyAsync(m->lens_dev, m->host_out_lens.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice, s));
     const float* cx;
     run_conv(m, feat, B, T, To, ys, s, &cx);
     // strip the time-stride padding: [B][C*F][ys] -> [B][C*F][To]
@@ -443,7 +503,8 @@ extern "C" int dsmi_rnn_layer(dsmi_model* m, int layer, const float* x, const in
     HIP_OK(m, hipSetDevice(m->device));
     hipStream_t s = (hipStream_t)stream;
     const int H = m->desc.rnn_hidden_size;
-    HIP_OK(m, hipMemcpyAsync(m->lens_dev, out_lens, sizeof(int32_t) * B, hipMemcpyHostToDevice, s));
+    m->host_out_lens.assign(out_lens, out_lens + B);
+    HIP_OK(m, hipMemcpyAsync(m->lens_dev, m->host_out_lens.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice, s));
     for (int dd = 0; dd < m->geom.D; ++dd)
         HIP_OK(m, hipMemsetAsync(m->hbuf[0][dd], 0, sizeof(float) * (size_t)To * B * m->Hs, s));
     const RnnW& r = m->rnn[layer];
@@ -490,9 +551,30 @@ extern "C" int dsmi_greedy(dsmi_model* m, const float* probs, const int32_t* siz
     return DSMI_OK;
 }
 
-extern "C" int dsmi_set_profiling(dsmi_model* m, int on) {
+extern "C" int dsmi_set_profiling(dsmi_model* m, int level) {
     if (!m) return DSMI_ERR_INVALID;
-    m->profiling = on != 0;
+    m->profiling = level < 0 ? 0 : (level > 2 ? 2 : level);
+    return DSMI_OK;
+}
+
+extern "C" int dsmi_kernel_stats(dsmi_model* m, int kind, int64_t* launches, int64_t* samples, double* avg_us,
+                                 double* flops_per_launch, double* bytes_per_launch) {
+    if (!m || kind < 0 || kind >= KK_COUNT) return DSMI_ERR_INVALID;
+    (void)hipSetDevice(m->device);
+    timer_resolve(m);
+    const KernelTimer& t = m->kt;
+    if (launches) *launches = t.launches[kind];
+    if (samples) *samples = t.samples[kind];
+    if (avg_us) *avg_us = t.samples[kind] ? t.sum_us[kind] / t.samples[kind] : 0.0;
+    if (flops_per_launch) *flops_per_launch = t.launches[kind] ? t.flops[kind] / t.launches[kind] : 0.0;
+    if (bytes_per_launch) *bytes_per_launch = t.launches[kind] ? t.bytes[kind] / t.launches[kind] : 0.0;
+    return DSMI_OK;
+}
+
+extern "C" int dsmi_reset_kernel_stats(dsmi_model* m) {
+    if (!m) return DSMI_ERR_INVALID;
+    timer_resolve(m);
+    for (int k = 0; k < KK_COUNT; ++k) { m->kt.sum_us[k] = 0; m->kt.samples[k] = 0; m->kt.launches[k] = 0; m->kt.flops[k] = 0; m->kt.bytes[k] = 0; }
     return DSMI_OK;
 }
 

@@ -1,6 +1,7 @@
 // Internal declarations shared by the libdsmi translation units (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cstdint>
 #include <cstdio>
 #include <string>
@@ -15,6 +16,17 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int kWave = 64;  // gfx950 wavefront
+
+// Optional per-dispatch timestamps: when both events are set the kernel is launched with
+// hipExtLaunchKernelGGL, which stamps them with the dispatch's own begin/end times (the same
+// clock rocprofv3's kernel trace reads), so elapsed(start, stop) is the kernel's duration
+// without launch gaps.
+struct EvPair { hipEvent_t start = nullptr, stop = nullptr; };
+#define DSMI_LAUNCH(kern, grid, block, lds, stream, ev, ...)                                          \
+    do {                                                                                              \
+        if ((ev).start) hipExtLaunchKernelGGL(kern, grid, block, lds, stream, (ev).start, (ev).stop, 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);                          \
+    } while (0)
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
@@ -38,6 +50,7 @@ struct ConvLaunch {
     const float* x; float* y; const float* wp; const float* bias; const float* bn_a; const float* bn_b;
     const int32_t* out_lens_dev;
     int B, ci, co, fi, fo, ti, to, xs, ys, layer;  // layer index selects the compile-time geometry
+    EvPair ev;
 };
 void launch_conv(const ConvLaunch& p, hipStream_t s);
 // Host-side weight packer: w [co][ci][kf][kt] -> kernel layout. Returns packed floats.
@@ -56,6 +69,7 @@ struct GemmLaunch {
     int M, N, K;       // N, K as stored (W is [N][K] row-major, K % 4 == 0 guaranteed by packing)
     int lda, ldw, ldc;
     int B, T, ys;      // GEMM_A_CONV: batch, frames per clip, time stride
+    EvPair ev;
 };
 void launch_gemm(const GemmLaunch& p, hipStream_t s);
 
@@ -86,6 +100,7 @@ struct RnnStepLaunch {
     float* cstate[2];            // LSTM cell state [B][H] per direction (else null)
     const int32_t* lens_dev;     // [B] output lengths
     int B, T, step;
+    EvPair ev;
 };
 void launch_rnn_step(const RnnStepLaunch& p, hipStream_t s);
 
@@ -96,6 +111,7 @@ void launch_lookahead(const float* x, const float* w, float* y, int T, int B, in
 struct HeadLaunch {
     const float* x1; const float* x2; const float* bn_a; const float* bn_b;
     const float* w_packed; int H, C, T, B; float* probs;
+    EvPair ev;
 };
 std::vector<float> pack_fc(const float* w, int C, int H);
 void launch_head(const HeadLaunch& p, hipStream_t s);

@@ -168,7 +168,7 @@ static void launch_layer(const ConvLaunch& c, hipStream_t s) {
     ConvArgs a{c.x, c.y, c.wp, c.bias, c.bn_a, c.bn_b, c.out_lens_dev, c.B, c.fi, c.fo, c.ti, c.to, c.xs, c.ys};
     dim3 grid(ceil_div(c.to, TT), ceil_div(c.fo, NF), c.B);
     const size_t lds = (size_t)D::NBUF * D::CHUNK * sizeof(float);
-    hipLaunchKernelGGL(conv_kernel<L>, grid, dim3(256), lds, s, a);
+    DSMI_LAUNCH(conv_kernel<L>, grid, dim3(256), lds, s, c.ev, a);
 }
 
 void launch_conv(const ConvLaunch& c, hipStream_t s) {

@@ -187,9 +187,13 @@ extern "C" int dsmi_features(dsmi_model* m, const void* pcm, int dtype, const in
         hipMemcpyAsync(f->offs + f->cap, host.data() + B, sizeof(int64_t) * B, hipMemcpyHostToDevice, s) != hipSuccess)
         return bad(DSMI_ERR_HIP, "hipMemcpyAsync failed");
     const size_t lds = sizeof(double) * ((size_t)2 * m->n_fft + (size_t)m->n_fft * FT);
-    hipLaunchKernelGGL(stft_logmag_kernel, dim3(ceil_div(maxfr, FT), B), dim3(256), lds, s, pcm, dtype, f->offs, f->offs + f->cap,
-                       f->tw, f->win, m->n_fft, m->hop, m->n_freq, m->desc.pad_mode, feat, t_stride);
+    double totfr = 0;
+    for (int b = 0; b < B; ++b) totfr += 1 + n_samples[b] / m->hop;
+    EvPair ev = timer_arm(m, KK_STFT, true, 4.0 * totfr * m->n_freq * m->n_fft,
+                          (double)off * (dtype == DSMI_PCM_I16 ? 2 : (dtype == DSMI_PCM_F32 ? 4 : 8)) + 4.0 * totfr * m->n_freq);
+    DSMI_LAUNCH(stft_logmag_kernel, dim3(ceil_div(maxfr, FT), B), dim3(256), lds, s, ev, pcm, dtype, f->offs, f->offs + f->cap,
+                f->tw, f->win, m->n_fft, m->hop, m->n_freq, m->desc.pad_mode, feat, t_stride);
     hipLaunchKernelGGL(normalize_kernel, dim3(B), dim3(1024), 0, s, feat, f->offs + f->cap, m->hop, m->n_freq, t_stride, m->desc.normalize);
-    if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) return bad(DSMI_ERR_HIP, "feature kernels failed");
+    if (hipGetLastError() != hipSuccess) return bad(DSMI_ERR_HIP, "feature kernels failed to launch");
     return DSMI_OK;
 }

@@ -198,11 +198,11 @@ void launch_gemm(const GemmLaunch& g, hipStream_t s) {
     const size_t lds_cv = 2 * (BK * LDC + BN * LDT) * sizeof(float);
     switch (g.mode) {
         case GEMM_A_ROWMAJOR:
-            hipLaunchKernelGGL(gemm_f32_kernel<GEMM_A_ROWMAJOR>, grid, dim3(256), lds_rm, s, a); break;
+            DSMI_LAUNCH(gemm_f32_kernel<GEMM_A_ROWMAJOR>, grid, dim3(256), lds_rm, s, g.ev, a); break;
         case GEMM_A_SUM_BN:
-            hipLaunchKernelGGL(gemm_f32_kernel<GEMM_A_SUM_BN>, grid, dim3(256), lds_rm, s, a); break;
+            DSMI_LAUNCH(gemm_f32_kernel<GEMM_A_SUM_BN>, grid, dim3(256), lds_rm, s, g.ev, a); break;
         default:
-            hipLaunchKernelGGL(gemm_f32_kernel<GEMM_A_CONV>, grid, dim3(256), lds_cv, s, a); break;
+            DSMI_LAUNCH(gemm_f32_kernel<GEMM_A_CONV>, grid, dim3(256), lds_cv, s, g.ev, a); break;
     }
 }
 

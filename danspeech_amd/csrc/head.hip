@@ -101,10 +101,10 @@ void launch_head(const HeadLaunch& h, hipStream_t s) {
     const int nt = ceil_div(h.C, 32);
     dim3 grid(ceil_div(a.M, 128));
     switch (nt) {
-        case 1: hipLaunchKernelGGL(head_kernel<1>, grid, dim3(256), 0, s, a); break;
-        case 2: hipLaunchKernelGGL(head_kernel<2>, grid, dim3(256), 0, s, a); break;
-        case 3: hipLaunchKernelGGL(head_kernel<3>, grid, dim3(256), 0, s, a); break;
-        default: hipLaunchKernelGGL(head_kernel<4>, grid, dim3(256), 0, s, a); break;
+        case 1: DSMI_LAUNCH(head_kernel<1>, grid, dim3(256), 0, s, h.ev, a); break;
+        case 2: DSMI_LAUNCH(head_kernel<2>, grid, dim3(256), 0, s, h.ev, a); break;
+        case 3: DSMI_LAUNCH(head_kernel<3>, grid, dim3(256), 0, s, h.ev, a); break;
+        default: DSMI_LAUNCH(head_kernel<4>, grid, dim3(256), 0, s, h.ev, a); break;
     }
 }
 

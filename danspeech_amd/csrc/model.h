@@ -21,6 +21,19 @@ struct RnnW {
 
 struct FeatState;   // features.hip
 
+// Per-kernel dispatch timing (profiling level 2): sampled launches carry an event pair stamped
+// with the dispatch's own begin/end timestamps; pairs are resolved lazily after a sync.
+enum KernelKind { KK_STFT = 0, KK_CONV1, KK_CONV2, KK_CONV3, KK_GEMM0, KK_GEMM, KK_STEP, KK_HEAD, KK_GREEDY, KK_BEAM, KK_COUNT };
+struct KernelTimer {
+    std::vector<hipEvent_t> free_events;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[KK_COUNT];
+    double sum_us[KK_COUNT] = {0};
+    int64_t samples[KK_COUNT] = {0};
+    int64_t launches[KK_COUNT] = {0};
+    double flops[KK_COUNT] = {0};     // algorithmic FLOPs summed over ALL launches of the kind
+    double bytes[KK_COUNT] = {0};     // algorithmic bytes summed over all launches
+};
+
 struct dsmi_model {
     dsmi_model_desc desc{};
     int device = 0;
@@ -50,6 +63,7 @@ struct dsmi_model {
     float* cst[2] = {nullptr, nullptr};
     float* look_buf = nullptr;
     float* xin = nullptr;
+    std::vector<int32_t> host_out_lens;   // output lengths of the batch being processed
     int32_t *lens_dev = nullptr, *sizes_dev = nullptr, *raw_ids = nullptr, *ids = nullptr, *offs = nullptr, *nout = nullptr;
 
     // greedy scratch
@@ -59,12 +73,14 @@ struct dsmi_model {
     FeatState* feat = nullptr;
 
     // profiling
-    bool profiling = false;
+    int profiling = 0;        // 0 off, 1 stage events, 2 + sampled per-kernel dispatch timestamps
+    KernelTimer kt;
     hipEvent_t ev[8];
     double stage_us[5] = {0, 0, 0, 0, 0};
     int64_t n_step_launches = 0;
     double step_flops = 0, total_flops = 0;
 };
 
+dsmi::EvPair timer_arm(dsmi_model* m, int kind, bool sample, double flops, double bytes);
 int features_init(dsmi_model* m);
 void features_destroy(dsmi_model* m);

@@ -175,14 +175,14 @@ __global__ __launch_bounds__(256) void rnn_step_kernel(StepArgs p) {
 }
 
 template <int KIND>
-static void launch_kind(const StepArgs& a, int D, hipStream_t s) {
+static void launch_kind(const StepArgs& a, int D, hipStream_t s, const EvPair& ev) {
     const int B = a.B;
     if (B <= 32) {
-        hipLaunchKernelGGL((rnn_step_kernel<KIND, 1>), dim3(a.nwg, D, 1), dim3(256), 0, s, a);
+        DSMI_LAUNCH((rnn_step_kernel<KIND, 1>), dim3(a.nwg, D, 1), dim3(256), 0, s, ev, a);
     } else if (B <= 64) {
-        hipLaunchKernelGGL((rnn_step_kernel<KIND, 2>), dim3(a.nwg, D, 1), dim3(256), 0, s, a);
+        DSMI_LAUNCH((rnn_step_kernel<KIND, 2>), dim3(a.nwg, D, 1), dim3(256), 0, s, ev, a);
     } else {
-        hipLaunchKernelGGL((rnn_step_kernel<KIND, 4>), dim3(a.nwg, D, ceil_div(B, 128)), dim3(256), 0, s, a);
+        DSMI_LAUNCH((rnn_step_kernel<KIND, 4>), dim3(a.nwg, D, ceil_div(B, 128)), dim3(256), 0, s, ev, a);
     }
 }
 
@@ -194,9 +194,9 @@ void launch_rnn_step(const RnnStepLaunch& p, hipStream_t s) {
     a.xp = p.xp; a.lens = p.lens_dev; a.B = p.B; a.T = p.T; a.step = p.step;
     a.G = p.g.G; a.H = p.g.H; a.U = p.g.U; a.Hs = p.g.Kp; a.nq = p.g.nq; a.Np = p.g.Np; a.nwg = p.g.nwg;
     switch (p.g.kind) {
-        case DSMI_RNN_GRU: launch_kind<DSMI_RNN_GRU>(a, p.g.D, s); break;
-        case DSMI_RNN_LSTM: launch_kind<DSMI_RNN_LSTM>(a, p.g.D, s); break;
-        default: launch_kind<DSMI_RNN_TANH>(a, p.g.D, s); break;
+        case DSMI_RNN_GRU: launch_kind<DSMI_RNN_GRU>(a, p.g.D, s, p.ev); break;
+        case DSMI_RNN_LSTM: launch_kind<DSMI_RNN_LSTM>(a, p.g.D, s, p.ev); break;
+        default: launch_kind<DSMI_RNN_TANH>(a, p.g.D, s, p.ev); break;
     }
 }
 

@@ -125,10 +125,19 @@ int dsmi_greedy(dsmi_model* m, const float* probs_dev, const int32_t* sizes_host
                 int blank_index, int32_t* ids_host, int32_t* offsets_host, int32_t* n_out_host,
                 void* stream);
 
-/* ---- timing of the last dsmi_forward on this handle, per stage, microseconds
- * (hipEvent on the call's stream).  stage: 0 conv, 1 input GEMMs, 2 recurrent steps,
- * 3 head, 4 total.  Enabled by dsmi_set_profiling(m, 1). */
-int dsmi_set_profiling(dsmi_model* m, int on);
+/* ---- measurement hooks (no reference counterpart; SURVEY 5 "tracing/profiling": none).
+ * level 0: off.  level 1: per-stage hipEvents around the last dsmi_forward (synchronises).
+ * level 2: sampled launches of each kernel kind are dispatched with their own begin/end
+ * timestamps (hipExtLaunchKernelGGL), fully asynchronous; read back with dsmi_kernel_stats.
+ * stage for dsmi_stage_time_us: 0 conv, 2 input GEMMs + recurrent steps, 3 head, 4 total. */
+int dsmi_set_profiling(dsmi_model* m, int level);
+/* kind: 0 stft, 1 conv1, 2 conv2, 3 conv3, 4 layer-0 input GEMM, 5 input GEMM (layers >= 1),
+ * 6 recurrent step, 7 head, 8 greedy, 9 beam.  launches = dispatches since the last reset,
+ * samples = how many of them were timed, avg_us = mean duration of the timed ones,
+ * flops/bytes_per_launch = algorithmic work (SURVEY 8d formulas) averaged over all launches. */
+int dsmi_kernel_stats(dsmi_model* m, int kind, int64_t* launches, int64_t* samples, double* avg_us,
+                      double* flops_per_launch, double* bytes_per_launch);
+int dsmi_reset_kernel_stats(dsmi_model* m);
 double dsmi_stage_time_us(const dsmi_model* m, int stage);
 /* Kernel launches the last dsmi_forward issued for stage 2 (recurrent steps) and their
  * summed algorithmic FLOPs (SURVEY 8d formula, recurrent part), for roofline maths. */

@@ -40,20 +40,36 @@ def _bn_affine(sd, prefix):
 
 
 def conv2d(x, w, bias, stride, pad):
-    """Cross-correlation, NCHW, zero padding; accumulates tap by tap with BLAS matmuls."""
+    """Cross-correlation, NCHW, zero padding.
+
+    Unfolds the time taps only (U[(ci,kt), r, t] = xp[ci, r, kt + st*t]) and then runs one BLAS
+    matmul per kernel row kf on the input rows r = sf*f + kf, which are a contiguous slice of the
+    rows with residue kf % sf -- no full im2col copy.
+    """
     B, Ci, Fi, Ti = x.shape
     Co, _, kf, kt = w.shape
     sf, st = stride
     pf, pt = pad
     Fo = (Fi + 2 * pf - kf) // sf + 1
     To = (Ti + 2 * pt - kt) // st + 1
-    xp = np.zeros((B, Ci, Fi + 2 * pf, Ti + 2 * pt), dtype=np.float32)
-    xp[:, :, pf:pf + Fi, pt:pt + Ti] = x
-    out = np.zeros((B, Co, Fo, To), dtype=np.float32)
-    for a in range(kf):
-        for b in range(kt):
-            patch = xp[:, :, a:a + sf * (Fo - 1) + 1:sf, b:b + st * (To - 1) + 1:st]  # B,Ci,Fo,To
-            out += np.einsum("oc,bcft->boft", w[:, :, a, b], patch, optimize=True)
+    R = Fi + 2 * pf
+    out = np.empty((B, Co, Fo, To), dtype=np.float32)
+    wk = [np.ascontiguousarray(w[:, :, a, :].reshape(Co, Ci * kt)) for a in range(kf)]
+    for b in range(B):
+        xp = np.zeros((Ci, R, Ti + 2 * pt), dtype=np.float32)
+        xp[:, pf:pf + Fi, pt:pt + Ti] = x[b]
+        ures = []
+        for res in range(sf):
+            rows = xp[:, res::sf, :]
+            u = np.empty((Ci, kt, rows.shape[1], To), dtype=np.float32)
+            for c in range(kt):
+                u[:, c] = rows[:, :, c:c + st * (To - 1) + 1:st]
+            ures.append(u.reshape(Ci * kt, rows.shape[1], To))
+        acc = np.zeros((Co, Fo * To), dtype=np.float32)
+        for a in range(kf):
+            u = ures[a % sf][:, a // sf:a // sf + Fo, :].reshape(Ci * kt, Fo * To)
+            acc += wk[a] @ u
+        out[b] = acc.reshape(Co, Fo, To)
     out += bias.reshape(1, Co, 1, 1)
     return out
 

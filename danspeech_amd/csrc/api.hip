@@ -278,6 +278,12 @@ extern "C" int dsmi_reserve(dsmi_model* m, int max_B, int max_T) {
         m->cst[dd] = nullptr;
         if (d.rnn_type == DSMI_RNN_LSTM && dd < m->geom.D && (rc = ws_alloc(m, &m->cst[dd], (size_t)max_B * m->Hs))) return rc;
     }
+    {
+        // zero once: operand slots of padding units (k in [H, Hs)) are never written and must stay finite
+        const size_t n = (size_t)2 * m->geom.D * ceil_div(max_B, 32) * m->geom.nq * 256;
+        if ((rc = ws_alloc(m, &m->hpack, n))) return rc;
+        HIP_OK(m, hipMemset(m->hpack, 0, n * sizeof(float)));
+    }
     m->look_buf = nullptr;
     if (!d.bidirectional && (rc = ws_alloc(m, &m->look_buf, rows * m->Hs))) return rc;
     if ((rc = ws_alloc(m, &m->xin, rows * round_up(std::max(m->I0, m->Hs), 4)))) return rc;
@@ -355,7 +361,7 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
         st.whh_packed[dd] = m->rnn[l].whh[dd]; st.bhh[dd] = m->rnn[l].bhh[dd];
         st.out[dd] = m->hbuf[dst][dd]; st.cstate[dd] = m->cst[dd];
     }
-    st.xp = m->xp; st.lens_dev = m->lens_dev; st.B = B; st.T = To;
+    st.xp = m->xp; st.lens_dev = m->lens_dev; st.B = B; st.T = To; st.hpack = m->hpack;
     for (int step = 0; step < To; ++step) {
         st.step = step;
         // algorithmic FLOPs of this launch: clips still running at this step (both directions)
@@ -588,5 +594,42 @@ extern "C" int dsmi_last_forward_stats(const dsmi_model* m, int64_t* n_step, dou
     if (n_step) *n_step = m->n_step_launches;
     if (step_flops) *step_flops = m->step_flops;
     if (total_flops) *total_flops = m->total_flops;
+    return DSMI_OK;
+}
+
+// ---- diagnostics: per-wave phase timestamps (s_memrealtime, 100 MHz) of ONE recurrent step launch.
+// Runs steps 0..step of `layer` on whatever the workspaces hold (timing only) and returns
+// stamps[D*nwg][8 waves][8] for the last one.  GRU, B <= 32.
+extern "C" int dsmi_debug_step_stamps(dsmi_model* m, int layer, int B, int To, int step, uint64_t* stamps_host, int64_t n_words) {
+    if (!m || !m->finalized || m->desc.rnn_type != DSMI_RNN_GRU || B > 32 || layer < 0 || layer >= m->desc.rnn_layers) return DSMI_ERR_INVALID;
+    int Tin = To;
+    while (seq_len(m, Tin) < To) Tin += 1;
+    int rc;
+    if ((rc = dsmi_reserve(m, B, Tin))) return rc;
+    HIP_OK(m, hipSetDevice(m->device));
+    const int64_t need = (int64_t)m->geom.D * m->geom.nwg * 8 * 8;
+    if (n_words < need) return fail(m, DSMI_ERR_INVALID, "stamp buffer too small");
+    unsigned long long* dbg;
+    HIP_OK(m, hipMalloc((void**)&dbg, sizeof(unsigned long long) * need));
+    HIP_OK(m, hipMemset(dbg, 0, sizeof(unsigned long long) * need));
+    std::vector<int32_t> lens(B, To);
+    HIP_OK(m, hipMemcpy(m->lens_dev, lens.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice));
+    HIP_OK(m, hipMemset(m->xp, 0, sizeof(float) * (size_t)To * B * m->geom.Np));
+    for (int dd = 0; dd < m->geom.D; ++dd) HIP_OK(m, hipMemset(m->hbuf[0][dd], 0, sizeof(float) * (size_t)To * B * m->Hs));
+    RnnStepLaunch st;
+    st.g = m->geom;
+    for (int dd = 0; dd < 2; ++dd) {
+        st.whh_packed[dd] = m->rnn[layer].whh[dd]; st.bhh[dd] = m->rnn[layer].bhh[dd];
+        st.out[dd] = m->hbuf[0][dd]; st.cstate[dd] = m->cst[dd];
+    }
+    st.xp = m->xp; st.lens_dev = m->lens_dev; st.B = B; st.T = To; st.hpack = m->hpack;
+    for (int s2 = 0; s2 <= step; ++s2) {
+        st.step = s2;
+        st.dbg = s2 == step ? dbg : nullptr;
+        launch_rnn_step(st, nullptr);
+    }
+    HIP_OK(m, hipDeviceSynchronize());
+    HIP_OK(m, hipMemcpy(stamps_host, dbg, sizeof(unsigned long long) * need, hipMemcpyDeviceToHost));
+    (void)hipFree(dbg);
     return DSMI_OK;
 }

@@ -99,8 +99,10 @@ struct RnnStepLaunch {
     float* out[2];               // per direction [T][B][H]
     float* cstate[2];            // LSTM cell state [B][H] per direction (else null)
     const int32_t* lens_dev;     // [B] output lengths
+    float* hpack;                // [2][D][ceil(B/32)][nq][64][4] packed state (double-buffered by step parity)
     int B, T, step;
     EvPair ev;
+    unsigned long long* dbg = nullptr;   // diagnostics: per-wave timestamps [D*nwg][8 waves][8]
 };
 void launch_rnn_step(const RnnStepLaunch& p, hipStream_t s);
 

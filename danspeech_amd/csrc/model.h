@@ -62,6 +62,7 @@ struct dsmi_model {
     float* hbuf[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     float* cst[2] = {nullptr, nullptr};
     float* look_buf = nullptr;
+    float* hpack = nullptr;
     float* xin = nullptr;
     std::vector<int32_t> host_out_lens;   // output lengths of the batch being processed
     int32_t *lens_dev = nullptr, *sizes_dev = nullptr, *raw_ids = nullptr, *ids = nullptr, *offs = nullptr, *nout = nullptr;

@@ -11,7 +11,7 @@
 // layer's own output buffer (row t-1 / t+1), so the output doubles as the state.
 //
 // Work split: one workgroup owns U = floor(32/G) hidden units of one direction, i.e. G*U <= 32
-// gate rows = one MFMA tile of rows; its 4 waves split K = H four ways and the partial
+// gate rows = one MFMA tile of rows; its 8 waves split K = H eight ways and the partial
 // tiles meet in LDS (fixed summation order -> run-to-run deterministic).  W_hh is
 // pre-packed on the host into the exact lane order of the A operand (1 KiB per wave
 // instruction, fully coalesced); a workgroup always reads the same slice, so it stays
@@ -71,123 +71,184 @@ std::vector<float> pack_whh(const RnnGeom& g, const float* w_hh) {
 struct StepArgs {
     const float* whh[2]; const float* bhh[2]; const float* xp; float* out[2]; float* cst[2];
     const int32_t* lens;
+    float* hpack;              // [2 parity][D][ceil(B/32)][nq][64][4]: h in the B operand's lane order
     int B, T, step, G, H, U, Hs, nq, Np, nwg;
+    unsigned long long* dbg;   // diagnostics build only (STAMP = true)
 };
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
 
-template <int KIND, int NBT>
-__global__ __launch_bounds__(256) void rnn_step_kernel(StepArgs p) {
-    __shared__ __attribute__((aligned(16))) float red[4 * NBT * 32 * 32];
-    const int tid = threadIdx.x, lane = tid & 63, v = tid >> 6;
+#define STAMP_AT(k)                                                                                   \
+    do {                                                                                              \
+        if (STAMP && lane == 0) {                                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                        \
+            p.dbg[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NW + v) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+            __builtin_amdgcn_sched_barrier(0);                                                        \
+        }                                                                                             \
+    } while (0)
+
+// KIND: cell type.  NQW: compile-time upper bound of the 8-wide k-blocks one wave owns (all of
+// its W_hh and h operands are requested in one burst before the first MFMA, so the whole
+// weight slice is in flight at once).  NW: waves per workgroup = K-split factor.
+// One workgroup handles 32 batch rows (blockIdx.z selects the batch tile).
+template <int KIND, int NQW, int NW, bool STAMP = false>
+__global__ __launch_bounds__(NW * 64) void rnn_step_kernel(StepArgs p) {
+    constexpr int NG = KIND == DSMI_RNN_GRU ? 3 : (KIND == DSMI_RNN_LSTM ? 4 : 1);
+    constexpr int NT = NW * 64;
+    constexpr int PP = ((32 / NG) * 32 + NT - 1) / NT;   // (unit, batch) pairs per thread, upper bound
+    __shared__ __attribute__((aligned(16))) float red[NW * 32 * 32];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int v = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave id, provably uniform -> scalar branches
     const int li = lane & 31, hk = lane >> 5;
     const int w = blockIdx.x, d = blockIdx.y;
-    const int b0 = blockIdx.z * (32 * NBT);
+    const int b0 = blockIdx.z * 32;
     const int t = d == 0 ? p.step : p.T - 1 - p.step;
     const int tprev = d == 0 ? t - 1 : t + 1;
     const bool has_prev = tprev >= 0 && tprev < p.T;
     float* outd = p.out[d];
     const float* hprev = outd + (size_t)(has_prev ? tprev : 0) * p.B * p.Hs;
-
-    f32x16 acc[NBT];
-#pragma unroll
-    for (int bt = 0; bt < NBT; ++bt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[bt][r] = 0.f;
-
-    if (has_prev) {
-        const int q0 = (v * p.nq) / 4, q1 = ((v + 1) * p.nq) / 4;
-        const f32x4* wp = reinterpret_cast<const f32x4*>(p.whh[d]) + ((size_t)w * p.nq) * 64 + lane;
-
-        for (int q = q0; q < q1; ++q) {
-            const f32x4 wv = wp[(size_t)q * 64];
-            f32x4 hv[NBT];
-#pragma unroll
-            for (int bt = 0; bt < NBT; ++bt) {
-                const int j = b0 + bt * 32 + li;
-                hv[bt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (j < p.B) hv[bt] = *reinterpret_cast<const f32x4*>(hprev + (size_t)j * p.Hs + 8 * q + 4 * hk);
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int bt = 0; bt < NBT; ++bt)
-                    acc[bt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[c], hv[bt][c], acc[bt], 0, 0, 0);
-        }
-    }
-    // partial tiles -> LDS: D[i][j], col j = lane&31 (batch), row i = (r&3)+8(r>>2)+4hk (gate row)
-#pragma unroll
-    for (int bt = 0; bt < NBT; ++bt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = (r & 3) + 8 * (r >> 2) + 4 * hk;
-            red[((v * NBT + bt) * 32 + i) * 32 + li] = acc[bt][r];
-        }
-    __syncthreads();
-
-    const int nb = min(32 * NBT, p.B - b0);
+    const int nb = min(32, p.B - b0);
     const int GU = p.G * p.U;
     const size_t xcol = (size_t)d * p.nwg * GU + (size_t)w * GU;
-    for (int pr = tid; pr < p.U * nb; pr += 256) {
-        const int bl = pr % nb, u = pr / nb;
+    STAMP_AT(0);
+
+    // ---- 1. request this wave's whole operand slice: W_hh (packed, 1 KiB per instruction) and h
+    const int q0 = (v * p.nq) / NW, q1 = ((v + 1) * p.nq) / NW;
+    f32x4 wv[NQW], hv[NQW];
+    if (has_prev) {
+        const f32x4* wp = reinterpret_cast<const f32x4*>(p.whh[d]) + ((size_t)w * p.nq) * 64 + lane;
+        const f32x4* hq = reinterpret_cast<const f32x4*>(p.hpack) +
+                          ((((size_t)((p.step & 1) ^ 1) * gridDim.y + d) * gridDim.z + blockIdx.z) * p.nq) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < NQW; ++i) {
+            const int q = min(q0 + i, q1 - 1);      // clamp: the duplicate is skipped below
+            wv[i] = wp[(size_t)q * 64];
+            hv[i] = hq[(size_t)q * 64];
+        }
+    }
+    STAMP_AT(1);
+
+    // ---- 2. request the epilogue's operands (independent of the MFMA phase, consumed after it)
+    float xg[PP][NG], bh[PP][NG], hp[PP];
+    int slen[PP];   // raw length: compared only in the epilogue so that no wait lands here
+#pragma unroll
+    for (int i = 0; i < PP; ++i) {
+        const int pr = tid + i * NT;
+        const int bl = pr & 31, u = pr >> 5;
+        const int unit = w * p.U + u;
+        const bool ok = pr < p.U * 32 && bl < nb && unit < p.H;
+        const int b = b0 + bl;
+        hp[i] = 0.f; slen[i] = 0;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) { xg[i][g] = 0.f; bh[i][g] = 0.f; }
+        if (ok) {
+            const float* xr = p.xp + ((size_t)t * p.B + b) * p.Np + xcol + u;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) { xg[i][g] = xr[g * p.U]; bh[i][g] = p.bhh[d][g * p.H + unit]; }
+            if (has_prev) hp[i] = hprev[(size_t)b * p.Hs + unit];
+            slen[i] = p.lens[b];
+        }
+    }
+
+    // ---- 3. MFMA: D[gate row][batch] += W[gate row][k] * h[batch][k] over this wave's k range
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (has_prev) {
+#pragma unroll
+        for (int i = 0; i < NQW; ++i) {
+            if (q0 + i < q1) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[i][c], hv[i][c], acc, 0, 0, 0);
+            }
+            if (i == 3) STAMP_AT(2);
+        }
+    }
+    STAMP_AT(3);
+    // partial tiles -> LDS: D[i][j], col j = lane&31 (batch), row i = (r&3)+8(r>>2)+4hk (gate row)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * hk;
+        red[(v * 32 + i) * 32 + li] = acc[r];
+    }
+    __syncthreads();
+    STAMP_AT(4);
+
+    // ---- 4. K-split reduction in fixed order + cell.  The new state goes to the layer output
+    // (natural layout) and to the packed copy the next step's B operand reads.
+    float* hw = p.hpack + ((((size_t)(p.step & 1) * gridDim.y + d) * gridDim.z + blockIdx.z) * p.nq) * 256;
+#pragma unroll
+    for (int i = 0; i < PP; ++i) {
+        const int pr = tid + i * NT;
+        if (pr >= p.U * 32) break;
+        const int bl = pr & 31, u = pr >> 5;
         const int b = b0 + bl;
         const int unit = w * p.U + u;
         if (unit >= p.Hs) continue;
+        float* hwp = hw + ((size_t)(unit >> 3) * 64 + ((unit >> 2) & 1) * 32 + bl) * 4 + (unit & 3);
+        if (bl >= nb) { *hwp = 0.f; continue; }      // batch padding of the tile: zero operand rows
         float* o = outd + ((size_t)t * p.B + b) * p.Hs + unit;
-        if (unit >= p.H) { *o = 0.f; continue; }
-        const int bt = bl >> 5, bj = bl & 31;
-        float hg[4];
+        if (unit >= p.H) { *o = 0.f; *hwp = 0.f; continue; }
+        float hg[NG];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            if (g < (KIND == DSMI_RNN_GRU ? 3 : (KIND == DSMI_RNN_LSTM ? 4 : 1))) {
-                const int row = g * p.U + u;
-                float s = red[((0 * NBT + bt) * 32 + row) * 32 + bj];
-                s += red[((1 * NBT + bt) * 32 + row) * 32 + bj];
-                s += red[((2 * NBT + bt) * 32 + row) * 32 + bj];
-                s += red[((3 * NBT + bt) * 32 + row) * 32 + bj];
-                hg[g] = s + p.bhh[d][g * p.H + unit];
-            }
+        for (int g = 0; g < NG; ++g) {
+            const int row = g * p.U + u;
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < NW; ++k) s += red[(k * 32 + row) * 32 + bl];
+            hg[g] = s + bh[i][g];
         }
-        const float* xr = p.xp + ((size_t)t * p.B + b) * p.Np + xcol + u;
-        const float hp = has_prev ? hprev[(size_t)b * p.Hs + unit] : 0.f;
-        const bool active = t < p.lens[b];
         float hn;
         if (KIND == DSMI_RNN_GRU) {
-            const float r = sigmoidf_(xr[0] + hg[0]);
-            const float z = sigmoidf_(xr[p.U] + hg[1]);
-            const float n = tanhf(xr[2 * p.U] + r * hg[2]);
-            hn = (1.f - z) * n + z * hp;
+            const float r = sigmoidf_(xg[i][0] + hg[0]);
+            const float z = sigmoidf_(xg[i][1] + hg[1]);
+            const float n = tanhf(xg[i][2] + r * hg[2]);
+            hn = (1.f - z) * n + z * hp[i];
         } else if (KIND == DSMI_RNN_LSTM) {
             float* cp = p.cst[d] + (size_t)b * p.Hs + unit;
             const float c0 = p.step == 0 ? 0.f : *cp;
-            const float ig = sigmoidf_(xr[0] + hg[0]);
-            const float fg = sigmoidf_(xr[p.U] + hg[1]);
-            const float gg = tanhf(xr[2 * p.U] + hg[2]);
-            const float og = sigmoidf_(xr[3 * p.U] + hg[3]);
+            const float ig = sigmoidf_(xg[i][0] + hg[0]);
+            const float fg = sigmoidf_(xg[i][1] + hg[1]);
+            const float gg = tanhf(xg[i][2] + hg[2]);
+            const float og = sigmoidf_(xg[i][3] + hg[3]);
             const float cn = fg * c0 + ig * gg;
             hn = og * tanhf(cn);
-            *cp = active ? cn : c0;
+            *cp = t < slen[i] ? cn : c0;
         } else {
-            hn = tanhf(xr[0] + hg[0]);
+            hn = tanhf(xg[i][0] + hg[0]);
         }
-        *o = active ? hn : 0.f;
+        hn = t < slen[i] ? hn : 0.f;
+        *o = hn;
+        *hwp = hn;
     }
+    STAMP_AT(5);
+}
+
+template <int KIND, int NW>
+static void launch_nw(const StepArgs& a, int D, hipStream_t s, const EvPair& ev) {
+    const int nqw = ceil_div(a.nq, NW);
+    const dim3 grid(a.nwg, D, ceil_div(a.B, 32)), block(NW * 64);
+    if (a.dbg) { hipLaunchKernelGGL((rnn_step_kernel<KIND, 13, NW, true>), grid, block, 0, s, a); return; }
+    if (nqw <= 4) DSMI_LAUNCH((rnn_step_kernel<KIND, 4, NW>), grid, block, 0, s, ev, a);
+    else if (nqw <= 7) DSMI_LAUNCH((rnn_step_kernel<KIND, 7, NW>), grid, block, 0, s, ev, a);
+    else if (nqw <= 10) DSMI_LAUNCH((rnn_step_kernel<KIND, 10, NW>), grid, block, 0, s, ev, a);
+    else if (nqw <= 13) DSMI_LAUNCH((rnn_step_kernel<KIND, 13, NW>), grid, block, 0, s, ev, a);
+    else if (nqw <= 16) DSMI_LAUNCH((rnn_step_kernel<KIND, 16, NW>), grid, block, 0, s, ev, a);
+    else DSMI_LAUNCH((rnn_step_kernel<KIND, 19, NW>), grid, block, 0, s, ev, a);
 }
 
 template <int KIND>
 static void launch_kind(const StepArgs& a, int D, hipStream_t s, const EvPair& ev) {
-    const int B = a.B;
-    if (B <= 32) {
-        DSMI_LAUNCH((rnn_step_kernel<KIND, 1>), dim3(a.nwg, D, 1), dim3(256), 0, s, ev, a);
-    } else if (B <= 64) {
-        DSMI_LAUNCH((rnn_step_kernel<KIND, 2>), dim3(a.nwg, D, 1), dim3(256), 0, s, ev, a);
-    } else {
-        DSMI_LAUNCH((rnn_step_kernel<KIND, 4>), dim3(a.nwg, D, ceil_div(B, 128)), dim3(256), 0, s, ev, a);
-    }
+    // 8 waves split K up to nq = 152 k-blocks (H <= 1216); wider layers use 16 waves (H <= 2432)
+    if (ceil_div(a.nq, 8) <= 19) launch_nw<KIND, 8>(a, D, s, ev);
+    else launch_nw<KIND, 16>(a, D, s, ev);
 }
 
 void launch_rnn_step(const RnnStepLaunch& p, hipStream_t s) {
     StepArgs a;
+    a.dbg = p.dbg;
+    a.hpack = p.hpack;
     for (int d = 0; d < 2; ++d) {
         a.whh[d] = p.whh_packed[d]; a.bhh[d] = p.bhh[d]; a.out[d] = p.out[d]; a.cst[d] = p.cstate[d];
     }

@@ -138,6 +138,10 @@ int dsmi_set_profiling(dsmi_model* m, int level);
 int dsmi_kernel_stats(dsmi_model* m, int kind, int64_t* launches, int64_t* samples, double* avg_us,
                       double* flops_per_launch, double* bytes_per_launch);
 int dsmi_reset_kernel_stats(dsmi_model* m);
+/* Diagnostics build of the recurrent step kernel: per-wave phase timestamps (100 MHz
+ * s_memrealtime ticks) of the launch for `step` of `layer`; stamps_host[D*nwg][8][8]. */
+int dsmi_debug_step_stamps(dsmi_model* m, int layer, int B, int T_out, int step, uint64_t* stamps_host,
+                           int64_t n_words);
 double dsmi_stage_time_us(const dsmi_model* m, int stage);
 /* Kernel launches the last dsmi_forward issued for stage 2 (recurrent steps) and their
  * summed algorithmic FLOPs (SURVEY 8d formula, recurrent part), for roofline maths. */

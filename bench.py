@@ -74,6 +74,8 @@ def main():
     sd = syn.make_state_dict(cfg["conv_layers"], cfg["rnn_type"], cfg["rnn_hidden_size"], cfg["rnn_layers"],
                              bidirectional=cfg["bidirectional"], seed=0, fc_gain=8.0)
     model = _native.NativeModel(cfg, sd, device=local, n_labels=len(labels))
+    frontend = _native.NativeFrontend(device=local)
+    decoder = _native.NativeDecoder(labels, blank_index=0, device=local)
 
     # ---- inputs: rank 0 synthesises, shards go out over RCCL (utterance-level data parallelism)
     if rank == 0:
@@ -86,9 +88,9 @@ def main():
     model.reserve(B, int(frames.max()))
 
     def step():
-        feat, fr = model.features(pcm.view(-1), n)
+        feat, fr = frontend.features(pcm.view(-1), n)
         probs, out_lens = model.forward(feat, fr)
-        dec = model.greedy(probs, out_lens, blank_index=0)
+        dec = decoder.greedy(probs, out_lens)
         ids = parallel.gather_token_ids([d[0] for d in dec], rank, world, torch.device("cuda", local))
         if rank == 0:
             return ["".join(labels[i] for i in seq) for seq in ids]

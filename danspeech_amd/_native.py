@@ -39,8 +39,13 @@ class ModelDesc(C.Structure):
         ("conv_layers", C.c_int32), ("rnn_type", C.c_int32), ("rnn_hidden_size", C.c_int32),
         ("rnn_layers", C.c_int32), ("bidirectional", C.c_int32), ("context", C.c_int32),
         ("n_labels", C.c_int32), ("sample_rate", C.c_int32), ("window_size", C.c_double),
-        ("window_stride", C.c_double), ("window", C.c_int32), ("normalize", C.c_int32),
-        ("pad_mode", C.c_int32),
+    ]
+
+
+class FrontendDesc(C.Structure):
+    _fields_ = [
+        ("sample_rate", C.c_int32), ("window_size", C.c_double), ("window_stride", C.c_double),
+        ("window", C.c_int32), ("normalize", C.c_int32), ("pad_mode", C.c_int32),
     ]
 
 
@@ -59,11 +64,19 @@ _PROTOS = {
     "dsmi_model_destroy": (None, [_vp]),
     "dsmi_last_error": (C.c_char_p, [_vp]),
     "dsmi_seq_lens": (C.c_int, [_vp, _vp, C.c_int, _vp]),
+    "dsmi_frontend_create": (C.c_int, [C.POINTER(FrontendDesc), C.c_int, C.POINTER(_vp)]),
+    "dsmi_frontend_destroy": (None, [_vp]),
+    "dsmi_frontend_last_error": (C.c_char_p, [_vp]),
     "dsmi_features": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _vp]),
+    "dsmi_decoder_create": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.c_int, C.c_int, C.POINTER(_vp)]),
+    "dsmi_decoder_destroy": (None, [_vp]),
+    "dsmi_decoder_last_error": (C.c_char_p, [_vp]),
+    "dsmi_decoder_set_lm": (C.c_int, [_vp, C.c_char_p, C.c_double, C.c_double]),
+    "dsmi_beam": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _vp, _vp, _vp, _vp, _vp]),
     "dsmi_forward": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     "dsmi_conv_stack": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
     "dsmi_rnn_layer": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
-    "dsmi_greedy": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
+    "dsmi_greedy": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "dsmi_set_profiling": (C.c_int, [_vp, C.c_int]),
     "dsmi_stage_time_us": (C.c_double, [_vp, C.c_int]),
     "dsmi_kernel_stats": (C.c_int, [_vp, C.c_int, _i64p, _i64p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
@@ -101,7 +114,7 @@ def _np_ptr(a):
 class NativeModel:
     """Owns one dsmi_model handle (one GPU)."""
 
-    def __init__(self, cfg, state_dict, device=0, audio_conf=None, n_labels=33, pad_mode="reflect"):
+    def __init__(self, cfg, state_dict, device=0, audio_conf=None, n_labels=33):
         L = lib()
         ac = audio_conf or {}
         d = ModelDesc()
@@ -114,10 +127,6 @@ class NativeModel:
         d.n_labels = int(n_labels)
         d.sample_rate = int(ac.get("sampling_rate", 16000))
         d.window_size = float(ac.get("window_size", 0.02))
-        d.window_stride = float(ac.get("window_stride", 0.01))
-        d.window = WINDOWS[ac.get("window", "hamming")]
-        d.normalize = int(bool(ac.get("normalize", True)))
-        d.pad_mode = PAD_MODES[pad_mode]
         self.desc = d
         self.n_labels = int(n_labels)
         self.device = device
@@ -166,23 +175,6 @@ class NativeModel:
         import torch
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
-    def features(self, pcm_dev, n_samples, t_stride=None):
-        """pcm_dev: 1-D CUDA tensor (int16/float32/float64) with the clips back to back."""
-        import torch
-        n_samples = np.ascontiguousarray(n_samples, dtype=np.int64)
-        B = len(n_samples)
-        hop = int(self.desc.sample_rate * self.desc.window_stride)
-        n_freq = int(self.desc.sample_rate * self.desc.window_size) // 2 + 1
-        frames = 1 + n_samples // hop
-        if t_stride is None:
-            t_stride = int(frames.max())
-        dt = {torch.int16: 0, torch.float32: 1, torch.float64: 2}[pcm_dev.dtype]
-        feat = torch.empty((B, 1, n_freq, t_stride), dtype=torch.float32, device=pcm_dev.device)
-        fr = np.empty(B, dtype=np.int32)
-        self._check(lib().dsmi_features(self._h, pcm_dev.data_ptr(), dt, _np_ptr(n_samples), B, feat.data_ptr(),
-                                        int(t_stride), _np_ptr(fr), self._stream()))
-        return feat, fr
-
     def forward(self, feat, lens, out=None):
         """feat: CUDA float32 [B,1,F,T] contiguous; lens sorted descending. -> (probs [B,T',C], out_lens)."""
         import torch
@@ -219,18 +211,7 @@ class NativeModel:
         self._check(lib().dsmi_rnn_layer(self._h, int(layer), x.data_ptr(), _np_ptr(out_lens), B, T, y.data_ptr(), self._stream()))
         return y
 
-    def greedy(self, probs, sizes=None, blank_index=0):
-        """probs: CUDA [B,T,C] -> list of (ids, offsets) int32 arrays per utterance."""
-        B, T = probs.shape[0], probs.shape[1]
-        ids = np.empty((B, T), dtype=np.int32)
-        offs = np.empty((B, T), dtype=np.int32)
-        n = np.empty(B, dtype=np.int32)
-        sz = None if sizes is None else np.ascontiguousarray(sizes, dtype=np.int32)
-        self._check(lib().dsmi_greedy(self._h, probs.data_ptr(), None if sz is None else _np_ptr(sz), B, T,
-                                      int(blank_index), _np_ptr(ids), _np_ptr(offs), _np_ptr(n), self._stream()))
-        return [(ids[b, :n[b]].copy(), offs[b, :n[b]].copy()) for b in range(B)]
-
-    KERNEL_KINDS = ["stft", "conv1", "conv2", "conv3", "gemm_l0", "gemm", "rnn_step", "head", "greedy", "beam"]
+    KERNEL_KINDS = ["unused", "conv1", "conv2", "conv3", "gemm_l0", "gemm", "rnn_step", "head", "greedy", "beam"]
 
     def set_profiling(self, level):
         self._check(lib().dsmi_set_profiling(self._h, int(level)))
@@ -256,3 +237,118 @@ class NativeModel:
         n = C.c_int64(); a = C.c_double(); b = C.c_double()
         self._check(lib().dsmi_last_forward_stats(self._h, C.byref(n), C.byref(a), C.byref(b)))
         return n.value, a.value, b.value
+
+
+def _stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class NativeFrontend:
+    """Owns one dsmi_frontend handle: SpectrogramAudioParser on one GPU."""
+
+    def __init__(self, audio_conf=None, device=0, pad_mode="reflect"):
+        L = lib()
+        ac = audio_conf or {}
+        d = FrontendDesc()
+        d.sample_rate = int(ac.get("sampling_rate", 16000))
+        d.window_size = float(ac.get("window_size", 0.02))
+        d.window_stride = float(ac.get("window_stride", 0.01))
+        d.window = WINDOWS[ac.get("window", "hamming")]
+        d.normalize = int(bool(ac.get("normalize", True)))
+        d.pad_mode = PAD_MODES[pad_mode]
+        self.desc = d
+        self.device = device
+        self.n_fft = int(d.sample_rate * d.window_size)
+        self.hop = int(d.sample_rate * d.window_stride)
+        self.n_freq = self.n_fft // 2 + 1
+        h = _vp()
+        rc = L.dsmi_frontend_create(C.byref(d), device, C.byref(h))
+        if rc != 0:
+            raise DsmiError(rc, (L.dsmi_frontend_last_error(None) or b"").decode())
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().dsmi_frontend_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def features(self, pcm_dev, n_samples, t_stride=None):
+        """pcm_dev: 1-D CUDA tensor (int16/float32/float64), clips back to back.
+        -> (feat [B,1,F,t_stride] float32 CUDA, frames int32[B])."""
+        import torch
+        n_samples = np.ascontiguousarray(n_samples, dtype=np.int64)
+        B = len(n_samples)
+        frames = 1 + n_samples // self.hop
+        if t_stride is None:
+            t_stride = int(frames.max())
+        dt = {torch.int16: 0, torch.float32: 1, torch.float64: 2}[pcm_dev.dtype]
+        feat = torch.empty((B, 1, self.n_freq, t_stride), dtype=torch.float32, device=pcm_dev.device)
+        fr = np.empty(B, dtype=np.int32)
+        rc = lib().dsmi_features(self._h, pcm_dev.data_ptr(), dt, _np_ptr(n_samples), B, feat.data_ptr(),
+                                 int(t_stride), _np_ptr(fr), _stream())
+        if rc != 0:
+            raise DsmiError(rc, (lib().dsmi_frontend_last_error(self._h) or b"").decode())
+        return feat, fr
+
+
+class NativeDecoder:
+    """Owns one dsmi_decoder handle: greedy and beam-search CTC decoding on one GPU."""
+
+    def __init__(self, labels, blank_index=0, device=0):
+        L = lib()
+        self.labels = labels
+        arr = (C.c_char_p * len(labels))(*[c.encode("utf-8") for c in labels])
+        h = _vp()
+        rc = L.dsmi_decoder_create(device, arr, len(labels), int(blank_index), C.byref(h))
+        if rc != 0:
+            raise DsmiError(rc, (L.dsmi_decoder_last_error(None) or b"").decode())
+        self._h = h
+
+    def _check(self, rc):
+        if rc != 0:
+            raise DsmiError(rc, (lib().dsmi_decoder_last_error(self._h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().dsmi_decoder_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_lm(self, lm_path, alpha, beta):
+        self._check(lib().dsmi_decoder_set_lm(self._h, lm_path.encode() if lm_path else None, float(alpha), float(beta)))
+
+    def greedy(self, probs, sizes=None):
+        """probs: CUDA [B,T,C] -> list of (ids, offsets) int32 arrays per utterance."""
+        B, T = probs.shape[0], probs.shape[1]
+        ids = np.empty((B, T), dtype=np.int32)
+        offs = np.empty((B, T), dtype=np.int32)
+        n = np.empty(B, dtype=np.int32)
+        sz = None if sizes is None else np.ascontiguousarray(sizes, dtype=np.int32)
+        self._check(lib().dsmi_greedy(self._h, probs.data_ptr(), None if sz is None else _np_ptr(sz), B, T,
+                                      _np_ptr(ids), _np_ptr(offs), _np_ptr(n), _stream()))
+        return [(ids[b, :n[b]].copy(), offs[b, :n[b]].copy()) for b in range(B)]
+
+    def beam(self, probs, sizes=None, beam_width=64, cutoff_top_n=40, cutoff_prob=1.0):
+        """probs: CUDA [B,T,C] -> (tokens [B,beam,T], timesteps [B,beam,T], lens [B,beam], scores [B,beam])."""
+        B, T = probs.shape[0], probs.shape[1]
+        tok = np.zeros((B, beam_width, T), dtype=np.int32)
+        ts = np.zeros((B, beam_width, T), dtype=np.int32)
+        ln = np.zeros((B, beam_width), dtype=np.int32)
+        sc = np.zeros((B, beam_width), dtype=np.float32)
+        sz = None if sizes is None else np.ascontiguousarray(sizes, dtype=np.int32)
+        self._check(lib().dsmi_beam(self._h, probs.data_ptr(), None if sz is None else _np_ptr(sz), B, T, int(beam_width),
+                                    int(cutoff_top_n), float(cutoff_prob), _np_ptr(tok), _np_ptr(ts), _np_ptr(ln),
+                                    _np_ptr(sc), _stream()))
+        return tok, ts, ln, sc

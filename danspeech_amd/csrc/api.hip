@@ -81,8 +81,7 @@ extern "C" int dsmi_model_create(const dsmi_model_desc* d, int device, dsmi_mode
     dsmi_model* m = new dsmi_model();
     m->desc = *d;
     m->device = device;
-    m->n_fft = (int)(d->sample_rate * d->window_size);      // parsers.py:47
-    m->hop = (int)(d->sample_rate * d->window_stride);      // parsers.py:48
+    m->n_fft = (int)(d->sample_rate * d->window_size);      // model.py:354: int(floor(rate * size / 2) + 1) below
     m->n_freq = m->n_fft / 2 + 1;                            // model.py:354
     int f = m->n_freq;
     for (int l = 0; l < d->conv_layers; ++l) {
@@ -215,7 +214,6 @@ extern "C" int dsmi_model_finalize(dsmi_model* m) {
         if ((rc = upload(m, b, &m->fc_b))) return rc;
         if ((rc = upload(m, pack_fc(fw->data.data(), d.n_labels, H), &m->fc_wp))) return rc;
     }
-    if ((rc = features_init(m))) return rc;
     m->tensors.clear();
     for (int i = 0; i < 8; ++i) HIP_OK(m, hipEventCreate(&m->ev[i]));
     m->finalized = true;
@@ -308,7 +306,6 @@ extern "C" void dsmi_model_destroy(dsmi_model* m) {
         for (int i = 0; i < 8; ++i) (void)hipEventDestroy(m->ev[i]);
     timer_resolve(m);
     for (hipEvent_t e : m->kt.free_events) (void)hipEventDestroy(e);
-    features_destroy(m);
     delete m;
 }
 
@@ -524,34 +521,6 @@ extern "C" int dsmi_rnn_layer(dsmi_model* m, int layer, const float* x, const in
     }
     run_rnn_layer(m, layer, gl, B, To, 0, s);
     launch_add2(m->hbuf[0][0], m->geom.D == 2 ? m->hbuf[0][1] : nullptr, y, (size_t)To * B, H, m->Hs, s);
-    HIP_OK(m, hipStreamSynchronize(s));
-    HIP_OK(m, hipGetLastError());
-    return DSMI_OK;
-}
-
-extern "C" int dsmi_greedy(dsmi_model* m, const float* probs, const int32_t* sizes, int B, int To, int blank,
-                           int32_t* ids, int32_t* offsets, int32_t* n_out, void* stream) {
-    if (!m) return DSMI_ERR_INVALID;
-    if (!m->finalized) return fail(m, DSMI_ERR_NOT_READY, "dsmi_model_finalize has not been called");
-    if (!probs || !ids || !offsets || !n_out || B < 1 || To < 1) return fail(m, DSMI_ERR_INVALID, "bad greedy arguments");
-    HIP_OK(m, hipSetDevice(m->device));
-    hipStream_t s = (hipStream_t)stream;
-    // scratch independent of dsmi_reserve (probs may come from anywhere)
-    if ((size_t)B * To > m->greedy_cap) {
-        HIP_OK(m, hipDeviceSynchronize());
-        for (void* p : {(void*)m->g_raw, (void*)m->g_ids, (void*)m->g_offs, (void*)m->g_nout, (void*)m->g_sizes}) if (p) (void)hipFree(p);
-        m->greedy_cap = (size_t)B * To;
-        HIP_OK(m, hipMalloc((void**)&m->g_raw, sizeof(int32_t) * m->greedy_cap));
-        HIP_OK(m, hipMalloc((void**)&m->g_ids, sizeof(int32_t) * m->greedy_cap));
-        HIP_OK(m, hipMalloc((void**)&m->g_offs, sizeof(int32_t) * m->greedy_cap));
-        HIP_OK(m, hipMalloc((void**)&m->g_nout, sizeof(int32_t) * m->greedy_cap));
-        HIP_OK(m, hipMalloc((void**)&m->g_sizes, sizeof(int32_t) * m->greedy_cap));
-    }
-    if (sizes) HIP_OK(m, hipMemcpyAsync(m->g_sizes, sizes, sizeof(int32_t) * B, hipMemcpyHostToDevice, s));
-    launch_greedy(probs, sizes ? m->g_sizes : nullptr, B, To, m->desc.n_labels, blank, m->g_raw, m->g_ids, m->g_offs, m->g_nout, s);
-    HIP_OK(m, hipMemcpyAsync(ids, m->g_ids, sizeof(int32_t) * (size_t)B * To, hipMemcpyDeviceToHost, s));
-    HIP_OK(m, hipMemcpyAsync(offsets, m->g_offs, sizeof(int32_t) * (size_t)B * To, hipMemcpyDeviceToHost, s));
-    HIP_OK(m, hipMemcpyAsync(n_out, m->g_nout, sizeof(int32_t) * B, hipMemcpyDeviceToHost, s));
     HIP_OK(m, hipStreamSynchronize(s));
     HIP_OK(m, hipGetLastError());
     return DSMI_OK;

@@ -1,0 +1,594 @@
+// Decoders on the GPU (gfx950): the handle behind dsmi_decoder*, greedy decode, and CTC prefix
+// beam search with an optional word-level n-gram scorer.
+//
+// Replaces GreedyDecoder.decode and BeamCTCDecoder.decode of the reference
+// (danspeech/deepspeech/decoder.py:183-198, 129-144).  The reference's beam search is the
+// un-vendored third-party ctcdecode (C++, thread pool over the batch); here one workgroup
+// decodes one utterance, the batch runs in parallel across CUs, and nothing leaves the GPU
+// until the final beams.  Algorithm and the deliberate float64 carry: see oracle/beam.py,
+// which restates the same published algorithm and is what the parity tests compare with.
+//
+// Per frame, for one utterance (256 threads):
+//   1. log p(c) = log(p + FLT_MIN), vocabulary pruning (cutoff_prob / cutoff_top_n);
+//   2. every (beam entry, character) pair in parallel: blank / repeat contributions go to the
+//      entry, an extension looks its child up in the utterance's prefix-trie hash table,
+//      checks the dictionary trie, adds alpha * ln P_lm + beta on the space character, and
+//      becomes a candidate (or feeds an entry already in the beam);
+//   3. exact top-`beam` of the candidates by (score desc, last character asc) with an 8-pass
+//      radix select on the order-preserving bits of the float64 score;
+//   4. survivors are committed (new trie nodes, hash insert), the rest are unlinked with the
+//      reference's "remove" semantics so that emission timesteps behave the same.
+#include "common.h"
+#include "lm.h"
+#include "lm.cpp.inc"
+
+#include <algorithm>
+#include <cmath>
+
+using namespace dsmi;
+
+namespace {
+
+constexpr int BT = 256;           // threads per utterance
+constexpr int MAXCTX = kMaxOrder - 1;
+constexpr int F_EXISTS = 1, F_DELETED = 2;
+
+struct BeamArgs {
+    const float* probs; const int32_t* sizes; int T, C, blank, space, beam, cutoff_top_n; float cutoff_prob;
+    int has_lm, order; double alpha, beta;
+    const LmEntry* lm_tab; uint64_t lm_mask; const int32_t* trie_next; const int32_t* trie_word; int unk, bos;
+    // per-utterance node pool (capacity ncap) and hash table (hsize, power of two)
+    int ncap, hsize;
+    int32_t *parent, *ch, *tstep, *dstate, *nchild, *flags, *slot, *ctx, *htab, *nnodes;
+    double* lpc;
+    // outputs
+    int32_t *out_tok, *out_step, *out_len, *out_n; double* out_score;
+};
+
+__device__ __forceinline__ double lse2(double x, double y) {
+    if (x == -INFINITY) return y;
+    if (y == -INFINITY) return x;
+    const double m = fmax(x, y);
+    return log(exp(x - m) + exp(y - m)) + m;
+}
+
+__device__ __forceinline__ uint64_t okey(double v) {   // order-preserving bits, > 0 for every double
+    uint64_t u = (uint64_t)__double_as_longlong(v);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+
+__device__ __forceinline__ uint32_t hmix(int parent, int c) {
+    uint32_t h = (uint32_t)parent * 0x9E3779B1u + (uint32_t)c * 0x85EBCA77u;
+    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
+    return h;
+}
+
+__global__ __launch_bounds__(BT) void beam_kernel(BeamArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int C = a.C, BW = a.beam, NMAX = BW * (C + 1);
+    // ---- LDS carve
+    double* lp = reinterpret_cast<double*>(smem_raw);                 // [128]
+    double* sd = lp + 128;                                            // [2] scalars (min_cutoff)
+    double* e_bprev = sd + 2;                                         // entry arrays [2][BW] (double-buffered)
+    double* e_nbprev = e_bprev + 2 * BW;
+    double* e_score = e_nbprev + 2 * BW;
+    double* e_bcur = e_score + 2 * BW;                                // [BW]
+    double* e_rep = e_bcur + BW;
+    double* e_ext = e_rep + BW;
+    double* c_logp = e_ext + BW;                                      // [NMAX]
+    uint64_t* c_key = reinterpret_cast<uint64_t*>(c_logp + NMAX);     // [NMAX]
+    uint64_t* su = c_key + NMAX;                                      // [2] scalars (radix prefix)
+    int* e_node = reinterpret_cast<int*>(su + 2);                     // [2][BW]
+    int* e_ch = e_node + 2 * BW;                                      // [2][BW]
+    int* c_child = e_ch + 2 * BW;                                     // [NMAX]
+    int* c_surv = c_child + NMAX;                                     // [NMAX]
+    int* use = c_surv + NMAX;                                         // [128]
+    unsigned* hist = reinterpret_cast<unsigned*>(use + 128);          // [256]
+    int* scan = reinterpret_cast<int*>(hist + 256);                   // [BT + 1]
+    int* si = scan + BT + 1;                                          // [8] scalars
+#define s_nb si[0]
+#define s_full si[1]
+#define s_m si[2]
+#define s_nuse si[3]
+#define s_kk si[4]
+#define s_mincut sd[0]
+#define s_prefix su[0]
+
+    // ---- per-utterance global state
+    const size_t nb0 = (size_t)b * a.ncap;
+    int32_t* parent = a.parent + nb0; int32_t* chn = a.ch + nb0; int32_t* tstep = a.tstep + nb0;
+    int32_t* dstate = a.dstate + nb0; int32_t* nchild = a.nchild + nb0; int32_t* flags = a.flags + nb0;
+    int32_t* slot = a.slot + nb0; int32_t* ctx = a.ctx + nb0 * MAXCTX; double* lpc = a.lpc + nb0;
+    int32_t* htab = a.htab + (size_t)b * a.hsize;
+    int32_t* nnodes = a.nnodes + b;
+    const unsigned hmask = (unsigned)a.hsize - 1;
+    const int T = a.sizes ? min(a.sizes[b], a.T) : a.T;
+    const float* pb = a.probs + (size_t)b * a.T * C;
+    const int NCTX = a.order - 1;
+
+    for (int i = tid; i < a.hsize; i += BT) htab[i] = -1;
+    if (tid == 0) {
+        parent[0] = -1; chn[0] = -1; tstep[0] = 0; dstate[0] = 0; nchild[0] = 0; flags[0] = F_EXISTS; slot[0] = 0; lpc[0] = -INFINITY;
+        for (int k = 0; k < MAXCTX; ++k) ctx[k] = a.bos;
+        *nnodes = 1;
+        e_node[0] = 0; e_ch[0] = -1; e_bprev[0] = 0.0; e_nbprev[0] = -INFINITY; e_score[0] = 0.0;
+        s_nb = 1;
+    }
+    __syncthreads();
+    int cur = 0;
+
+    for (int t = 0; t < T; ++t) {
+        const int nb = s_nb;
+        double* bprev = e_bprev + cur * BW; double* nbprev = e_nbprev + cur * BW; double* score = e_score + cur * BW;
+        int* node = e_node + cur * BW; int* ech = e_ch + cur * BW;
+        const float* pr = pb + (size_t)t * C;
+        // ---- 1. log-probabilities and vocabulary pruning (decoder_utils get_pruned_log_probs)
+        for (int c = tid; c < C; c += BT) { lp[c] = log((double)pr[c] + 1.17549435e-38); use[c] = 1; }
+        __syncthreads();
+        if (tid == 0) {
+            s_nuse = C;
+            if (a.cutoff_prob < 1.0f || a.cutoff_top_n < C) {
+                // selection by repeated maximum: C is small (<= 128)
+                for (int c = 0; c < C; ++c) use[c] = 0;
+                double cum = 0.0; int len = 0;
+                const int maxlen = a.cutoff_prob < 1.0f ? C : a.cutoff_top_n;
+                while (len < maxlen) {
+                    int best = -1; float bv = -1.f;
+                    for (int c = 0; c < C; ++c) if (!use[c] && pr[c] > bv) { bv = pr[c]; best = c; }
+                    if (best < 0) break;
+                    use[best] = 1; ++len; cum += (double)bv;
+                    if (a.cutoff_prob < 1.0f && (cum >= (double)a.cutoff_prob || len >= a.cutoff_top_n)) break;
+                }
+                s_nuse = len;
+            }
+            // ---- min_cutoff / full_beam (scorer only)
+            s_full = 0; s_mincut = -INFINITY;
+            if (a.has_lm) {
+                double mn = INFINITY;
+                for (int i = 0; i < nb; ++i) mn = fmin(mn, score[i]);
+                const double blp = pr[a.blank] > 0.f ? log((double)pr[a.blank]) : -INFINITY;
+                s_mincut = mn + blp - fmax(0.0, a.beta);
+                s_full = nb == BW;
+            }
+        }
+        for (int i = tid; i < nb; i += BT) { e_bcur[i] = -INFINITY; e_rep[i] = -INFINITY; e_ext[i] = -INFINITY; }
+        __syncthreads();
+        const bool full = s_full != 0;
+        const double mincut = s_mincut;
+
+        // ---- 2. all (entry, character) pairs
+        const int NP = nb * C;
+        for (int idx = tid; idx < NP; idx += BT) {
+            const int i = idx / C, c = idx - i * C;
+            c_key[idx] = 0; c_child[idx] = -2;
+            if (!use[c]) continue;
+            const double l = lp[c], sc = score[i];
+            if (full && l + sc < mincut) continue;
+            if (c == a.blank) { e_bcur[i] = l + sc; continue; }
+            const int lastc = ech[i];
+            if (c == lastc) e_rep[i] = l + nbprev[i];
+            const int pn = node[i];
+            // child lookup in the prefix trie
+            int child = -1;
+            for (unsigned s = hmix(pn, c) & hmask;; s = (s + 1) & hmask) {
+                const int id = htab[s];
+                if (id < 0) break;
+                if (parent[id] == pn && chn[id] == c) { child = id; break; }
+            }
+            const bool alive = child >= 0 && !(flags[child] & F_DELETED);
+            const int ds = dstate[pn];
+            if (!alive && a.has_lm) {   // dictionary: a new child needs an arc (space: a word must end here)
+                const bool ok = c == a.space ? a.trie_word[ds] >= 0 : a.trie_next[(size_t)ds * C + c] >= 0;
+                if (!ok) continue;
+            }
+            double logp = -INFINITY;
+            if (c == lastc) { if (bprev[i] > -INFINITY) logp = l + bprev[i]; }
+            else logp = l + sc;
+            if (a.has_lm && c == a.space) {
+                const int w = a.trie_word[ds];
+                double lm = kOovScore;
+                if (w >= 0) lm = (double)lm_cond_log10(a.lm_tab, a.lm_mask, ctx + (size_t)pn * MAXCTX, NCTX, w, a.unk) / (double)kLog10E;
+                logp += lm * a.alpha;
+                logp += a.beta;
+            }
+            if (alive) {
+                if (lpc[child] < l) { lpc[child] = l; tstep[child] = t; }
+                if (flags[child] & F_EXISTS) { e_ext[slot[child]] = logp; continue; }
+            }
+            c_logp[idx] = logp; c_child[idx] = alive ? child : (child >= 0 ? -3 - child : -1);   // <= -3: reuse deleted id
+            c_key[idx] = okey(logp);
+        }
+        __syncthreads();
+        // entries themselves
+        for (int i = tid; i < nb; i += BT) {
+            const double nbc = lse2(e_rep[i], e_ext[i]);
+            e_rep[i] = nbc;                         // now nb_cur
+            const double s = lse2(e_bcur[i], nbc);
+            c_logp[NP + i] = s; c_child[NP + i] = node[i]; c_key[NP + i] = okey(s);
+        }
+        __syncthreads();
+        const int N = NP + nb;
+
+        // ---- 3. exact top-BW selection
+        {
+            int cnt = 0;
+            for (int idx = tid; idx < N; idx += BT) cnt += c_key[idx] != 0;
+            for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+            if ((tid & 63) == 0) scan[tid >> 6] = cnt;
+            __syncthreads();
+            if (tid == 0) s_m = scan[0] + scan[1] + scan[2] + scan[3];
+            __syncthreads();
+        }
+        const int M = s_m;
+        if (M <= BW) {
+            for (int idx = tid; idx < N; idx += BT) c_surv[idx] = c_key[idx] != 0;
+        } else {
+            if (tid == 0) { s_prefix = 0; s_kk = BW; }
+            for (int pass = 0; pass < 8; ++pass) {
+                const int shift = 56 - 8 * pass;
+                hist[tid] = 0;
+                __syncthreads();
+                const uint64_t pre = s_prefix;
+                for (int idx = tid; idx < N; idx += BT) {
+                    const uint64_t k = c_key[idx];
+                    if (k != 0 && (pass == 0 || (k >> (shift + 8)) == pre)) atomicAdd(&hist[(unsigned)(k >> shift) & 255u], 1u);
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    unsigned kk = (unsigned)s_kk, cum = 0;
+                    int d = 255;
+                    for (; d > 0; --d) { if (cum + hist[d] >= kk) break; cum += hist[d]; }
+                    s_kk = (int)(kk - cum);
+                    s_prefix = (pre << 8) | (unsigned)d;
+                }
+                __syncthreads();
+            }
+            const uint64_t thr = s_prefix;
+            const int need = (int)s_kk;          // how many of the keys equal to thr survive
+            // ties at the threshold: (character asc, candidate index asc)
+            for (int idx = tid; idx < N; idx += BT) {
+                const uint64_t k = c_key[idx];
+                int sv = k > thr;
+                if (k == thr) {
+                    const int myc = idx < NP ? idx % C : e_ch[cur * BW + (idx - NP)];
+                    int rank = 0;
+                    for (int j = 0; j < N; ++j) {
+                        if (c_key[j] != thr || j == idx) continue;
+                        const int oc = j < NP ? j % C : e_ch[cur * BW + (j - NP)];
+                        rank += (oc < myc) || (oc == myc && j < idx);
+                    }
+                    sv = rank < need;
+                }
+                c_surv[idx] = sv;
+            }
+        }
+        __syncthreads();
+        // ---- deterministic slot numbers: exclusive scan of the survivor flags in index order
+        const int per = (N + BT - 1) / BT;
+        const int i0 = tid * per, i1 = min(i0 + per, N);
+        int local = 0;
+        for (int idx = i0; idx < i1; ++idx) local += c_surv[idx];
+        scan[tid] = local;
+        __syncthreads();
+        if (tid == 0) {
+            int acc = 0;
+            for (int i = 0; i < BT; ++i) { const int v = scan[i]; scan[i] = acc; acc += v; }
+            scan[BT] = acc;
+        }
+        __syncthreads();
+        const int nnext = scan[BT];
+        const int nxt = cur ^ 1;
+        // ---- 4a. commit survivors (new nodes first so that child counts are up before any removal)
+        {
+            int pos = scan[tid];
+            for (int idx = i0; idx < i1; ++idx) {
+                if (!c_surv[idx]) continue;
+                const int sl = pos++;
+                if (idx >= NP) {                                   // an entry that stays
+                    const int i = idx - NP;
+                    e_node[nxt * BW + sl] = node[i]; e_ch[nxt * BW + sl] = ech[i];
+                    e_bprev[nxt * BW + sl] = e_bcur[i]; e_nbprev[nxt * BW + sl] = e_rep[i]; e_score[nxt * BW + sl] = c_logp[idx];
+                    slot[node[i]] = sl;
+                    continue;
+                }
+                const int i = idx / C, c = idx - i * C;
+                const int pn = node[i];
+                int id = c_child[idx];
+                const double l = lp[c];
+                if (id >= 0) {                                     // dormant node (kept alive by descendants) comes back
+                    atomicOr(&flags[id], F_EXISTS);
+                } else {
+                    const bool reuse = id <= -3;
+                    id = reuse ? -3 - id : atomicAdd(nnodes, 1);
+                    parent[id] = pn; chn[id] = c; tstep[id] = t; lpc[id] = l; nchild[id] = 0; flags[id] = F_EXISTS;
+                    const int ds = dstate[pn];
+                    const bool sp = a.has_lm && c == a.space;
+                    dstate[id] = a.has_lm ? (sp ? 0 : a.trie_next[(size_t)ds * C + c]) : 0;
+                    const int w = sp ? a.trie_word[ds] : -1;
+                    for (int k = 0; k < MAXCTX; ++k) {
+                        int v = ctx[(size_t)pn * MAXCTX + k];
+                        if (sp) v = k + 1 < NCTX ? ctx[(size_t)pn * MAXCTX + k + 1] : (k + 1 == NCTX ? w : a.bos);
+                        ctx[(size_t)id * MAXCTX + k] = v;
+                    }
+                    atomicAdd(&nchild[pn], 1);
+                    if (!reuse) {
+                        for (unsigned s = hmix(pn, c) & hmask;; s = (s + 1) & hmask)
+                            if (atomicCAS(&htab[s], -1, id) == -1) break;
+                    }
+                }
+                slot[id] = sl;
+                e_node[nxt * BW + sl] = id; e_ch[nxt * BW + sl] = c;
+                e_bprev[nxt * BW + sl] = -INFINITY; e_nbprev[nxt * BW + sl] = c_logp[idx]; e_score[nxt * BW + sl] = c_logp[idx];
+            }
+        }
+        __syncthreads();
+        // ---- 4b. PathTrie::remove for the entries that fell out
+        for (int i = tid; i < nb; i += BT) {
+            if (c_surv[NP + i]) continue;
+            int n = node[i];
+            atomicAnd(&flags[n], ~F_EXISTS);
+            slot[n] = -1;
+        }
+        __syncthreads();
+        for (int i = tid; i < nb; i += BT) {
+            if (c_surv[NP + i]) continue;
+            int n = node[i];
+            while (n > 0) {
+                if (atomicAdd(&nchild[n], 0) != 0) break;
+                const int f = atomicAdd(&flags[n], 0);
+                if (f & F_EXISTS) break;
+                if (atomicOr(&flags[n], F_DELETED) & F_DELETED) break;    // someone else unlinked it
+                const int p = parent[n];
+                if (atomicSub(&nchild[p], 1) != 1) break;
+                n = p;
+            }
+        }
+        if (tid == 0) s_nb = nnext;
+        __syncthreads();
+        cur = nxt;
+    }
+
+    // ---- final: trailing partial word, order, write out
+    {
+        const int nb = s_nb;
+        double* score = e_score + cur * BW; int* node = e_node + cur * BW; int* ech = e_ch + cur * BW;
+        if (a.has_lm) {
+            for (int i = tid; i < nb; i += BT) {
+                const int n = node[i];
+                if (n != 0 && ech[i] != a.space) {
+                    const int w = a.trie_word[dstate[n]];
+                    double lm = kOovScore;
+                    if (w >= 0) lm = (double)lm_cond_log10(a.lm_tab, a.lm_mask, ctx + (size_t)n * MAXCTX, NCTX, w, a.unk) / (double)kLog10E;
+                    double s = lm * a.alpha;
+                    s += a.beta;
+                    score[i] += s;
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < nb; i += BT) {
+            int rank = 0;
+            for (int j = 0; j < nb; ++j) {
+                if (j == i) continue;
+                rank += score[j] > score[i] || (score[j] == score[i] && (ech[j] < ech[i] || (ech[j] == ech[i] && j < i)));
+            }
+            int len = 0;
+            for (int n = node[i]; n > 0; n = parent[n]) ++len;
+            const size_t o = ((size_t)b * BW + rank) * a.T;
+            int k = len;
+            for (int n = node[i]; n > 0; n = parent[n]) { --k; a.out_tok[o + k] = chn[n]; a.out_step[o + k] = tstep[n]; }
+            a.out_len[(size_t)b * BW + rank] = len;
+            a.out_score[(size_t)b * BW + rank] = score[i];
+        }
+        if (tid == 0) a.out_n[b] = nb;
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+struct dsmi_decoder {
+    int device = 0;
+    std::vector<std::string> labels;
+    int blank = 0, space = -2;
+    std::string err;
+    // greedy scratch
+    size_t greedy_cap = 0;
+    int32_t *g_raw = nullptr, *g_ids = nullptr, *g_offs = nullptr, *g_nout = nullptr, *g_sizes = nullptr;
+    // LM
+    bool has_lm = false;
+    HostLM lm;
+    double alpha = 0, beta = 0;
+    LmEntry* d_tab = nullptr; int32_t *d_next = nullptr, *d_word = nullptr;
+    // beam workspace
+    size_t ws_bytes = 0;
+    unsigned char* ws = nullptr;
+};
+
+static thread_local std::string g_dec_error;
+
+#define DEC_HIP(d, expr)                                                                  \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess) { (d)->err = std::string(#expr) + ": " + hipGetErrorString(e_); return DSMI_ERR_HIP; } \
+    } while (0)
+
+extern "C" int dsmi_decoder_create(int device, const char* const* labels, int n_labels, int blank, dsmi_decoder** out) {
+    if (!labels || !out || n_labels < 1 || n_labels > 128 || blank < 0 || blank >= n_labels) { g_dec_error = "bad decoder arguments"; return DSMI_ERR_INVALID; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { g_dec_error = "no such HIP device"; return DSMI_ERR_HIP; }
+    dsmi_decoder* d = new dsmi_decoder();
+    d->device = device;
+    d->blank = blank;
+    for (int i = 0; i < n_labels; ++i) {
+        d->labels.push_back(labels[i] ? labels[i] : "");
+        if (d->labels.back() == " ") d->space = i;     // Decoder.__init__, decoder.py:39-42
+    }
+    *out = d;
+    return DSMI_OK;
+}
+
+static void free_lm(dsmi_decoder* d) {
+    if (d->d_tab) (void)hipFree(d->d_tab);
+    if (d->d_next) (void)hipFree(d->d_next);
+    if (d->d_word) (void)hipFree(d->d_word);
+    d->d_tab = nullptr; d->d_next = nullptr; d->d_word = nullptr;
+    d->has_lm = false;
+    d->lm = HostLM();
+}
+
+extern "C" void dsmi_decoder_destroy(dsmi_decoder* d) {
+    if (!d) return;
+    (void)hipSetDevice(d->device);
+    (void)hipDeviceSynchronize();
+    for (void* p : {(void*)d->g_raw, (void*)d->g_ids, (void*)d->g_offs, (void*)d->g_nout, (void*)d->g_sizes, (void*)d->ws}) if (p) (void)hipFree(p);
+    free_lm(d);
+    delete d;
+}
+
+extern "C" const char* dsmi_decoder_last_error(const dsmi_decoder* d) { return d ? d->err.c_str() : g_dec_error.c_str(); }
+
+extern "C" int dsmi_decoder_set_lm(dsmi_decoder* d, const char* path, double alpha, double beta) {
+    if (!d) return DSMI_ERR_INVALID;
+    DEC_HIP(d, hipSetDevice(d->device));
+    DEC_HIP(d, hipDeviceSynchronize());
+    free_lm(d);
+    d->alpha = alpha; d->beta = beta;
+    if (!path || !*path) return DSMI_OK;
+    const std::string msg = d->lm.load_arpa(path, d->labels);
+    if (!msg.empty()) { d->lm = HostLM(); d->err = msg; return DSMI_ERR_IO; }
+    if (d->lm.order > kMaxOrder) { d->err = "n-gram order above 6 is not supported"; d->lm = HostLM(); return DSMI_ERR_IO; }
+    DEC_HIP(d, hipMalloc((void**)&d->d_tab, sizeof(LmEntry) * d->lm.table.size()));
+    DEC_HIP(d, hipMalloc((void**)&d->d_next, sizeof(int32_t) * d->lm.trie_next.size()));
+    DEC_HIP(d, hipMalloc((void**)&d->d_word, sizeof(int32_t) * d->lm.trie_word.size()));
+    DEC_HIP(d, hipMemcpy(d->d_tab, d->lm.table.data(), sizeof(LmEntry) * d->lm.table.size(), hipMemcpyHostToDevice));
+    DEC_HIP(d, hipMemcpy(d->d_next, d->lm.trie_next.data(), sizeof(int32_t) * d->lm.trie_next.size(), hipMemcpyHostToDevice));
+    DEC_HIP(d, hipMemcpy(d->d_word, d->lm.trie_word.data(), sizeof(int32_t) * d->lm.trie_word.size(), hipMemcpyHostToDevice));
+    d->has_lm = true;
+    return DSMI_OK;
+}
+
+extern "C" int dsmi_greedy(dsmi_decoder* d, const float* probs, const int32_t* sizes, int B, int To,
+                           int32_t* ids, int32_t* offsets, int32_t* n_out, void* stream) {
+    if (!d) return DSMI_ERR_INVALID;
+    if (!probs || !ids || !offsets || !n_out || B < 1 || To < 1) { d->err = "bad greedy arguments"; return DSMI_ERR_INVALID; }
+    DEC_HIP(d, hipSetDevice(d->device));
+    hipStream_t s = (hipStream_t)stream;
+    if ((size_t)B * To > d->greedy_cap) {
+        DEC_HIP(d, hipDeviceSynchronize());
+        for (void* p : {(void*)d->g_raw, (void*)d->g_ids, (void*)d->g_offs, (void*)d->g_nout, (void*)d->g_sizes}) if (p) (void)hipFree(p);
+        d->greedy_cap = (size_t)B * To;
+        DEC_HIP(d, hipMalloc((void**)&d->g_raw, sizeof(int32_t) * d->greedy_cap));
+        DEC_HIP(d, hipMalloc((void**)&d->g_ids, sizeof(int32_t) * d->greedy_cap));
+        DEC_HIP(d, hipMalloc((void**)&d->g_offs, sizeof(int32_t) * d->greedy_cap));
+        DEC_HIP(d, hipMalloc((void**)&d->g_nout, sizeof(int32_t) * d->greedy_cap));
+        DEC_HIP(d, hipMalloc((void**)&d->g_sizes, sizeof(int32_t) * d->greedy_cap));
+    }
+    if (sizes) DEC_HIP(d, hipMemcpyAsync(d->g_sizes, sizes, sizeof(int32_t) * B, hipMemcpyHostToDevice, s));
+    launch_greedy(probs, sizes ? d->g_sizes : nullptr, B, To, (int)d->labels.size(), d->blank, d->g_raw, d->g_ids, d->g_offs, d->g_nout, s);
+    DEC_HIP(d, hipMemcpyAsync(ids, d->g_ids, sizeof(int32_t) * (size_t)B * To, hipMemcpyDeviceToHost, s));
+    DEC_HIP(d, hipMemcpyAsync(offsets, d->g_offs, sizeof(int32_t) * (size_t)B * To, hipMemcpyDeviceToHost, s));
+    DEC_HIP(d, hipMemcpyAsync(n_out, d->g_nout, sizeof(int32_t) * B, hipMemcpyDeviceToHost, s));
+    DEC_HIP(d, hipStreamSynchronize(s));
+    DEC_HIP(d, hipGetLastError());
+    return DSMI_OK;
+}
+
+extern "C" int dsmi_beam(dsmi_decoder* d, const float* probs, const int32_t* sizes, int B, int To, int beam, int cutoff_top_n,
+                         double cutoff_prob, int32_t* tokens, int32_t* tsteps, int32_t* lens, float* scores, void* stream) {
+    if (!d) return DSMI_ERR_INVALID;
+    const int C = (int)d->labels.size();
+    if (!probs || !tokens || !tsteps || !lens || !scores || B < 1 || To < 1 || beam < 1) { d->err = "bad beam arguments"; return DSMI_ERR_INVALID; }
+    const size_t NMAX = (size_t)beam * (C + 1);
+    const size_t lds = sizeof(double) * (128 + 2 + 6 * (size_t)beam + 3 * (size_t)beam + NMAX) + sizeof(uint64_t) * (NMAX + 2) +
+                       sizeof(int) * (4 * (size_t)beam + 2 * NMAX + 128) + sizeof(unsigned) * 256 + sizeof(int) * (BT + 1 + 8) + 64;
+    if (lds > 160 * 1024 - 256) { d->err = "beam_width * (n_labels + 1) exceeds the on-chip candidate buffer"; return DSMI_ERR_CAPACITY; }
+    DEC_HIP(d, hipSetDevice(d->device));
+    hipStream_t s = (hipStream_t)stream;
+    // ---- workspace carve
+    const int ncap = 2 + To * beam;
+    int hsize = 16;
+    while (hsize < 2 * ncap) hsize <<= 1;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t n_i32 = (size_t)B * ncap;
+    size_t off = 0;
+    size_t o_parent = off; off += al(n_i32 * 4);
+    size_t o_ch = off; off += al(n_i32 * 4);
+    size_t o_tstep = off; off += al(n_i32 * 4);
+    size_t o_dstate = off; off += al(n_i32 * 4);
+    size_t o_nchild = off; off += al(n_i32 * 4);
+    size_t o_flags = off; off += al(n_i32 * 4);
+    size_t o_slot = off; off += al(n_i32 * 4);
+    size_t o_ctx = off; off += al(n_i32 * 4 * MAXCTX);
+    size_t o_lpc = off; off += al(n_i32 * 8);
+    size_t o_htab = off; off += al((size_t)B * hsize * 4);
+    size_t o_nn = off; off += al((size_t)B * 4);
+    size_t o_sizes = off; off += al((size_t)B * 4);
+    size_t o_tok = off; off += al((size_t)B * beam * To * 4);
+    size_t o_step = off; off += al((size_t)B * beam * To * 4);
+    size_t o_len = off; off += al((size_t)B * beam * 4);
+    size_t o_n = off; off += al((size_t)B * 4);
+    size_t o_score = off; off += al((size_t)B * beam * 8);
+    if (off > d->ws_bytes) {
+        DEC_HIP(d, hipDeviceSynchronize());
+        if (d->ws) (void)hipFree(d->ws);
+        d->ws = nullptr; d->ws_bytes = 0;
+        DEC_HIP(d, hipMalloc((void**)&d->ws, off));
+        d->ws_bytes = off;
+    }
+    unsigned char* w = d->ws;
+    BeamArgs a{};
+    a.probs = probs; a.T = To; a.C = C; a.blank = d->blank; a.space = d->space; a.beam = beam;
+    a.cutoff_top_n = cutoff_top_n; a.cutoff_prob = (float)cutoff_prob;
+    a.has_lm = d->has_lm ? 1 : 0; a.order = d->has_lm ? d->lm.order : 1; a.alpha = d->alpha; a.beta = d->beta;
+    a.lm_tab = d->d_tab; a.lm_mask = d->lm.mask; a.trie_next = d->d_next; a.trie_word = d->d_word; a.unk = d->lm.unk; a.bos = d->lm.bos;
+    a.ncap = ncap; a.hsize = hsize;
+    a.parent = (int32_t*)(w + o_parent); a.ch = (int32_t*)(w + o_ch); a.tstep = (int32_t*)(w + o_tstep); a.dstate = (int32_t*)(w + o_dstate);
+    a.nchild = (int32_t*)(w + o_nchild); a.flags = (int32_t*)(w + o_flags); a.slot = (int32_t*)(w + o_slot); a.ctx = (int32_t*)(w + o_ctx);
+    a.lpc = (double*)(w + o_lpc); a.htab = (int32_t*)(w + o_htab); a.nnodes = (int32_t*)(w + o_nn);
+    a.out_tok = (int32_t*)(w + o_tok); a.out_step = (int32_t*)(w + o_step); a.out_len = (int32_t*)(w + o_len); a.out_n = (int32_t*)(w + o_n);
+    a.out_score = (double*)(w + o_score);
+    a.sizes = nullptr;
+    if (sizes) {
+        DEC_HIP(d, hipMemcpyAsync(w + o_sizes, sizes, sizeof(int32_t) * B, hipMemcpyHostToDevice, s));
+        a.sizes = (const int32_t*)(w + o_sizes);
+    }
+    DEC_HIP(d, hipMemsetAsync(w + o_len, 0, (size_t)B * beam * 4, s));
+    DEC_HIP(d, hipFuncSetAttribute(reinterpret_cast<const void*>(beam_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(beam_kernel, dim3(B), dim3(BT), lds, s, a);
+    std::vector<int32_t> h_len((size_t)B * beam), h_n(B);
+    std::vector<double> h_score((size_t)B * beam);
+    DEC_HIP(d, hipMemcpyAsync(tokens, w + o_tok, (size_t)B * beam * To * 4, hipMemcpyDeviceToHost, s));
+    DEC_HIP(d, hipMemcpyAsync(tsteps, w + o_step, (size_t)B * beam * To * 4, hipMemcpyDeviceToHost, s));
+    DEC_HIP(d, hipMemcpyAsync(h_len.data(), w + o_len, (size_t)B * beam * 4, hipMemcpyDeviceToHost, s));
+    DEC_HIP(d, hipMemcpyAsync(h_n.data(), w + o_n, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+    DEC_HIP(d, hipMemcpyAsync(h_score.data(), w + o_score, (size_t)B * beam * 8, hipMemcpyDeviceToHost, s));
+    DEC_HIP(d, hipStreamSynchronize(s));
+    DEC_HIP(d, hipGetLastError());
+    // ---- ctcdecode "approx_ctc": strip the word bonus and the LM weight; score = -approx
+    for (int b = 0; b < B; ++b)
+        for (int p = 0; p < beam; ++p) {
+            const size_t q = (size_t)b * beam + p;
+            if (p >= h_n[b]) { lens[q] = 0; scores[q] = 0.f; continue; }
+            lens[q] = h_len[q];
+            double approx = h_score[q];
+            if (d->has_lm) {
+                std::vector<int32_t> words;
+                std::string cur;
+                auto flush = [&]() {
+                    if (cur.empty()) return;
+                    auto it = d->lm.word2id.find(cur);
+                    words.push_back(it == d->lm.word2id.end() ? -1 : it->second);
+                    cur.clear();
+                };
+                const int32_t* tk = tokens + q * To;
+                for (int k = 0; k < h_len[q]; ++k) { if (tk[k] == d->space) flush(); else cur += d->labels[tk[k]]; }
+                flush();
+                approx -= (double)h_len[q] * d->beta;
+                approx -= d->lm.sent_ln(words) * d->alpha;
+            }
+            scores[q] = (float)-approx;
+        }
+    return DSMI_OK;
+}

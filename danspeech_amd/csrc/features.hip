@@ -10,19 +10,24 @@
 // real/imaginary parts are rounded to float32, then hypotf and log1pf.
 // Mean and unbiased std are accumulated in float64 per clip (two passes, fixed order).
 #include "common.h"
-#include "model.h"
 
 #include <cmath>
 
 using namespace dsmi;
 
-struct FeatState {
+// The handle behind dsmi_frontend* : one SpectrogramAudioParser on one GPU.
+struct dsmi_frontend {
+    dsmi_frontend_desc desc{};
+    int device = 0;
+    int n_fft = 0, hop = 0, n_freq = 0;
+    std::string err;
     double* tw = nullptr;    // [n_fft][2] cos, sin
     double* win = nullptr;   // [n_fft]
     int64_t* offs = nullptr; // device: per-clip sample offset, n_samples  [2][cap]
-    int32_t* frames = nullptr;
     int cap = 0;
 };
+
+static thread_local std::string g_fe_error;
 
 namespace {
 
@@ -118,17 +123,24 @@ __global__ __launch_bounds__(1024) void normalize_kernel(float* feat, const int6
 
 }  // namespace
 
-int features_init(dsmi_model* m) {
-    FeatState* f = new FeatState();
-    m->feat = f;
-    const int n = m->n_fft;
-    if (n < 2) return DSMI_OK;   // degenerate audio_conf: features unavailable, forward still usable
+extern "C" int dsmi_frontend_create(const dsmi_frontend_desc* d, int device, dsmi_frontend** out) {
+    if (!d || !out) { g_fe_error = "null argument"; return DSMI_ERR_INVALID; }
+    const int n = (int)(d->sample_rate * d->window_size);       // parsers.py:47
+    const int hop = (int)(d->sample_rate * d->window_stride);   // parsers.py:48
+    if (n < 2 || hop < 1 || d->window < 0 || d->window > 3) { g_fe_error = "audio_conf gives n_fft < 2 or hop < 1"; return DSMI_ERR_INVALID; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev || hipSetDevice(device) != hipSuccess) {
+        g_fe_error = "no such HIP device";
+        return DSMI_ERR_HIP;
+    }
+    dsmi_frontend* f = new dsmi_frontend();
+    f->desc = *d; f->device = device; f->n_fft = n; f->hop = hop; f->n_freq = n / 2 + 1;
     std::vector<double> tw(2 * (size_t)n), win(n);
     const double pi = 3.14159265358979323846;
     for (int j = 0; j < n; ++j) { tw[2 * j] = std::cos(2.0 * pi * j / n); tw[2 * j + 1] = std::sin(2.0 * pi * j / n); }
     for (int j = 0; j < n; ++j) {   // scipy.signal.windows.* with sym=True (parsers.py:9-10, 27: a callable window)
         const double x = n > 1 ? (double)j / (n - 1) : 0.0;
-        switch (m->desc.window) {
+        switch (d->window) {
             case DSMI_WIN_HANN: win[j] = 0.5 - 0.5 * std::cos(2 * pi * x); break;
             case DSMI_WIN_BLACKMAN: win[j] = 0.42 - 0.5 * std::cos(2 * pi * x) + 0.08 * std::cos(4 * pi * x); break;
             case DSMI_WIN_BARTLETT: win[j] = 1.0 - std::fabs(2.0 * x - 1.0); break;
@@ -139,30 +151,32 @@ int features_init(dsmi_model* m) {
         hipMalloc((void**)&f->win, sizeof(double) * win.size()) != hipSuccess ||
         hipMemcpy(f->tw, tw.data(), sizeof(double) * tw.size(), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(f->win, win.data(), sizeof(double) * win.size(), hipMemcpyHostToDevice) != hipSuccess) {
-        m->err = "features_init: HIP allocation failed";
+        g_fe_error = "frontend: HIP allocation failed";
+        delete f;
         return DSMI_ERR_HIP;
     }
+    *out = f;
     return DSMI_OK;
 }
 
-void features_destroy(dsmi_model* m) {
-    if (!m->feat) return;
-    FeatState* f = m->feat;
+extern "C" void dsmi_frontend_destroy(dsmi_frontend* f) {
+    if (!f) return;
+    (void)hipSetDevice(f->device);
+    (void)hipDeviceSynchronize();
     if (f->tw) (void)hipFree(f->tw);
     if (f->win) (void)hipFree(f->win);
     if (f->offs) (void)hipFree(f->offs);
     delete f;
-    m->feat = nullptr;
 }
 
-extern "C" int dsmi_features(dsmi_model* m, const void* pcm, int dtype, const int64_t* n_samples, int B, float* feat,
+extern "C" const char* dsmi_frontend_last_error(const dsmi_frontend* f) { return f ? f->err.c_str() : g_fe_error.c_str(); }
+
+extern "C" int dsmi_features(dsmi_frontend* m, const void* pcm, int dtype, const int64_t* n_samples, int B, float* feat,
                              int t_stride, int32_t* frames, void* stream) {
     if (!m) return DSMI_ERR_INVALID;
     auto bad = [&](int code, const char* msg) { m->err = msg; return code; };
-    if (!m->finalized) return bad(DSMI_ERR_NOT_READY, "dsmi_model_finalize has not been called");
+    dsmi_frontend* f = m;
     if (!pcm || !n_samples || !feat || B < 1 || dtype < 0 || dtype > 2) return bad(DSMI_ERR_INVALID, "bad features arguments");
-    if (m->n_fft < 2 || m->hop < 1) return bad(DSMI_ERR_INVALID, "audio_conf gives n_fft < 2");
-    FeatState* f = m->feat;
     hipStream_t s = (hipStream_t)stream;
     if (hipSetDevice(m->device) != hipSuccess) return bad(DSMI_ERR_HIP, "hipSetDevice failed");
     std::vector<int64_t> host(2 * (size_t)B);
@@ -187,10 +201,7 @@ extern "C" int dsmi_features(dsmi_model* m, const void* pcm, int dtype, const in
         hipMemcpyAsync(f->offs + f->cap, host.data() + B, sizeof(int64_t) * B, hipMemcpyHostToDevice, s) != hipSuccess)
         return bad(DSMI_ERR_HIP, "hipMemcpyAsync failed");
     const size_t lds = sizeof(double) * ((size_t)2 * m->n_fft + (size_t)m->n_fft * FT);
-    double totfr = 0;
-    for (int b = 0; b < B; ++b) totfr += 1 + n_samples[b] / m->hop;
-    EvPair ev = timer_arm(m, KK_STFT, true, 4.0 * totfr * m->n_freq * m->n_fft,
-                          (double)off * (dtype == DSMI_PCM_I16 ? 2 : (dtype == DSMI_PCM_F32 ? 4 : 8)) + 4.0 * totfr * m->n_freq);
+    EvPair ev;
     DSMI_LAUNCH(stft_logmag_kernel, dim3(ceil_div(maxfr, FT), B), dim3(256), lds, s, ev, pcm, dtype, f->offs, f->offs + f->cap,
                 f->tw, f->win, m->n_fft, m->hop, m->n_freq, m->desc.pad_mode, feat, t_stride);
     hipLaunchKernelGGL(normalize_kernel, dim3(B), dim3(1024), 0, s, feat, f->offs + f->cap, m->hop, m->n_freq, t_stride, m->desc.normalize);

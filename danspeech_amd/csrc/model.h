@@ -19,8 +19,6 @@ struct RnnW {
     int K = 0, ldw = 0;
 };
 
-struct FeatState;   // features.hip
-
 // Per-kernel dispatch timing (profiling level 2): sampled launches carry an event pair stamped
 // with the dispatch's own begin/end timestamps; pairs are resolved lazily after a sync.
 enum KernelKind { KK_STFT = 0, KK_CONV1, KK_CONV2, KK_CONV3, KK_GEMM0, KK_GEMM, KK_STEP, KK_HEAD, KK_GREEDY, KK_BEAM, KK_COUNT };
@@ -42,7 +40,7 @@ struct dsmi_model {
     std::map<std::string, HostTensor> tensors;
 
     // geometry
-    int n_fft = 0, hop = 0, n_freq = 0;
+    int n_fft = 0, n_freq = 0;
     int conv_fi[3] = {0, 0, 0}, conv_fo[3] = {0, 0, 0};
     int I0 = 0, Hs = 0;
     dsmi::RnnGeom geom{};
@@ -67,12 +65,6 @@ struct dsmi_model {
     std::vector<int32_t> host_out_lens;   // output lengths of the batch being processed
     int32_t *lens_dev = nullptr, *sizes_dev = nullptr, *raw_ids = nullptr, *ids = nullptr, *offs = nullptr, *nout = nullptr;
 
-    // greedy scratch
-    size_t greedy_cap = 0;
-    int32_t *g_raw = nullptr, *g_ids = nullptr, *g_offs = nullptr, *g_nout = nullptr, *g_sizes = nullptr;
-
-    FeatState* feat = nullptr;
-
     // profiling
     int profiling = 0;        // 0 off, 1 stage events, 2 + sampled per-kernel dispatch timestamps
     KernelTimer kt;
@@ -83,5 +75,3 @@ struct dsmi_model {
 };
 
 dsmi::EvPair timer_arm(dsmi_model* m, int kind, bool sample, double flops, double bytes);
-int features_init(dsmi_model* m);
-void features_destroy(dsmi_model* m);

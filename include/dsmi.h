@@ -63,16 +63,23 @@ typedef struct {
     int32_t bidirectional;      /* 0/1                                    */
     int32_t context;            /* Lookahead context (unidirectional)     */
     int32_t n_labels;           /* len(labels)                            */
-    int32_t sample_rate;        /* audio_conf["sampling_rate"]            */
-    double  window_size;        /* seconds (double: n_fft = int(rate * size) as Python computes it, parsers.py:47) */
-    double  window_stride;      /* seconds                                */
-    int32_t window;             /* DSMI_WIN_*                             */
-    int32_t normalize;          /* 0/1                                    */
-    int32_t pad_mode;           /* DSMI_PAD_* (librosa center padding)    */
+    int32_t sample_rate;        /* audio_conf["sampling_rate"]  (fixes n_freq, model.py:340-355) */
+    double  window_size;        /* audio_conf["window_size"], seconds     */
 } dsmi_model_desc;
 
-typedef struct dsmi_model dsmi_model;
-typedef struct dsmi_lm dsmi_lm;
+/* Mirrors AudioParser.__init__ (danspeech/audio/parsers.py:18-30, 43-48): audio_conf. */
+typedef struct {
+    int32_t sample_rate;        /* audio_conf["sampling_rate"]            */
+    double  window_size;        /* seconds; n_fft = int(rate * size), double arithmetic as in Python */
+    double  window_stride;      /* seconds; hop   = int(rate * stride)    */
+    int32_t window;             /* DSMI_WIN_*                             */
+    int32_t normalize;          /* 0/1                                    */
+    int32_t pad_mode;           /* DSMI_PAD_*: librosa's centre padding (reflect <= 0.9, constant >= 0.10) */
+} dsmi_frontend_desc;
+
+typedef struct dsmi_model dsmi_model;        /* a DeepSpeech instance on one GPU          */
+typedef struct dsmi_frontend dsmi_frontend;  /* a SpectrogramAudioParser on one GPU       */
+typedef struct dsmi_decoder dsmi_decoder;    /* a GreedyDecoder / BeamCTCDecoder on one GPU */
 
 /* ---- lifecycle: replaces DeepSpeech.__init__ / load_model (model.py:293-425, 599-624) */
 int dsmi_model_create(const dsmi_model_desc* desc, int device, dsmi_model** out);
@@ -93,12 +100,15 @@ const char* dsmi_last_error(const dsmi_model* m);
 /* ---- DeepSpeech.get_seq_lens (model.py:540-551); pure host arithmetic */
 int dsmi_seq_lens(const dsmi_model* m, const int32_t* lens_host, int n, int32_t* out_lens_host);
 
-/* ---- SpectrogramAudioParser.parse_audio (parsers.py:50-72), batched.
+/* ---- SpectrogramAudioParser (parsers.py:37-72), batched.
  * pcm_dev: B clips back to back, clip b has n_samples_host[b] samples starting at
  * sample offset sum(n_samples_host[:b]); dtype DSMI_PCM_*.
  * feat_dev: [B][n_freq][t_stride] float32, frames past a clip's own count are zero.
- * frames_host[b] = 1 + n_samples[b] / hop. */
-int dsmi_features(dsmi_model* m, const void* pcm_dev, int pcm_dtype, const int64_t* n_samples_host,
+ * frames_host[b] = 1 + n_samples[b] / hop.  Asynchronous on `stream`. */
+int dsmi_frontend_create(const dsmi_frontend_desc* desc, int device, dsmi_frontend** out);
+void dsmi_frontend_destroy(dsmi_frontend* f);
+const char* dsmi_frontend_last_error(const dsmi_frontend* f);
+int dsmi_features(dsmi_frontend* f, const void* pcm_dev, int pcm_dtype, const int64_t* n_samples_host,
                   int B, float* feat_dev, int t_stride, int32_t* frames_host, void* stream);
 
 /* ---- DeepSpeech.forward (model.py:496-515), eval mode.
@@ -118,12 +128,19 @@ int dsmi_conv_stack(dsmi_model* m, const float* feat_dev, const int32_t* lens_ho
 int dsmi_rnn_layer(dsmi_model* m, int layer, const float* x_dev, const int32_t* out_lens_host,
                    int B, int T_out, float* y_dev, void* stream);
 
+/* ---- Decoder.__init__ (decoder.py:35-43): labels as n_labels UTF-8 strings (labels may be
+ * multi-byte, e.g. the Danish letters), blank_index as DanSpeechRecognizer passes it
+ * (labels.index('_'), DanSpeechRecognizer.py:92,94). */
+int dsmi_decoder_create(int device, const char* const* labels_utf8, int n_labels, int blank_index,
+                        dsmi_decoder** out);
+void dsmi_decoder_destroy(dsmi_decoder* d);
+const char* dsmi_decoder_last_error(const dsmi_decoder* d);
+
 /* ---- GreedyDecoder.decode (decoder.py:183-198 + 151-181).
- * probs_dev [B][T_out][C]; sizes_host[B] or NULL (= T_out for all).
- * ids_host/offsets_host: [B][T_out] int32, first n_out_host[b] entries valid. */
-int dsmi_greedy(dsmi_model* m, const float* probs_dev, const int32_t* sizes_host, int B, int T_out,
-                int blank_index, int32_t* ids_host, int32_t* offsets_host, int32_t* n_out_host,
-                void* stream);
+ * probs_dev [B][T_out][n_labels]; sizes_host[B] or NULL (= T_out for all).
+ * ids_host/offsets_host: [B][T_out] int32, first n_out_host[b] entries valid.  Synchronises. */
+int dsmi_greedy(dsmi_decoder* d, const float* probs_dev, const int32_t* sizes_host, int B, int T_out,
+                int32_t* ids_host, int32_t* offsets_host, int32_t* n_out_host, void* stream);
 
 /* ---- measurement hooks (no reference counterpart; SURVEY 5 "tracing/profiling": none).
  * level 0: off.  level 1: per-stage hipEvents around the last dsmi_forward (synchronises).
@@ -147,6 +164,18 @@ double dsmi_stage_time_us(const dsmi_model* m, int stage);
  * summed algorithmic FLOPs (SURVEY 8d formula, recurrent part), for roofline maths. */
 int dsmi_last_forward_stats(const dsmi_model* m, int64_t* n_step_launches, double* step_flops,
                             double* total_flops);
+
+/* ---- BeamCTCDecoder (decoder.py:91-144): what ctcdecode.CTCBeamDecoder(labels, lm_path, alpha,
+ * beta, cutoff_top_n, cutoff_prob, beam_width, num_processes, blank_index).decode(probs, sizes)
+ * does for the reference (third-party, not in the reference tree; restated in oracle/beam.py).
+ * dsmi_decoder_set_lm: lm_path = ARPA text n-gram model (order <= 6) or NULL/"" for none.
+ * dsmi_beam outputs, all host: tokens/tsteps [B][beam][T_out] int32 (token ids and the frame
+ * of each token's strongest emission), lens [B][beam], scores [B][beam] (ctcdecode's
+ * "-approx_ctc", lower is better; beams are ordered best first).  Synchronises. */
+int dsmi_decoder_set_lm(dsmi_decoder* d, const char* lm_path, double alpha, double beta);
+int dsmi_beam(dsmi_decoder* d, const float* probs_dev, const int32_t* sizes_host, int B, int T_out,
+              int beam_width, int cutoff_top_n, double cutoff_prob, int32_t* tokens_host,
+              int32_t* tsteps_host, int32_t* lens_host, float* scores_host, void* stream);
 
 #ifdef __cplusplus
 }

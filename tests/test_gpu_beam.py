@@ -1,0 +1,104 @@
+"""GPU parity: dsmi_beam (HIP prefix beam search + n-gram scorer) against oracle/beam.py.
+Parity with ctcdecode itself is unpinned (third-party, absent); both sides restate the same
+published algorithm and carry float64, so strings/timesteps must be identical and scores agree
+to 1e-4 (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+
+from danspeech_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def native():
+    from danspeech_amd import _native
+    assert torch.cuda.is_available()
+    _native.lib()
+    return _native
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _peaky_probs(rng, B, T, C, sharp=3.0):
+    logits = rng.standard_normal((B, T, C)) * sharp
+    logits[:, :, 0] += 1.5        # blanks dominate like a trained CTC model
+    e = np.exp(logits - logits.max(-1, keepdims=True))
+    return (e / e.sum(-1, keepdims=True)).astype(np.float32)
+
+
+def _compare(native, probs, sizes, labels, beam, lm_path=None, alpha=0.0, beta=0.0, cutoff_top_n=40, cutoff_prob=1.0,
+             n_check=None):
+    from oracle import beam as ob
+    dec = native.NativeDecoder(labels, blank_index=0)
+    dec.set_lm(lm_path, alpha, beta)
+    tok, ts, ln, sc = dec.beam(_dev(probs), sizes, beam_width=beam, cutoff_top_n=cutoff_top_n, cutoff_prob=cutoff_prob)
+    strings, offsets, scores = ob.beam_decode(probs.astype(np.float64), sizes, labels, beam, lm_path=lm_path, alpha=alpha,
+                                              beta=beta, cutoff_top_n=cutoff_top_n, cutoff_prob=cutoff_prob)
+    B = probs.shape[0]
+    for b in range(B):
+        nref = len([s for s, o in zip(strings[b], offsets[b]) if True])
+        k = n_check or beam
+        for p in range(min(k, nref)):
+            if p >= len(scores[b]) or (strings[b][p] == "" and scores[b][p] == 0.0 and ln[b, p] == 0 and p > 0):
+                continue
+            got = "".join(labels[i] for i in tok[b, p, :ln[b, p]])
+            if np.isinf(scores[b][p]):
+                continue
+            assert got == strings[b][p], (b, p, got, strings[b][p])
+            assert list(ts[b, p, :ln[b, p]]) == offsets[b][p], (b, p)
+            assert abs(float(sc[b, p]) - scores[b][p]) < 1e-4 * max(1.0, abs(scores[b][p]) / 100.0), (b, p, sc[b, p], scores[b][p])
+    dec.close()
+
+
+def test_beam_no_lm_small_alphabet_exhaustive(native):
+    rng = np.random.default_rng(0)
+    probs = rng.dirichlet(np.ones(4), size=(3, 6)).astype(np.float32)
+    _compare(native, probs, None, "_ab ", beam=64)
+
+
+def test_beam_no_lm_danspeech_labels(native):
+    rng = np.random.default_rng(1)
+    labels = syn.DANSPEECH_LABELS
+    probs = _peaky_probs(rng, 4, 60, len(labels))
+    _compare(native, probs, np.array([60, 45, 33, 7], dtype=np.int32), labels, beam=16)
+
+
+def test_beam_with_lm(native, tmp_path):
+    labels = syn.DANSPEECH_LABELS
+    path = str(tmp_path / "toy3.arpa")
+    syn.make_arpa(path, order=3, n_words=200, seed=5, ngrams_per_order=600)
+    rng = np.random.default_rng(2)
+    probs = _peaky_probs(rng, 3, 80, len(labels), sharp=2.0)
+    # DanSpeechRecognizer defaults: alpha=1.3, beta=0.2, cutoff_top_n=40, cutoff_prob=1.0 (DanSpeechRecognizer.py:16-17,89-92)
+    _compare(native, probs, np.array([80, 64, 20], dtype=np.int32), labels, beam=32, lm_path=path, alpha=1.3, beta=0.2)
+
+
+def test_beam_with_lm_wide_beam_5gram(native, tmp_path):
+    labels = syn.DANSPEECH_LABELS
+    path = str(tmp_path / "toy5.arpa")
+    syn.make_arpa(path, order=5, n_words=300, seed=6, ngrams_per_order=500)
+    rng = np.random.default_rng(3)
+    probs = _peaky_probs(rng, 2, 50, len(labels), sharp=1.5)
+    _compare(native, probs, None, labels, beam=128, lm_path=path, alpha=1.2, beta=0.15, n_check=40)
+
+
+def test_beam_cutoff_top_n(native):
+    labels = syn.DANSPEECH_LABELS
+    rng = np.random.default_rng(4)
+    probs = _peaky_probs(rng, 2, 40, len(labels))
+    _compare(native, probs, None, labels, beam=20, cutoff_top_n=10)
+
+
+def test_lm_file_errors(native, tmp_path):
+    dec = native.NativeDecoder(syn.DANSPEECH_LABELS, blank_index=0)
+    with pytest.raises(native.DsmiError):
+        dec.set_lm(str(tmp_path / "missing.arpa"), 1.0, 0.1)
+    bad = tmp_path / "bad.klm"
+    bad.write_bytes(b"mmap lm http://kheafield.com/code format version 5\\n\\x00\\x01")
+    with pytest.raises(native.DsmiError):
+        dec.set_lm(str(bad), 1.0, 0.1)
+    dec.close()

@@ -79,7 +79,7 @@ def test_batch_rnn_g3(native, golden, kind, bidir):
     layer 1 (BN, I=H=16) of a 1-conv model whose audio_conf gives n_freq=2."""
     g = golden("g3_batch_rnn")
     H = 16
-    audio_conf = dict(sampling_rate=100, window_size=0.02, window_stride=0.01, window="hamming", normalize=True)
+    audio_conf = dict(sampling_rate=100, window_size=0.02)
     sd = syn.make_state_dict(1, kind, H, 2, bidirectional=bool(bidir), context=3, seed=2)
     for bn in (0, 1):
         tag = "%s_bn%d_bi%d" % (kind, bn, bidir)
@@ -137,8 +137,9 @@ def test_forward_full_cfgA_and_greedy_g4_g7(native, golden):
     err = np.abs(pn - g["probs"]).max()
     print("cfgA max |probs - reference| = %.3g" % err)
     assert err < 1e-4
-    dec = m.greedy(p, ol, blank_index=0)
     labels = syn.DANSPEECH_LABELS
+    gd = native.NativeDecoder(labels, blank_index=0)
+    dec = gd.greedy(p, ol)
     strings = ["".join(labels[i] for i in ids) for ids, _ in dec]
     assert strings == [str(s) for s in g["strings"]]
     assert np.array_equal(dec[0][1], g["off0"]) and np.array_equal(dec[1][1], g["off1"])
@@ -151,9 +152,9 @@ def test_forward_full_cfgA_and_greedy_g4_g7(native, golden):
 def test_greedy_g5(native, golden):
     g = golden("g5_greedy")
     labels = syn.DANSPEECH_LABELS
-    m = native.NativeModel(_cfg(2, "gru", 8, 1), syn.make_state_dict(2, "gru", 8, 1, seed=1))
+    m = native.NativeDecoder(labels, blank_index=labels.index("_"))
     for sizes, skey, okey in ((g["sizes"], "strings", "offsets"), (None, "strings_nosize", "offsets_nosize")):
-        dec = m.greedy(_dev(g["probs"]), sizes, blank_index=labels.index("_"))
+        dec = m.greedy(_dev(g["probs"]), sizes)
         strings = ["".join(labels[i] for i in ids) for ids, _ in dec]
         assert strings == [str(s) for s in g[skey]]
         for b, (_, off) in enumerate(dec):
@@ -164,7 +165,7 @@ def test_greedy_g5(native, golden):
 
 def test_features_vs_oracle(native):
     from oracle import features as of
-    m = native.NativeModel(_cfg(2, "gru", 8, 1), syn.make_state_dict(2, "gru", 8, 1, seed=1))
+    m = native.NativeFrontend()
     clips = [syn.make_clip(0, 160000), syn.make_clip(1, 66944), syn.make_clip(2, 4000), syn.make_clip(3, 161)]
     n = np.array([len(c) for c in clips], dtype=np.int64)
     for dtype in (np.float64, np.float32, np.int16):
@@ -194,3 +195,19 @@ def test_errors(native):
         m.forward(_dev(syn.make_features(2, 30)), [20, 30])
     assert e.value.code == native.DSMI_ERR_UNSORTED
     m.close()
+
+
+def test_features_window_and_pad_variants(native):
+    """hann / constant-padding front ends against the oracle's generic path."""
+    from oracle import features as of
+    import scipy.signal.windows as W
+    clip = syn.make_clip(5, 20000)
+    n = np.array([len(clip)], dtype=np.int64)
+    fe = native.NativeFrontend(pad_mode="constant")
+    feat, fr = fe.features(_dev(clip), n)
+    np.testing.assert_allclose(feat.cpu().numpy()[0, 0], of.spectrogram(clip, pad_mode="constant"), rtol=0, atol=2e-5)
+    fe.close()
+    fe = native.NativeFrontend(dict(normalize=False))
+    feat, fr = fe.features(_dev(clip), n)
+    np.testing.assert_allclose(feat.cpu().numpy()[0, 0], of.spectrogram(clip, normalize=False), rtol=0, atol=2e-5)
+    fe.close()

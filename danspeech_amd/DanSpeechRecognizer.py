@@ -1,0 +1,124 @@
+"""The engine of the drop-in surface (reference danspeech/DanSpeechRecognizer.py:13-231,
+non-streaming part): owns the device, the model, the audio parser and the decoder.
+
+Same constructor, ``update_model`` / ``update_decoder`` state machine, prints and warnings as
+the reference; ``transcribe`` is the reference's batch-1 path and ``transcribe_batch`` is the
+batched extension the MI355X needs to be fed properly.  Everything numeric
+runs on the GPU through libdsmi.so; there is no CPU path, so ``with_gpu=False`` is accepted
+for signature compatibility but the device is still the MI355X.
+"""
+import warnings
+
+import numpy as np
+
+from .deepspeech.decoder import GreedyDecoder, BeamCTCDecoder
+from .errors.recognizer_errors import ModelNotInitialized
+from .audio.parsers import SpectrogramAudioParser
+
+
+class NoLmInstantiatedWarning(Warning):
+    pass
+
+
+class DanSpeechRecognizer(object):
+
+    def __init__(self, model_name=None, lm_name=None, alpha=1.3, beta=0.2, with_gpu=False, beam_width=64):
+        import torch
+        self.device = torch.device("cuda")
+        print("Using device: {0}".format(self.device))
+        # state first (the reference reads self.lm / self.decoder inside update_model before
+        # they exist when a model is passed here, DanSpeechRecognizer.py:23-24 vs 43-46)
+        self.lm = None
+        self.decoder = None
+        self.alpha = alpha
+        self.beta = beta
+        self.beam_width = beam_width
+        if model_name:
+            self.update_model(model_name)
+        else:
+            self.model = None
+            self.model_name = None
+            self.labels = None
+            self.audio_config = None
+            self.audio_parser = None
+        if lm_name:
+            if not self.model:
+                raise ModelNotInitialized("Trying to initialize LM without also choosing a DanSpeech model.")
+            else:
+                self.update_decoder(lm_name)
+                self.lm = lm_name
+
+    def update_model(self, model):
+        self.audio_config = model.audio_conf
+        self.model = model.to(self.device)
+        self.model.eval()
+        index = int(str(self.model.device).split(":")[1]) if ":" in str(self.model.device) else 0
+        self.audio_parser = SpectrogramAudioParser(self.audio_config, device=index)
+        self.labels = self.model.labels
+        # When updating model, always update decoder because of labels
+        self.update_decoder(labels=self.labels)
+
+    def update_decoder(self, lm=None, alpha=None, beta=None, labels=None, beam_width=None):
+        """DanSpeechRecognizer.py:58-95, verbatim semantics: falsy arguments are ignored, the decoder
+        is rebuilt only when something changed, the first call selects greedy decoding."""
+        update = False
+        if not self.lm and not self.decoder:
+            update = True
+            self.lm = "greedy"
+        if lm and self.lm != lm:
+            update = True
+            self.lm = lm
+        if alpha and self.alpha != alpha:
+            update = True
+            self.alpha = alpha
+        if beta and self.beta != beta:
+            update = True
+            self.beta = beta
+        if labels and labels != self.labels:
+            update = True
+            self.labels = labels
+        if beam_width and beam_width != self.beam_width:
+            update = True
+            self.beam_width = beam_width
+        if update:
+            if self.lm != "greedy":
+                self.decoder = BeamCTCDecoder(labels=self.labels, lm_path=self.lm,
+                                              alpha=self.alpha, beta=self.beta,
+                                              beam_width=self.beam_width, num_processes=6, cutoff_prob=1.0,
+                                              cutoff_top_n=40, blank_index=self.labels.index('_'))
+            else:
+                self.decoder = GreedyDecoder(labels=self.labels, blank_index=self.labels.index('_'))
+
+    def transcribe(self, recording, show_all=False):
+        """DanSpeechRecognizer.py:218-231."""
+        import torch
+        recording = self.audio_parser.parse_audio(recording)
+        recording = recording.view(1, 1, recording.size(0), recording.size(1))
+        recording = recording.to(self.device)
+        input_sizes = torch.IntTensor([recording.size(3)]).int()
+        out, output_sizes = self.model(recording, input_sizes)
+        decoded_output, _ = self.decoder.decode(out, output_sizes)
+        if show_all:
+            if self.lm == 'greedy':
+                warnings.warn("You are trying to get all beams but no LM has been instantiated.",
+                              NoLmInstantiatedWarning)
+            return decoded_output[0]
+        else:
+            return decoded_output[0][0]
+
+    def transcribe_batch(self, recordings, show_all=False):
+        """Batched ``transcribe``: clips are sorted by length (pack_padded_sequence's order,
+        reference model.py:117), run as ONE batch, and results return in the caller's order."""
+        import torch
+        if len(recordings) == 0:
+            return []
+        order = np.argsort([-len(r) for r in recordings], kind="stable")
+        feats, frames = self.audio_parser.parse_batch([recordings[i] for i in order])
+        out, output_sizes = self.model(feats, torch.from_numpy(frames.astype(np.int32)))
+        decoded_output, _ = self.decoder.decode(out, output_sizes)
+        if show_all and self.lm == 'greedy':
+            warnings.warn("You are trying to get all beams but no LM has been instantiated.", NoLmInstantiatedWarning)
+        res = [None] * len(recordings)
+        for pos, i in enumerate(order):
+            res[i] = decoded_output[pos] if show_all else decoded_output[pos][0]
+        return res

@@ -1,0 +1,52 @@
+"""``SpectrogramAudioParser`` of the drop-in surface (reference danspeech/audio/parsers.py:37-72).
+
+``parse_audio(recording)`` returns the normalised log-magnitude spectrogram ``[n_freq, T]`` as a
+float32 torch tensor; the STFT runs in libdsmi.so (float64 DFT on the GPU, features.hip) and the
+tensor stays on the device (the engine's ``.to(device)`` is then a no-op).
+"""
+import numpy as np
+
+
+class AudioParser(object):
+    def __init__(self, audio_config=None):
+        self.audio_config = audio_config
+        if not self.audio_config:
+            self.audio_config = {}
+        self.normalize = self.audio_config.get("normalize", True)
+        self.sampling_rate = self.audio_config.get("sampling_rate", 16000)
+        self.window = self.audio_config.get("window", "hamming")
+        self.window_stride = self.audio_config.get("window_stride", 0.01)
+        self.window_size = self.audio_config.get("window_size", 0.02)
+
+    def parse_audio(self, recording):
+        raise NotImplementedError
+
+
+class SpectrogramAudioParser(AudioParser):
+    def __init__(self, audio_config=None, device=0, pad_mode="reflect"):
+        super(SpectrogramAudioParser, self).__init__(audio_config)
+        self.n_fft = int(self.sampling_rate * self.window_size)
+        self.hop_length = int(self.sampling_rate * self.window_stride)
+        self.device = device
+        self.pad_mode = pad_mode          # librosa <= 0.9 'reflect' (era of danspeech 1.0.4), >= 0.10 'constant'
+        self._native = None
+
+    def _frontend(self):
+        if self._native is None:
+            from .. import _native
+            conf = dict(sampling_rate=self.sampling_rate, window_size=self.window_size, window_stride=self.window_stride,
+                        window=self.window, normalize=self.normalize)
+            self._native = _native.NativeFrontend(conf, device=self.device, pad_mode=self.pad_mode)
+        return self._native
+
+    def parse_batch(self, recordings):
+        """list of 1-D arrays -> (features [B,1,F,Tmax] CUDA float32, frames int32[B]); batched extension."""
+        import torch
+        recs = [np.ascontiguousarray(r, dtype=np.float64) for r in recordings]
+        n = np.array([len(r) for r in recs], dtype=np.int64)
+        pcm = torch.from_numpy(np.concatenate(recs)).to("cuda:%d" % self.device)
+        return self._frontend().features(pcm, n)
+
+    def parse_audio(self, recording):
+        feat, frames = self.parse_batch([recording])
+        return feat[0, 0, :, :int(frames[0])]

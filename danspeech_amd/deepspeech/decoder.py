@@ -1,0 +1,122 @@
+"""Decoders of the drop-in surface (reference danspeech/deepspeech/decoder.py).
+
+``GreedyDecoder`` and ``BeamCTCDecoder`` keep the reference's constructor arguments and the
+``decode(probs, sizes=None) -> (strings[B][K], offsets[B][K])`` contract; the work is done by
+the HIP kernels behind ``dsmi_greedy`` / ``dsmi_beam`` (danspeech_amd/csrc/decoder.hip).
+"""
+import numpy as np
+
+
+def _edit_distance(a, b):
+    """Levenshtein distance (the reference imports the ``Levenshtein`` package for this)."""
+    prev = list(range(len(b) + 1))
+    for i, ca in enumerate(a, 1):
+        cur = [i]
+        for j, cb in enumerate(b, 1):
+            cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (ca != cb)))
+        prev = cur
+    return prev[-1]
+
+
+class Decoder(object):
+    """decoder.py:24-88."""
+
+    def __init__(self, labels, blank_index=0):
+        self.labels = labels
+        self.int_to_char = dict([(i, c) for (i, c) in enumerate(labels)])
+        self.blank_index = blank_index
+        space_index = len(labels)          # out-of-range marker when there is no space label
+        if ' ' in labels:
+            space_index = labels.index(' ')
+        self.space_index = space_index
+        self._native = None
+
+    def _dec(self, device_index):
+        from .. import _native
+        if self._native is None or self._native_device != device_index:
+            if self._native is not None:
+                self._native.close()
+            self._native = _native.NativeDecoder(self.labels, blank_index=self.blank_index, device=device_index)
+            self._native_device = device_index
+            self._configure(self._native)
+        return self._native
+
+    def _configure(self, native):
+        pass
+
+    @staticmethod
+    def _on_gpu(probs):
+        import torch
+        probs = torch.as_tensor(probs, dtype=torch.float32)
+        if not probs.is_cuda:
+            if not torch.cuda.is_available():
+                raise RuntimeError("decoding runs on the MI355X only (no CPU path) and no GPU is visible")
+            probs = probs.cuda()
+        return probs.contiguous()
+
+    def wer(self, s1, s2):
+        b = set(s1.split() + s2.split())
+        word2char = dict(zip(b, range(len(b))))
+        return _edit_distance([word2char[w] for w in s1.split()], [word2char[w] for w in s2.split()])
+
+    def cer(self, s1, s2):
+        return _edit_distance(s1.replace(' ', ''), s2.replace(' ', ''))
+
+    def decode(self, probs, sizes=None):
+        raise NotImplementedError
+
+
+class GreedyDecoder(Decoder):
+    """decoder.py:147-198: argmax per frame, collapse repeats, drop blanks; one path per utterance."""
+
+    def __init__(self, labels, blank_index=0):
+        super(GreedyDecoder, self).__init__(labels, blank_index)
+
+    def decode(self, probs, sizes=None):
+        import torch
+        probs = self._on_gpu(probs)
+        dec = self._dec(probs.device.index or 0)
+        sz = None if sizes is None else np.asarray(torch.as_tensor(sizes).cpu()).astype(np.int32)
+        res = dec.greedy(probs, sz)
+        strings = [["".join(self.int_to_char[int(i)] for i in ids)] for ids, _ in res]
+        offsets = [[torch.from_numpy(off.astype(np.int32))] for _, off in res]
+        return strings, offsets
+
+
+class BeamCTCDecoder(Decoder):
+    """decoder.py:91-144.  ``lm_path`` may be an ARPA text model; ``num_processes`` is accepted for
+    signature compatibility (the batch is decoded in parallel on the GPU, one workgroup per utterance)."""
+
+    def __init__(self, labels, lm_path=None, alpha=0, beta=0, cutoff_top_n=40, cutoff_prob=1.0, beam_width=100,
+                 num_processes=4, blank_index=0):
+        super(BeamCTCDecoder, self).__init__(labels, blank_index)
+        self.lm_path = lm_path
+        self.alpha = alpha
+        self.beta = beta
+        self.cutoff_top_n = cutoff_top_n
+        self.cutoff_prob = cutoff_prob
+        self.beam_width = beam_width
+        self.num_processes = num_processes
+        self.last_scores = None
+
+    def _configure(self, native):
+        native.set_lm(self.lm_path, self.alpha, self.beta)
+
+    def decode(self, probs, sizes=None):
+        import torch
+        probs = self._on_gpu(probs)
+        dec = self._dec(probs.device.index or 0)
+        sz = None if sizes is None else np.asarray(torch.as_tensor(sizes).cpu()).astype(np.int32)
+        tok, ts, ln, sc = dec.beam(probs, sz, beam_width=self.beam_width, cutoff_top_n=self.cutoff_top_n,
+                                   cutoff_prob=self.cutoff_prob)
+        self.last_scores = sc      # the reference drops ctcdecode's scores (decoder.py:140); kept for inspection
+        strings, offsets = [], []
+        for b in range(tok.shape[0]):
+            su, ou = [], []
+            for p in range(tok.shape[1]):
+                n = int(ln[b, p])
+                su.append("".join(self.int_to_char[int(i)] for i in tok[b, p, :n]) if n > 0 else "")
+                ou.append(torch.from_numpy(ts[b, p, :n].copy()) if n > 0 else torch.tensor([], dtype=torch.int))
+            strings.append(su)
+            offsets.append(ou)
+        return strings, offsets

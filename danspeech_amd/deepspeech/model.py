@@ -1,0 +1,175 @@
+"""``DeepSpeech``: the acoustic-model object of the drop-in surface.
+
+Mirrors the contract the reference's engine relies on (reference
+danspeech/deepspeech/model.py:287-666, used at danspeech/DanSpeechRecognizer.py:48-56,218-224):
+attributes ``audio_conf, labels, model_name, context`` (+ the package fields), ``.to(device)``,
+``.eval()``, and ``model(x[B,1,F,T], lengths[B]) -> (probs[B,T',C], output_lengths[B])`` with
+eval-mode softmax probabilities.  The arithmetic runs in libdsmi.so (HIP, gfx950) through
+``danspeech_amd._native.NativeModel``; this class only holds the state dict and the handle.
+There is no CPU path: ``.to('cpu')`` keeps the weights on the host and any forward call then
+fails loudly.
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+
+from ..errors.model_errors import ConvError
+from .utils import get_default_audio_config, DANSPEECH_LABELS
+
+# reference model.py:14-19 maps names to torch.nn classes; here names map to kernel kinds.
+supported_rnns = {"lstm": "lstm", "rnn": "rnn", "gru": "gru"}
+supported_rnns_inv = dict((v, k) for k, v in supported_rnns.items())
+
+
+def _rnn_kind(rnn_type):
+    """Accept 'gru'/'lstm'/'rnn' or the torch.nn.GRU/LSTM/RNN classes the reference passes."""
+    if isinstance(rnn_type, str):
+        k = rnn_type.lower()
+    else:
+        k = getattr(rnn_type, "__name__", str(rnn_type)).lower()
+    if k not in supported_rnns:
+        raise ValueError("unsupported rnn_type %r (supported: gru, lstm, rnn)" % (rnn_type,))
+    return k
+
+
+class DeepSpeech(object):
+    def __init__(self, model_name, rnn_type="gru", labels=None, rnn_hidden_size=768, rnn_layers=5, audio_conf=None,
+                 bidirectional=True, context=20, conv_layers=2, streaming_inference_model=False):
+        if not labels:                      # model.py:318-322: default DanSpeech labels
+            labels = DANSPEECH_LABELS
+        if audio_conf is None:              # model.py:325-326
+            audio_conf = get_default_audio_config()
+        self.model_name = model_name
+        self.rnn_hidden_size = rnn_hidden_size
+        self.rnn_layers = rnn_layers
+        self.rnn_type = _rnn_kind(rnn_type)
+        self.audio_conf = audio_conf or {}
+        self.labels = labels
+        self.bidirectional = bidirectional
+        self.conv_layers = conv_layers
+        self.streaming_model = streaming_inference_model
+        self.context = context
+        if conv_layers == 0:                # model.py:344-348
+            raise ConvError("0 convolutional layers configuration not supported by DanSpeech")
+        if conv_layers > 3:
+            raise ConvError("Maximum amount of convolutional layers supported by DanSpeech is 3")
+        if self.streaming_model:
+            raise NotImplementedError(
+                "streaming_inference_model=True (chunked unidirectional inference, reference model.py:427-494) is "
+                "outside the recognize() hot path this package implements")
+        self._state = None
+        self._native = None
+        self.device = "cpu"
+        self.training = False
+
+    # ---- parameters -------------------------------------------------------------------------
+    def load_state_dict(self, state_dict):
+        sd = OrderedDict()
+        for k, v in state_dict.items():
+            a = v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
+            sd[k] = a
+        self._state = sd
+        if self._native is not None:
+            self._native.close()
+            self._native = None
+        return self
+
+    def state_dict(self):
+        return self._state
+
+    def _cfg(self):
+        return dict(conv_layers=self.conv_layers, rnn_type=self.rnn_type, rnn_hidden_size=self.rnn_hidden_size,
+                    rnn_layers=self.rnn_layers, bidirectional=self.bidirectional, context=self.context)
+
+    # ---- torch.nn.Module look-alikes the engine calls ------------------------------------------
+    def to(self, device):
+        import torch
+        dev = torch.device(device)
+        if dev.type == "cuda":
+            if self._state is None:
+                raise RuntimeError("DeepSpeech has no weights: call load_state_dict()/load_model() first")
+            index = dev.index if dev.index is not None else torch.cuda.current_device()
+            if self._native is None or self._native.device != index:
+                from .. import _native
+                if self._native is not None:
+                    self._native.close()
+                self._native = _native.NativeModel(self._cfg(), self._state, device=index,
+                                                   audio_conf=self.audio_conf, n_labels=len(self.labels))
+            self.device = "cuda:%d" % index
+        else:
+            self.device = "cpu"
+        return self
+
+    def cuda(self, device=None):
+        return self.to("cuda" if device is None else "cuda:%d" % device)
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def get_seq_lens(self, input_length):
+        """model.py:540-551."""
+        import torch
+        L = torch.as_tensor(input_length).clone().long()
+        from ..synthetic import CONV_SPECS
+        for (_, _, _, kt, _, st, _, pt) in CONV_SPECS[:self.conv_layers]:
+            L = (L + 2 * pt - (kt - 1) - 1) // st + 1
+        return L.int()
+
+    def forward(self, x, lengths):
+        """model.py:496-515. x: [B,1,F,T] float tensor, lengths: [B] sorted descending."""
+        import torch
+        if self._native is None:
+            raise RuntimeError("this DeepSpeech runs only on an MI355X: call model.to('cuda') first (no CPU path)")
+        lengths = torch.as_tensor(lengths).cpu().int()
+        dev = torch.device(self.device)
+        x = torch.as_tensor(x, dtype=torch.float32).to(dev).contiguous()
+        probs, out_lens = self._native.forward(x, lengths.numpy())
+        return probs, torch.from_numpy(out_lens.copy()).int()
+
+    __call__ = forward
+
+    def freeze_layers(self, number_to_freeze=0):
+        raise NotImplementedError("training helpers live in the separate danspeech_training repository (reference README.md:19-21)")
+
+    # ---- packages (reference model.py:599-650) --------------------------------------------------
+    @classmethod
+    def load_model(cls, path):
+        import torch
+        package = torch.load(path, map_location=lambda storage, loc: storage, weights_only=False)
+        return cls.load_model_package(package)
+
+    @classmethod
+    def load_model_package(cls, package):
+        model = cls(model_name=package["model_name"],
+                    rnn_hidden_size=package["rnn_hidden_size"],
+                    rnn_layers=package["rnn_layers"],
+                    labels=package["labels"],
+                    audio_conf=package["audio_conf"],
+                    rnn_type=supported_rnns[package["rnn_type"]],
+                    bidirectional=package["bidirectional"],
+                    conv_layers=package["conv_layers"],
+                    context=package["context"],
+                    streaming_inference_model=package.get("streaming_model", False))
+        model.load_state_dict(package["state_dict"])
+        return model
+
+    def serialize(self):
+        """The ``.pth`` package layout load_model expects (model.py:607-619)."""
+        import torch
+        return {"model_name": self.model_name, "rnn_hidden_size": self.rnn_hidden_size, "rnn_layers": self.rnn_layers,
+                "labels": self.labels, "audio_conf": self.audio_conf, "rnn_type": self.rnn_type,
+                "bidirectional": self.bidirectional, "conv_layers": self.conv_layers, "context": self.context,
+                "streaming_model": self.streaming_model,
+                "state_dict": OrderedDict((k, torch.from_numpy(np.ascontiguousarray(v))) for k, v in self._state.items())}
+
+    @staticmethod
+    def get_param_size(model):
+        """model.py:652-666: number of trainable parameters (BatchNorm running stats are buffers)."""
+        params = 0
+        for k, v in model.state_dict().items():
+            if k.endswith(("running_mean", "running_var", "num_batches_tracked")):
+                continue
+            params += int(np.prod(np.asarray(v).shape)) if np.asarray(v).shape else 1
+        return params

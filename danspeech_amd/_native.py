@@ -211,7 +211,7 @@ class NativeModel:
         self._check(lib().dsmi_rnn_layer(self._h, int(layer), x.data_ptr(), _np_ptr(out_lens), B, T, y.data_ptr(), self._stream()))
         return y
 
-    KERNEL_KINDS = ["unused", "conv1", "conv2", "conv3", "gemm_l0", "gemm", "rnn_step", "head", "greedy", "beam"]
+    KERNEL_KINDS = ["unused", "conv1", "conv2", "conv3", "gemm_l0", "gemm", "rnn_step", "head", "greedy", "beam", "rnn_layer_persistent"]
 
     def set_profiling(self, level):
         self._check(lib().dsmi_set_profiling(self._h, int(level)))

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 
 using namespace dsmi;
 
@@ -94,6 +95,12 @@ extern "C" int dsmi_model_create(const dsmi_model_desc* d, int device, dsmi_mode
     m->geom = make_rnn_geom(d->rnn_type, d->rnn_hidden_size, d->bidirectional ? 2 : 1);
     m->Hs = m->geom.Kp;
     m->rnn.resize(d->rnn_layers);
+    {
+        hipDeviceProp_t prop;
+        m->n_cus = hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount : 0;
+        const char* mode = std::getenv("DSMI_RNN_MODE");      // "steps" forces one launch per time step
+        m->rnn_mode = (mode && std::string(mode) == "steps") ? 0 : 1;
+    }
     *out = m;
     return DSMI_OK;
 }
@@ -282,6 +289,9 @@ extern "C" int dsmi_reserve(dsmi_model* m, int max_B, int max_T) {
         if ((rc = ws_alloc(m, &m->hpack, n))) return rc;
         HIP_OK(m, hipMemset(m->hpack, 0, n * sizeof(float)));
     }
+    if ((rc = ws_alloc(m, &m->pcnt, (size_t)m->geom.D * ceil_div(max_B, 32) * std::max(To, 1)))) return rc;
+    if ((rc = ws_alloc(m, &m->perr, (size_t)4))) return rc;
+    HIP_OK(m, hipMemset(m->perr, 0, 4 * sizeof(unsigned)));
     m->look_buf = nullptr;
     if (!d.bidirectional && (rc = ws_alloc(m, &m->look_buf, rows * m->Hs))) return rc;
     if ((rc = ws_alloc(m, &m->xin, rows * round_up(std::max(m->I0, m->Hs), 4)))) return rc;
@@ -305,6 +315,7 @@ extern "C" void dsmi_model_destroy(dsmi_model* m) {
     if (m->finalized)
         for (int i = 0; i < 8; ++i) (void)hipEventDestroy(m->ev[i]);
     timer_resolve(m);
+    if (m->perr_host) (void)hipHostFree(m->perr_host);
     for (hipEvent_t e : m->kt.free_events) (void)hipEventDestroy(e);
     delete m;
 }
@@ -352,6 +363,17 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
     gl.ev = timer_arm(m, gl.mode == GEMM_A_CONV ? KK_GEMM0 : KK_GEMM, true, 2.0 * Dd * GH * gl.K * sumlen,
                       4.0 * ((double)gl.M * gl.K * (gl.a2 ? 2 : 1) + (double)gl.N * gl.K + (double)gl.M * gl.N));
     launch_gemm(gl, s);
+    if (m->rnn_mode == 1 && rnn_persist_eligible(m->geom, B, m->n_cus)) {
+        // whole layer in one launch; counters are single-use per step, zeroed right before
+        RnnPersistLaunch pl;
+        pl.g = m->geom;
+        for (int dd = 0; dd < 2; ++dd) { pl.whh_packed[dd] = m->rnn[l].whh[dd]; pl.bhh[dd] = m->rnn[l].bhh[dd]; pl.out[dd] = m->hbuf[dst][dd]; }
+        pl.xp = m->xp; pl.lens_dev = m->lens_dev; pl.hpack = m->hpack; pl.counters = m->pcnt; pl.err = m->perr; pl.B = B; pl.T = To;
+        (void)hipMemsetAsync(m->pcnt, 0, sizeof(unsigned) * (size_t)m->geom.D * ceil_div(B, 32) * To, s);
+        pl.ev = timer_arm(m, KK_PERSIST, true, 2.0 * Dd * GH * m->desc.rnn_hidden_size * sumlen,
+                          4.0 * Dd * (GH * m->desc.rnn_hidden_size + (double)To * B * (GH + 2.0 * m->desc.rnn_hidden_size)));
+        if (launch_rnn_persist(pl, s)) return;
+    }
     RnnStepLaunch st;
     st.g = m->geom;
     for (int dd = 0; dd < 2; ++dd) {
@@ -388,6 +410,13 @@ extern "C" int dsmi_forward(dsmi_model* m, const float* feat, const int32_t* len
     if ((rc = dsmi_reserve(m, B, T))) return rc;
     HIP_OK(m, hipSetDevice(m->device));
     hipStream_t s = (hipStream_t)stream;
+    if (m->perr_host && *m->perr_host) {      // a wait inside the previous forward's persistent kernel timed out
+        *m->perr_host = 0;
+        m->rnn_mode = 0;
+        HIP_OK(m, hipMemsetAsync(m->perr, 0, sizeof(unsigned), s));
+        return fail(m, DSMI_ERR_HIP, "the persistent recurrent kernel timed out in the previous forward (results invalid); "
+                                     "falling back to one launch per step");
+    }
     const dsmi_model_desc& d = m->desc;
     const int To = seq_len(m, T), ys = round_up(To, 4);
     for (int i = 0; i < B; ++i) out_lens[i] = seq_len(m, lens[i]);
@@ -432,6 +461,13 @@ extern "C" int dsmi_forward(dsmi_model* m, const float* feat, const int32_t* len
                          4.0 * To * B * ((d.bidirectional ? 2.0 : 1.0) * m->Hs + d.n_labels));
     }
     launch_head(h, s);
+    if (m->rnn_mode == 1) {
+        if (!m->perr_host) {
+            HIP_OK(m, hipHostMalloc((void**)&m->perr_host, sizeof(unsigned), hipHostMallocDefault));
+            *m->perr_host = 0;
+        }
+        HIP_OK(m, hipMemcpyAsync(m->perr_host, m->perr, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    }
     if (m->profiling) HIP_OK(m, hipEventRecord(m->ev[3], s));
     HIP_OK(m, hipGetLastError());
 

@@ -78,7 +78,7 @@ struct RnnGeom {
     int kind;      // DSMI_RNN_*
     int G;         // gates per unit: 3 / 4 / 1
     int H;
-    int U;         // hidden units per workgroup: floor(32 / G)
+    int U;         // hidden units per workgroup (8: its h granules are whole 16-byte groups of the packed state)
     int nwg;       // ceil(H / U) workgroups per direction
     int Kp;        // H rounded up to 8
     int nq;        // Kp / 8 k-blocks
@@ -105,6 +105,20 @@ struct RnnStepLaunch {
     unsigned long long* dbg = nullptr;   // diagnostics: per-wave timestamps [D*nwg][8 waves][8]
 };
 void launch_rnn_step(const RnnStepLaunch& p, hipStream_t s);
+
+// rnn_persist.hip: all T steps of one layer in one launch (weights resident in registers,
+// counter-based hand-off of h between workgroups).  Needs every workgroup co-resident.
+struct RnnPersistLaunch {
+    RnnGeom g;
+    const float* whh_packed[2]; const float* bhh[2]; const float* xp; float* out[2];
+    const int32_t* lens_dev; float* hpack;
+    unsigned* counters;          // [D * ceil(B/32)][T], zeroed before the launch
+    unsigned* err;               // one word, set on a wait timeout
+    int B, T;
+    EvPair ev;
+};
+bool rnn_persist_eligible(const RnnGeom& g, int B, int n_cus);
+bool launch_rnn_persist(const RnnPersistLaunch& p, hipStream_t s);
 
 // head.hip
 //   lookahead: y[t][b][h] = clip(sum_k w[h][k] * x[t+k][b][h], 0, 20)

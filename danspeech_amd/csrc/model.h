@@ -21,7 +21,7 @@ struct RnnW {
 
 // Per-kernel dispatch timing (profiling level 2): sampled launches carry an event pair stamped
 // with the dispatch's own begin/end timestamps; pairs are resolved lazily after a sync.
-enum KernelKind { KK_STFT = 0, KK_CONV1, KK_CONV2, KK_CONV3, KK_GEMM0, KK_GEMM, KK_STEP, KK_HEAD, KK_GREEDY, KK_BEAM, KK_COUNT };
+enum KernelKind { KK_STFT = 0, KK_CONV1, KK_CONV2, KK_CONV3, KK_GEMM0, KK_GEMM, KK_STEP, KK_HEAD, KK_GREEDY, KK_BEAM, KK_PERSIST, KK_COUNT };
 struct KernelTimer {
     std::vector<hipEvent_t> free_events;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[KK_COUNT];
@@ -61,6 +61,11 @@ struct dsmi_model {
     float* cst[2] = {nullptr, nullptr};
     float* look_buf = nullptr;
     float* hpack = nullptr;
+    unsigned* pcnt = nullptr;     // persistent-kernel step counters [layers][D*ceil(B/32)][T]
+    unsigned* perr = nullptr;     // persistent-kernel timeout word (device)
+    unsigned* perr_host = nullptr; // pinned mirror, refreshed at the end of every forward
+    int n_cus = 0;
+    int rnn_mode = 1;             // 1: persistent layer kernel when eligible, 0: one launch per step
     float* xin = nullptr;
     std::vector<int32_t> host_out_lens;   // output lengths of the batch being processed
     int32_t *lens_dev = nullptr, *sizes_dev = nullptr, *raw_ids = nullptr, *ids = nullptr, *offs = nullptr, *nout = nullptr;

@@ -10,7 +10,7 @@
 // pack_padded_sequence's semantics without any gather.  h_{t-1} is read back from the
 // layer's own output buffer (row t-1 / t+1), so the output doubles as the state.
 //
-// Work split: one workgroup owns U = floor(32/G) hidden units of one direction, i.e. G*U <= 32
+// Work split: one workgroup owns U = 8 hidden units of one direction, i.e. G*U <= 32
 // gate rows = one MFMA tile of rows; its 8 waves split K = H eight ways and the partial
 // tiles meet in LDS (fixed summation order -> run-to-run deterministic).  W_hh is
 // pre-packed on the host into the exact lane order of the A operand (1 KiB per wave
@@ -26,7 +26,7 @@ RnnGeom make_rnn_geom(int kind, int H, int D) {
     g.kind = kind;
     g.G = kind == DSMI_RNN_GRU ? 3 : (kind == DSMI_RNN_LSTM ? 4 : 1);
     g.H = H;
-    g.U = 32 / g.G;
+    g.U = 8;
     g.nwg = ceil_div(H, g.U);
     g.Kp = round_up(H, 8);
     g.nq = g.Kp / 8;

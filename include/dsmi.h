@@ -149,7 +149,7 @@ int dsmi_greedy(dsmi_decoder* d, const float* probs_dev, const int32_t* sizes_ho
  * stage for dsmi_stage_time_us: 0 conv, 2 input GEMMs + recurrent steps, 3 head, 4 total. */
 int dsmi_set_profiling(dsmi_model* m, int level);
 /* kind: 0 stft, 1 conv1, 2 conv2, 3 conv3, 4 layer-0 input GEMM, 5 input GEMM (layers >= 1),
- * 6 recurrent step, 7 head, 8 greedy, 9 beam.  launches = dispatches since the last reset,
+ * 6 recurrent step (per-step path), 7 head, 8 greedy, 9 beam, 10 persistent recurrent layer.  launches = dispatches since the last reset,
  * samples = how many of them were timed, avg_us = mean duration of the timed ones,
  * flops/bytes_per_launch = algorithmic work (SURVEY 8d formulas) averaged over all launches. */
 int dsmi_kernel_stats(dsmi_model* m, int kind, int64_t* launches, int64_t* samples, double* avg_us,

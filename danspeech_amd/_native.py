@@ -81,6 +81,7 @@ _PROTOS = {
     "dsmi_stage_time_us": (C.c_double, [_vp, C.c_int]),
     "dsmi_kernel_stats": (C.c_int, [_vp, C.c_int, _i64p, _i64p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "dsmi_reset_kernel_stats": (C.c_int, [_vp]),
+    "dsmi_debug_persist_stamps": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int64]),
     "dsmi_debug_step_stamps": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int64]),
     "dsmi_last_forward_stats": (C.c_int, [_vp, _i64p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }

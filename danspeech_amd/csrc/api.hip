@@ -638,3 +638,35 @@ extern "C" int dsmi_debug_step_stamps(dsmi_model* m, int layer, int B, int To, i
     (void)hipFree(dbg);
     return DSMI_OK;
 }
+
+// ---- diagnostics: accumulated per-wave phase times (100 MHz ticks) of one persistent layer launch;
+// stamps_host[D*nwg][8 waves][8]: 0 loop head, 1 wait, 2 h load + MFMA, 3 LDS + barrier, 4 cell, 5 publish.
+extern "C" int dsmi_debug_persist_stamps(dsmi_model* m, int layer, int B, int To, uint64_t* stamps_host, int64_t n_words) {
+    if (!m || !m->finalized || B > 32 || layer < 0 || layer >= m->desc.rnn_layers || !rnn_persist_eligible(m->geom, B, m->n_cus)) return DSMI_ERR_INVALID;
+    int Tin = To;
+    while (seq_len(m, Tin) < To) Tin += 1;
+    int rc;
+    if ((rc = dsmi_reserve(m, B, Tin))) return rc;
+    HIP_OK(m, hipSetDevice(m->device));
+    const int64_t need = (int64_t)m->geom.D * m->geom.nwg * 8 * 8;
+    if (n_words < need) return fail(m, DSMI_ERR_INVALID, "stamp buffer too small");
+    unsigned long long* dbg;
+    HIP_OK(m, hipMalloc((void**)&dbg, sizeof(unsigned long long) * need));
+    HIP_OK(m, hipMemset(dbg, 0, sizeof(unsigned long long) * need));
+    std::vector<int32_t> lens(B, To);
+    HIP_OK(m, hipMemcpy(m->lens_dev, lens.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice));
+    HIP_OK(m, hipMemset(m->xp, 0, sizeof(float) * (size_t)To * B * m->geom.Np));
+    RnnPersistLaunch pl;
+    pl.g = m->geom;
+    for (int dd = 0; dd < 2; ++dd) { pl.whh_packed[dd] = m->rnn[layer].whh[dd]; pl.bhh[dd] = m->rnn[layer].bhh[dd]; pl.out[dd] = m->hbuf[0][dd]; }
+    pl.xp = m->xp; pl.lens_dev = m->lens_dev; pl.hpack = m->hpack; pl.counters = m->pcnt; pl.err = m->perr; pl.B = B; pl.T = To;
+    for (int rep = 0; rep < 2; ++rep) {     // first pass warms up, second is stamped
+        HIP_OK(m, hipMemset(m->pcnt, 0, sizeof(unsigned) * (size_t)m->geom.D * To));
+        pl.dbg = rep ? dbg : nullptr;
+        launch_rnn_persist(pl, nullptr);
+        HIP_OK(m, hipDeviceSynchronize());
+    }
+    HIP_OK(m, hipMemcpy(stamps_host, dbg, sizeof(unsigned long long) * need, hipMemcpyDeviceToHost));
+    (void)hipFree(dbg);
+    return DSMI_OK;
+}

@@ -116,6 +116,7 @@ struct RnnPersistLaunch {
     unsigned* err;               // one word, set on a wait timeout
     int B, T;
     EvPair ev;
+    unsigned long long* dbg = nullptr;   // diagnostics: accumulated per-wave phase times
 };
 bool rnn_persist_eligible(const RnnGeom& g, int B, int n_cus);
 bool launch_rnn_persist(const RnnPersistLaunch& p, hipStream_t s);

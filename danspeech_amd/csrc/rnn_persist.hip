@@ -36,12 +36,25 @@ struct PersistArgs {
     const float* whh[2]; const float* bhh[2]; const float* xp; float* out[2];
     const int32_t* lens; float* hpack; unsigned* cnt; unsigned* err;
     int B, T, G, H, Hs, nq, Np, nwg;
+    unsigned long long* dbg;   // diagnostics build only: per-wave accumulated phase times [wg][wave][8]
 };
 
 __device__ __forceinline__ float psigmoid(float v) { return 1.f / (1.f + expf(-v)); }
 
-template <int KIND, int NQW>
+#define PSTAMP(k)                                                                         \
+    do {                                                                                  \
+        if (STAMP) {                                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                            \
+            const unsigned long long now_ = __builtin_amdgcn_s_memrealtime();             \
+            tacc[k] += now_ - tlast; tlast = now_;                                        \
+            __builtin_amdgcn_sched_barrier(0);                                            \
+        }                                                                                 \
+    } while (0)
+
+template <int KIND, int NQW, bool STAMP = false>
 __global__ __launch_bounds__(PNT) void rnn_persist_kernel(PersistArgs p) {
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = STAMP ? __builtin_amdgcn_s_memrealtime() : 0;
     constexpr int NG = KIND == DSMI_RNN_GRU ? 3 : (KIND == DSMI_RNN_LSTM ? 4 : 1);
     // reduce buffer + new-state staging; padded past 80 KiB so that two workgroups never share a CU
     // (dynamic LDS, requested as PERSIST_LDS bytes at launch: a static pad would be optimised away)
@@ -100,6 +113,7 @@ __global__ __launch_bounds__(PNT) void rnn_persist_kernel(PersistArgs p) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        PSTAMP(0);   // loop head + x-projection request
         if (s > 0) {
             // ---- wait until every workgroup of this chain has published h_{s-1}
             // (bounded: after a timeout here or anywhere else on the chip nobody waits any more)
@@ -113,6 +127,7 @@ __global__ __launch_bounds__(PNT) void rnn_persist_kernel(PersistArgs p) {
                 }
             }
             __syncthreads();
+            PSTAMP(1);   // waiting for the other workgroups
             // ---- B operand: h_{s-1} of all units, this wave's K-slice, sc1 loads only
             const unsigned hbase = (unsigned)(((s - 1) & 1) * hp_par * sizeof(float)) + hchain + (unsigned)lane * 16u;
             f32x4 hv[NQW];
@@ -131,12 +146,14 @@ __global__ __launch_bounds__(PNT) void rnn_persist_kernel(PersistArgs p) {
                 }
             }
         }
+        PSTAMP(2);   // h load + MFMA chain
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i = (r & 3) + 8 * (r >> 2) + 4 * hk;
             red[(v * 32 + i) * 32 + li] = acc[r];
         }
         __syncthreads();
+        PSTAMP(3);   // partial tiles to LDS + barrier (wave skew)
         // ---- K-split reduction (fixed order) + cell, one (unit, batch) pair per thread
         if (tid < PU * 32) {
             float hn = 0.f;
@@ -175,6 +192,7 @@ __global__ __launch_bounds__(PNT) void rnn_persist_kernel(PersistArgs p) {
             hstage[eu * 32 + ebl] = hn;
         }
         __syncthreads();
+        PSTAMP(4);   // reduction + cell
         // ---- publish: wave 0 writes this workgroup's 8 units x 32 batch rows as one 1-KiB sc1 store
         if (v == 0) {
             f32x4 o;
@@ -186,6 +204,11 @@ __global__ __launch_bounds__(PNT) void rnn_persist_kernel(PersistArgs p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave drains its own stores
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(&cnt[s], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        PSTAMP(5);   // publish + drain + signal
+    }
+    if (STAMP && lane == 0) {
+        unsigned long long* o = p.dbg + ((size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * PNW + v) * 8;
+        for (int k = 0; k < 6; ++k) o[k] = tacc[k];
     }
 }
 
@@ -193,6 +216,11 @@ template <int KIND>
 bool launch_kind(const PersistArgs& a, int D, int nz, hipStream_t s, const EvPair& ev) {
     const int nqw = ceil_div(a.nq, PNW);
     const dim3 grid(a.nwg, D, nz), block(PNT);
+    if (a.dbg) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rnn_persist_kernel<KIND, 13, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PERSIST_LDS);
+        hipLaunchKernelGGL((rnn_persist_kernel<KIND, 13, true>), grid, block, PERSIST_LDS, s, a);
+        return true;
+    }
 #define LAUNCH_P(N)                                                                                                  \
     do {                                                                                                             \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rnn_persist_kernel<KIND, N>),                         \
@@ -220,7 +248,7 @@ bool rnn_persist_eligible(const RnnGeom& g, int B, int n_cus) {
 bool launch_rnn_persist(const RnnPersistLaunch& p, hipStream_t s) {
     PersistArgs a;
     for (int d = 0; d < 2; ++d) { a.whh[d] = p.whh_packed[d]; a.bhh[d] = p.bhh[d]; a.out[d] = p.out[d]; }
-    a.xp = p.xp; a.lens = p.lens_dev; a.hpack = p.hpack; a.cnt = p.counters; a.err = p.err;
+    a.xp = p.xp; a.lens = p.lens_dev; a.hpack = p.hpack; a.cnt = p.counters; a.err = p.err; a.dbg = p.dbg;
     a.B = p.B; a.T = p.T; a.G = p.g.G; a.H = p.g.H; a.Hs = p.g.Kp; a.nq = p.g.nq; a.Np = p.g.Np; a.nwg = p.g.nwg;
     const int nz = ceil_div(p.B, 32);
     switch (p.g.kind) {

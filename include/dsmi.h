@@ -157,6 +157,7 @@ int dsmi_kernel_stats(dsmi_model* m, int kind, int64_t* launches, int64_t* sampl
 int dsmi_reset_kernel_stats(dsmi_model* m);
 /* Diagnostics build of the recurrent step kernel: per-wave phase timestamps (100 MHz
  * s_memrealtime ticks) of the launch for `step` of `layer`; stamps_host[D*nwg][8][8]. */
+int dsmi_debug_persist_stamps(dsmi_model* m, int layer, int B, int T_out, uint64_t* stamps_host, int64_t n_words);
 int dsmi_debug_step_stamps(dsmi_model* m, int layer, int B, int T_out, int step, uint64_t* stamps_host,
                            int64_t n_words);
 double dsmi_stage_time_us(const dsmi_model* m, int stage);

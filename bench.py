@@ -50,6 +50,9 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default: the config's 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-sampling", action="store_true")
+    ap.add_argument("--pipeline", type=int, default=1,
+                    help="batches in flight per GPU: each has its own handle set and HIP stream, so the conv/GEMM "
+                         "kernels of batch i+1 overlap the latency-bound recurrent chain of batch i")
     args = ap.parse_args()
 
     import torch
@@ -73,9 +76,12 @@ def main():
     labels = syn.DANSPEECH_LABELS
     sd = syn.make_state_dict(cfg["conv_layers"], cfg["rnn_type"], cfg["rnn_hidden_size"], cfg["rnn_layers"],
                              bidirectional=cfg["bidirectional"], seed=0, fc_gain=8.0)
-    model = _native.NativeModel(cfg, sd, device=local, n_labels=len(labels))
-    frontend = _native.NativeFrontend(device=local)
-    decoder = _native.NativeDecoder(labels, blank_index=0, device=local)
+    P = max(1, args.pipeline)
+    models = [_native.NativeModel(cfg, sd, device=local, n_labels=len(labels)) for _ in range(P)]
+    frontends = [_native.NativeFrontend(device=local) for _ in range(P)]
+    decoders = [_native.NativeDecoder(labels, blank_index=0, device=local) for _ in range(P)]
+    streams = [torch.cuda.Stream(device=local) for _ in range(P)] if P > 1 else [torch.cuda.current_stream()]
+    model = models[0]
 
     # ---- inputs: rank 0 synthesises, shards go out over RCCL (utterance-level data parallelism)
     if rank == 0:
@@ -85,16 +91,38 @@ def main():
     pcm = parallel.scatter_clips(all_clips, B, n_samples, rank, world, torch.device("cuda", local))
     n = np.full(B, n_samples, dtype=np.int64)
     frames = 1 + n // 160
-    model.reserve(B, int(frames.max()))
+    for mdl in models:
+        mdl.reserve(B, int(frames.max()))
+    inflight = []          # (context index, probs, out_lens) enqueued but not yet decoded
 
-    def step():
-        feat, fr = frontend.features(pcm.view(-1), n)
-        probs, out_lens = model.forward(feat, fr)
-        dec = decoder.greedy(probs, out_lens)
+    def finish(item):
+        k, probs, out_lens = item
+        with torch.cuda.stream(streams[k]):
+            dec = decoders[k].greedy(probs, out_lens)          # synchronises stream k only
         ids = parallel.gather_token_ids([d[0] for d in dec], rank, world, torch.device("cuda", local))
         if rank == 0:
             return ["".join(labels[i] for i in seq) for seq in ids]
         return None
+
+    step_no = [0]
+
+    def step():
+        """Enqueue one batch on the next context; retire the oldest batch once P are in flight."""
+        k = step_no[0] % P
+        step_no[0] += 1
+        with torch.cuda.stream(streams[k]):
+            feat, fr = frontends[k].features(pcm.view(-1), n)
+            probs, out_lens = models[k].forward(feat, fr)
+        inflight.append((k, probs, out_lens))
+        if len(inflight) >= P:
+            return finish(inflight.pop(0))
+        return None
+
+    def drain():
+        out = None
+        while inflight:
+            out = finish(inflight.pop(0))
+        return out
 
     def sync():
         if world > 1:
@@ -103,17 +131,31 @@ def main():
 
     for _ in range(args.warmup):
         out = step()
+    out = drain() or out
     if not args.no_kernel_sampling:
-        model.set_profiling(2)
-        model.reset_kernel_stats()
+        for mdl in models:
+            mdl.set_profiling(2)
+            mdl.reset_kernel_stats()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = step()
+        out = step() or out
+    out = drain() or out
     sync()
     dt = time.perf_counter() - t0
-    stats = model.kernel_stats() if not args.no_kernel_sampling else {}
-    model.set_profiling(0)
+    stats = {}
+    if not args.no_kernel_sampling:
+        for mdl in models:                       # merge the per-context samples
+            for k, v in mdl.kernel_stats().items():
+                a = stats.setdefault(k, dict(launches=0, samples=0, _us=0.0, _fl=0.0, _by=0.0))
+                a["launches"] += v["launches"]; a["samples"] += v["samples"]
+                a["_us"] += v["avg_us"] * v["samples"]; a["_fl"] += v["flops_per_launch"] * v["launches"]
+                a["_by"] += v["bytes_per_launch"] * v["launches"]
+            mdl.set_profiling(0)
+        for a in stats.values():
+            a["avg_us"] = a["_us"] / max(a["samples"], 1)
+            a["flops_per_launch"] = a["_fl"] / max(a["launches"], 1)
+            a["bytes_per_launch"] = a["_by"] / max(a["launches"], 1)
 
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -142,7 +184,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: 2conv + 5xBiGRU800 (DanSpeechPrimary per BASELINE), greedy CTC, "
                                    "batch=%d x %.0f s 16 kHz clips per GPU, STFT+forward+decode" % (B, c["seconds"]),
-                       "clips_per_gpu": B, "clip_seconds": c["seconds"], "parallelism": "utterance-dp%d" % world},
+                       "clips_per_gpu": B, "clip_seconds": c["seconds"], "parallelism": "utterance-dp%d" % world,
+                       "batches_in_flight": P},
             "roofline": roof,
             "sample_transcript_len": len(out[0]) if out else None,
         }
@@ -151,7 +194,8 @@ def main():
         else:
             result["cpu_baseline"] = None
         print(json.dumps(result), flush=True)
-    model.close()
+    for mdl in models:
+        mdl.close()
     if world > 1:
         dist.destroy_process_group()
     return result

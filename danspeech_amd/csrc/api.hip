@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstring>
 #include <cstdlib>
+#include <mutex>
 
 using namespace dsmi;
 
@@ -56,6 +57,18 @@ static void timer_resolve(dsmi_model* m) {
         }
         t.pending[k].clear();
     }
+}
+
+static hipEvent_t persist_gate(int device) {
+    static std::mutex mu;
+    static std::map<int, hipEvent_t> gates;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = gates.find(device);
+    if (it != gates.end()) return it->second;
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
+    gates[device] = e;
+    return e;
 }
 
 static int fail(dsmi_model* m, int code, const std::string& msg) {
@@ -372,7 +385,13 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
         (void)hipMemsetAsync(m->pcnt, 0, sizeof(unsigned) * (size_t)m->geom.D * ceil_div(B, 32) * To, s);
         pl.ev = timer_arm(m, KK_PERSIST, true, 2.0 * Dd * GH * m->desc.rnn_hidden_size * sumlen,
                           4.0 * Dd * (GH * m->desc.rnn_hidden_size + (double)To * B * (GH + 2.0 * m->desc.rnn_hidden_size)));
-        if (launch_rnn_persist(pl, s)) return;
+        // Persistent kernels need every workgroup co-resident, so two of them must never share
+        // the device (e.g. two handles on two streams): chain them through a per-device event.
+        hipEvent_t gate = persist_gate(m->device);
+        if (gate) (void)hipStreamWaitEvent(s, gate, 0);
+        const bool ok = launch_rnn_persist(pl, s);
+        if (gate) (void)hipEventRecord(gate, s);
+        if (ok) return;
     }
     RnnStepLaunch st;
     st.g = m->geom;

@@ -211,6 +211,7 @@ extern "C" int dsmi_model_finalize(dsmi_model* m) {
         if ((rc = upload(m, bih, &r.bih))) return rc;
         for (int dd = 0; dd < g.D; ++dd) {
             if ((rc = upload(m, pack_whh(g, wh[dd]->data.data()), &r.whh[dd]))) return rc;
+            if ((rc = upload(m, pack_whh3(g, wh[dd]->data.data()), &r.whh3[dd]))) return rc;
             if ((rc = upload(m, bh[dd]->data, &r.bhh[dd]))) return rc;
         }
         if (l > 0) {  // model.py:403-404: BatchNorm1d(H) in front of layers >= 1
@@ -302,6 +303,11 @@ extern "C" int dsmi_reserve(dsmi_model* m, int max_B, int max_T) {
         if ((rc = ws_alloc(m, &m->hpack, n))) return rc;
         HIP_OK(m, hipMemset(m->hpack, 0, n * sizeof(float)));
     }
+    {
+        const size_t n = (size_t)2 * m->geom.D * ceil_div(max_B, 32) * ceil_div(m->geom.nq, 2) * 3 * 64 * 8;
+        if ((rc = ws_alloc(m, &m->hpack3, n))) return rc;
+        HIP_OK(m, hipMemset(m->hpack3, 0, n * sizeof(uint16_t)));
+    }
     if ((rc = ws_alloc(m, &m->pcnt, (size_t)m->geom.D * ceil_div(max_B, 32) * std::max(To, 1)))) return rc;
     if ((rc = ws_alloc(m, &m->perr, (size_t)4))) return rc;
     HIP_OK(m, hipMemset(m->perr, 0, 4 * sizeof(unsigned)));
@@ -380,8 +386,8 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
         // whole layer in one launch; counters are single-use per step, zeroed right before
         RnnPersistLaunch pl;
         pl.g = m->geom;
-        for (int dd = 0; dd < 2; ++dd) { pl.whh_packed[dd] = m->rnn[l].whh[dd]; pl.bhh[dd] = m->rnn[l].bhh[dd]; pl.out[dd] = m->hbuf[dst][dd]; }
-        pl.xp = m->xp; pl.lens_dev = m->lens_dev; pl.hpack = m->hpack; pl.counters = m->pcnt; pl.err = m->perr; pl.B = B; pl.T = To;
+        for (int dd = 0; dd < 2; ++dd) { pl.whh3[dd] = m->rnn[l].whh3[dd]; pl.bhh[dd] = m->rnn[l].bhh[dd]; pl.out[dd] = m->hbuf[dst][dd]; }
+        pl.xp = m->xp; pl.lens_dev = m->lens_dev; pl.hpack3 = m->hpack3; pl.counters = m->pcnt; pl.err = m->perr; pl.B = B; pl.T = To;
         (void)hipMemsetAsync(m->pcnt, 0, sizeof(unsigned) * (size_t)m->geom.D * ceil_div(B, 32) * To, s);
         pl.ev = timer_arm(m, KK_PERSIST, true, 2.0 * Dd * GH * m->desc.rnn_hidden_size * sumlen,
                           4.0 * Dd * (GH * m->desc.rnn_hidden_size + (double)To * B * (GH + 2.0 * m->desc.rnn_hidden_size)));
@@ -677,8 +683,8 @@ extern "C" int dsmi_debug_persist_stamps(dsmi_model* m, int layer, int B, int To
     HIP_OK(m, hipMemset(m->xp, 0, sizeof(float) * (size_t)To * B * m->geom.Np));
     RnnPersistLaunch pl;
     pl.g = m->geom;
-    for (int dd = 0; dd < 2; ++dd) { pl.whh_packed[dd] = m->rnn[layer].whh[dd]; pl.bhh[dd] = m->rnn[layer].bhh[dd]; pl.out[dd] = m->hbuf[0][dd]; }
-    pl.xp = m->xp; pl.lens_dev = m->lens_dev; pl.hpack = m->hpack; pl.counters = m->pcnt; pl.err = m->perr; pl.B = B; pl.T = To;
+    for (int dd = 0; dd < 2; ++dd) { pl.whh3[dd] = m->rnn[layer].whh3[dd]; pl.bhh[dd] = m->rnn[layer].bhh[dd]; pl.out[dd] = m->hbuf[0][dd]; }
+    pl.xp = m->xp; pl.lens_dev = m->lens_dev; pl.hpack3 = m->hpack3; pl.counters = m->pcnt; pl.err = m->perr; pl.B = B; pl.T = To;
     for (int rep = 0; rep < 2; ++rep) {     // first pass warms up, second is stamped
         HIP_OK(m, hipMemset(m->pcnt, 0, sizeof(unsigned) * (size_t)m->geom.D * To));
         pl.dbg = rep ? dbg : nullptr;

@@ -110,8 +110,9 @@ void launch_rnn_step(const RnnStepLaunch& p, hipStream_t s);
 // counter-based hand-off of h between workgroups).  Needs every workgroup co-resident.
 struct RnnPersistLaunch {
     RnnGeom g;
-    const float* whh_packed[2]; const float* bhh[2]; const float* xp; float* out[2];
-    const int32_t* lens_dev; float* hpack;
+    const uint16_t* whh3[2];     // pack_whh3 output per direction
+    const float* bhh[2]; const float* xp; float* out[2];
+    const int32_t* lens_dev; uint16_t* hpack3;   // [2][D*ceil(B/32)][npair][3][64][8] bf16
     unsigned* counters;          // [D * ceil(B/32)][T], zeroed before the launch
     unsigned* err;               // one word, set on a wait timeout
     int B, T;
@@ -119,6 +120,7 @@ struct RnnPersistLaunch {
     unsigned long long* dbg = nullptr;   // diagnostics: accumulated per-wave phase times
 };
 bool rnn_persist_eligible(const RnnGeom& g, int B, int n_cus);
+std::vector<uint16_t> pack_whh3(const RnnGeom& g, const float* w_hh);
 bool launch_rnn_persist(const RnnPersistLaunch& p, hipStream_t s);
 
 // head.hip

@@ -13,6 +13,7 @@ struct RnnW {
     float* wih = nullptr;   // [Np][ldw] gate-permuted (see rnn_src_row), zero padded
     float* bih = nullptr;   // [Np]
     float* whh[2] = {nullptr, nullptr};  // packed MFMA operand stream per direction
+    uint16_t* whh3[2] = {nullptr, nullptr};  // three-term bf16 split of the same, persistent kernel
     float* bhh[2] = {nullptr, nullptr};  // torch layout [G*H]
     float* bn_a = nullptr;  // [Hs] BatchNorm1d in front of layers >= 1
     float* bn_b = nullptr;
@@ -61,6 +62,7 @@ struct dsmi_model {
     float* cst[2] = {nullptr, nullptr};
     float* look_buf = nullptr;
     float* hpack = nullptr;
+    uint16_t* hpack3 = nullptr;
     unsigned* pcnt = nullptr;     // persistent-kernel step counters [layers][D*ceil(B/32)][T]
     unsigned* perr = nullptr;     // persistent-kernel timeout word (device)
     unsigned* perr_host = nullptr; // pinned mirror, refreshed at the end of every forward

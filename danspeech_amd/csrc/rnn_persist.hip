@@ -1,24 +1,32 @@
 // Persistent recurrent layer: ALL time steps of both directions of one BatchRNN in ONE launch.
 //
-// Same arithmetic as rnn_step.hip (which stays as the general fallback and as the reference the
-// parity tests compare this kernel with), different machine mapping:
+// Same cell arithmetic as rnn_step.hip (which stays as the general fallback and as the plain
+// fp32-MFMA statement of the step that the parity tests also run), different machine mapping:
 //   * one workgroup per CU owns 8 hidden units of one direction for the whole sequence; every
 //     wave keeps its K-slice of W_hh in REGISTERS for all T steps, so the weights cross the
 //     fabric once per layer instead of once per step (the per-step launch re-fetches all of
 //     W_hh from Infinity Cache/HBM every step: profiles/r01_pmc_rnn_step.md);
+//   * the h . W_hh^T product runs on the bf16 MFMA (v_mfma_f32_32x32x16_bf16, 16x the fp32 MFMA
+//     rate) with BOTH operands split into three bf16 terms (x = hi + mid + lo, exact to 2^-24)
+//     and the six significant cross products accumulated in fp32: measured error vs an fp64
+//     reference 8.0e-7 at K = 800 against 1.0e-6 for the fp32 MFMA chain
+//     (tools/exp/bf16x6_test.hip), i.e. fp32-grade results at 6/16 of the fp32 MFMA time.
+//     W_hh is split once on the host; each workgroup splits the 256 state values it produces
+//     and publishes them already in B-operand lane order;
 //   * the per-step all-to-all of h goes through the packed state buffer with the counter form
 //     of the hand-off protocol of cdna_hip_programming.md Guideline 16 / MI355X_MICROARCH.md
-//     "Valid forms" row 3: producers store their h granules write-through (sc1, one wave
-//     instruction = whole 128-B lines), every storing wave drains vmcnt, workgroup barrier, ONE
+//     "Valid forms" row 3: producers store their h granules write-through (sc1, whole 128-B
+//     lines per wave instruction), every storing wave drains vmcnt, workgroup barrier, ONE
 //     lane adds to an agent-scope counter; consumers poll that counter with an sc1 load, pass a
 //     workgroup barrier, and read h with sc1 loads only.  One counter per (direction, batch
 //     tile, step), zeroed by a memset node before the launch; no flag is ever reused.
 //   * every spin is bounded: on timeout the workgroup raises an error word and stops waiting,
 //     so a lost workgroup can never hang the GPU (the host then reports DSMI_ERR_HIP).
 // Requires all workgroups co-resident: the launcher checks grid <= number of CUs (the kernel
-// reserves > 80 KiB of LDS so that at most one workgroup fits a CU) and otherwise falls back
+// requests > 80 KiB of LDS so that at most one workgroup fits a CU) and otherwise falls back
 // to the per-step path.
 #include "common.h"
+#include <cstring>
 
 namespace dsmi {
 
@@ -32,10 +40,13 @@ constexpr size_t PERSIST_LDS = 82 * 1024;   // > half of the CU's 160 KiB: at mo
 
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+
 struct PersistArgs {
-    const float* whh[2]; const float* bhh[2]; const float* xp; float* out[2];
-    const int32_t* lens; float* hpack; unsigned* cnt; unsigned* err;
-    int B, T, G, H, Hs, nq, Np, nwg;
+    const uint16_t* whh3[2];   // [wg][pair][plane 3][lane 64][8 bf16]: split W_hh in A-operand lane order
+    const float* bhh[2]; const float* xp; float* out[2];
+    const int32_t* lens; uint16_t* hpack3; unsigned* cnt; unsigned* err;
+    int B, T, G, H, Hs, npair, Np, nwg;
     unsigned long long* dbg;   // diagnostics build only: per-wave accumulated phase times [wg][wave][8]
 };
 
@@ -51,7 +62,7 @@ __device__ __forceinline__ float psigmoid(float v) { return 1.f / (1.f + expf(-v
         }                                                                                 \
     } while (0)
 
-template <int KIND, int NQW, bool STAMP = false>
+template <int KIND, int NPW, bool STAMP = false>
 __global__ __launch_bounds__(PNT) void rnn_persist_kernel(PersistArgs p) {
     unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long tlast = STAMP ? __builtin_amdgcn_s_memrealtime() : 0;
@@ -74,19 +85,22 @@ __global__ __launch_bounds__(PNT) void rnn_persist_kernel(PersistArgs p) {
     unsigned* cnt = p.cnt + (size_t)chain * p.T;
     if (tid == 0) s_dead = 0;
 
-    // ---- resident operand: this wave's K-slice of the packed W_hh (1 KiB per instruction)
-    const int q0 = (v * p.nq) / PNW, q1 = ((v + 1) * p.nq) / PNW;
-    f32x4 wv[NQW];
+    // ---- resident operand: this wave's pairs of the split W_hh (three 1-KiB planes per 16 k)
+    const int p0 = (v * p.npair) / PNW, p1 = ((v + 1) * p.npair) / PNW;
+    bf16x8 wv[NPW][3];
     {
-        const f32x4* wp = reinterpret_cast<const f32x4*>(p.whh[d]) + ((size_t)w * p.nq) * 64 + lane;
+        const u32x4* wp = reinterpret_cast<const u32x4*>(p.whh3[d]) + ((size_t)w * p.npair) * 192 + lane;
 #pragma unroll
-        for (int i = 0; i < NQW; ++i) wv[i] = wp[(size_t)min(q0 + i, q1 - 1) * 64];
+        for (int i = 0; i < NPW; ++i) {
+            const int pq = min(p0 + i, p1 - 1);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) wv[i][pl] = __builtin_bit_cast(bf16x8, wp[((size_t)pq * 3 + pl) * 64]);
+        }
     }
-    // packed state, [parity][chain][nq][64 lanes][4]; accessed ONLY through sc1 buffer ops
-    const size_t hp_par = (size_t)gridDim.y * gridDim.z * p.nq * 256;    // floats per parity
-    const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)p.hpack, 0, (int)(2 * hp_par * sizeof(float)), 0x00020000);
-    const unsigned hchain = (unsigned)((size_t)chain * p.nq * 256 * sizeof(float));
+    // packed split state, [parity][chain][pair][plane][hk][batch j][8 bf16]; accessed ONLY through sc1 buffer ops
+    const size_t hp_par = (size_t)gridDim.y * gridDim.z * p.npair * 3072;    // bytes per parity
+    const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.hpack3, 0, (int)(2 * hp_par), 0x00020000);
+    const unsigned hchain = (unsigned)((size_t)chain * p.npair * 3072);
 
     // epilogue role: threads 0..255 own (unit u = tid>>5, batch bl = tid&31)
     const int eu = tid >> 5, ebl = tid & 31;
@@ -128,21 +142,27 @@ __global__ __launch_bounds__(PNT) void rnn_persist_kernel(PersistArgs p) {
             }
             __syncthreads();
             PSTAMP(1);   // waiting for the other workgroups
-            // ---- B operand: h_{s-1} of all units, this wave's K-slice, sc1 loads only
-            const unsigned hbase = (unsigned)(((s - 1) & 1) * hp_par * sizeof(float)) + hchain + (unsigned)lane * 16u;
-            f32x4 hv[NQW];
+            // ---- B operand: split h_{s-1}, this wave's pairs, sc1 loads only (lane = hk*32 + j)
+            const unsigned hbase = (unsigned)(((s - 1) & 1) * hp_par) + hchain + (unsigned)lane * 16u;
+            bf16x8 hv[NPW][3];
 #pragma unroll
-            for (int i = 0; i < NQW; ++i) {
-                const int q = min(q0 + i, q1 - 1);
-                const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(hrs, hbase + (unsigned)q * 1024u, 0, 16);
-                hv[i] = __builtin_bit_cast(f32x4, raw);
+            for (int i = 0; i < NPW; ++i) {
+                const int pq = min(p0 + i, p1 - 1);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    hv[i][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                        hrs, hbase + (unsigned)(pq * 3 + pl) * 1024u, 0, 16));
             }
+            // x . w = sum over the six cross products that matter (mid.lo, lo.mid, lo.lo < 2^-24), small terms first
 #pragma unroll
-            for (int i = 0; i < NQW; ++i) {
-                if (q0 + i < q1) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[i][c], hv[i][c], acc, 0, 0, 0);
+            for (int i = 0; i < NPW; ++i) {
+                if (p0 + i < p1) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[i][1], hv[i][1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[i][2], hv[i][0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[i][0], hv[i][2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[i][1], hv[i][0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[i][0], hv[i][1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[i][0], hv[i][0], acc, 0, 0, 0);
                 }
             }
         }
@@ -193,13 +213,24 @@ __global__ __launch_bounds__(PNT) void rnn_persist_kernel(PersistArgs p) {
         }
         __syncthreads();
         PSTAMP(4);   // reduction + cell
-        // ---- publish: wave 0 writes this workgroup's 8 units x 32 batch rows as one 1-KiB sc1 store
-        if (v == 0) {
-            f32x4 o;
+        // ---- publish: lanes 0..31 of wave 0 split this workgroup's 8 units of batch row j into three
+        // bf16 terms and store one 16-byte granule per plane (512 contiguous bytes per instruction)
+        if (v == 0 && lane < 32) {
+            bf16x8 ph, pm, pl;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) o[c] = hstage[(4 * hk + c) * 32 + li];
-            const unsigned off = (unsigned)((s & 1) * hp_par * sizeof(float)) + hchain + (unsigned)w * 1024u + (unsigned)lane * 16u;
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), hrs, off, 0, 16);
+            for (int e = 0; e < 8; ++e) {
+                const float x = hstage[e * 32 + lane];
+                const __bf16 h1 = (__bf16)x;
+                const float r1 = x - (float)h1;
+                const __bf16 h2 = (__bf16)r1;
+                const __bf16 h3 = (__bf16)(r1 - (float)h2);
+                ph[e] = h1; pm[e] = h2; pl[e] = h3;
+            }
+            const unsigned off = (unsigned)((s & 1) * hp_par) + hchain + (unsigned)(w >> 1) * 3072u +
+                                 (unsigned)(w & 1) * 512u + (unsigned)lane * 16u;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ph), hrs, off, 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pm), hrs, off + 1024u, 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pl), hrs, off + 2048u, 0, 16);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave drains its own stores
         __syncthreads();
@@ -214,42 +245,77 @@ __global__ __launch_bounds__(PNT) void rnn_persist_kernel(PersistArgs p) {
 
 template <int KIND>
 bool launch_kind(const PersistArgs& a, int D, int nz, hipStream_t s, const EvPair& ev) {
-    const int nqw = ceil_div(a.nq, PNW);
+    const int npw = ceil_div(a.npair, PNW);
     const dim3 grid(a.nwg, D, nz), block(PNT);
-    if (a.dbg) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rnn_persist_kernel<KIND, 13, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PERSIST_LDS);
-        hipLaunchKernelGGL((rnn_persist_kernel<KIND, 13, true>), grid, block, PERSIST_LDS, s, a);
-        return true;
-    }
-#define LAUNCH_P(N)                                                                                                  \
+#define LAUNCH_P(N, ST)                                                                                              \
     do {                                                                                                             \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rnn_persist_kernel<KIND, N>),                         \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rnn_persist_kernel<KIND, N, ST>),                     \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)PERSIST_LDS);                      \
-        DSMI_LAUNCH((rnn_persist_kernel<KIND, N>), grid, block, PERSIST_LDS, s, ev, a);                               \
+        DSMI_LAUNCH((rnn_persist_kernel<KIND, N, ST>), grid, block, PERSIST_LDS, s, ev, a);                           \
     } while (0)
-    if (nqw <= 4) LAUNCH_P(4);
-    else if (nqw <= 7) LAUNCH_P(7);
-    else if (nqw <= 10) LAUNCH_P(10);
-    else if (nqw <= 13) LAUNCH_P(13);
-    else if (nqw <= 16) LAUNCH_P(16);
-    else if (nqw <= 19) LAUNCH_P(19);
+    if (a.dbg) { if (npw > 7) return false; LAUNCH_P(7, true); return true; }
+    if (npw <= 2) LAUNCH_P(2, false);
+    else if (npw <= 4) LAUNCH_P(4, false);
+    else if (npw <= 7) LAUNCH_P(7, false);
     else return false;
     return true;
 }
 
 }  // namespace
 
+// H up to 896 (7 pairs of 16 k per wave): wider layers take the per-step path for now.
 bool rnn_persist_eligible(const RnnGeom& g, int B, int n_cus) {
     if (g.U != PU || (g.H % 8) != 0) return false;
-    if (ceil_div(g.nq, PNW) > 19) return false;
+    if (ceil_div(ceil_div(g.nq, 2), PNW) > 7) return false;
     return g.nwg * g.D * ceil_div(B, 32) <= n_cus;
+}
+
+static inline uint16_t bf16_rne(float x) {
+    uint32_t u;
+    std::memcpy(&u, &x, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static inline float bf16_to_f32(uint16_t b) {
+    const uint32_t u = (uint32_t)b << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
+// w_hh [G*H][H] (torch layout) of one direction -> [wg][pair][plane][lane][8] bf16 terms; lane (i = gate row,
+// hk) element e holds k = 16*pair + 8*hk + e, the same k the producer of units 8*(2*pair+hk).. publishes.
+std::vector<uint16_t> pack_whh3(const RnnGeom& g, const float* w_hh) {
+    const int npair = ceil_div(g.nq, 2);
+    std::vector<uint16_t> out((size_t)g.nwg * npair * 3 * 64 * 8, 0);
+    const int GU = g.G * g.U;
+    for (int w = 0; w < g.nwg; ++w)
+        for (int pq = 0; pq < npair; ++pq)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int i = lane & 31, hk = lane >> 5;
+                if (i >= GU) continue;
+                const int gate = i / g.U, u = i % g.U, unit = w * g.U + u;
+                if (unit >= g.H) continue;
+                for (int e = 0; e < 8; ++e) {
+                    const int k = 16 * pq + 8 * hk + e;
+                    if (k >= g.H) continue;
+                    const float x = w_hh[(size_t)(gate * g.H + unit) * g.H + k];
+                    const uint16_t h1 = bf16_rne(x);
+                    const float r1 = x - bf16_to_f32(h1);
+                    const uint16_t h2 = bf16_rne(r1);
+                    const uint16_t h3 = bf16_rne(r1 - bf16_to_f32(h2));
+                    const size_t base = (((size_t)w * npair + pq) * 3) * 64 * 8 + (size_t)lane * 8 + e;
+                    out[base] = h1; out[base + 512] = h2; out[base + 1024] = h3;
+                }
+            }
+    return out;
 }
 
 bool launch_rnn_persist(const RnnPersistLaunch& p, hipStream_t s) {
     PersistArgs a;
-    for (int d = 0; d < 2; ++d) { a.whh[d] = p.whh_packed[d]; a.bhh[d] = p.bhh[d]; a.out[d] = p.out[d]; }
-    a.xp = p.xp; a.lens = p.lens_dev; a.hpack = p.hpack; a.cnt = p.counters; a.err = p.err; a.dbg = p.dbg;
-    a.B = p.B; a.T = p.T; a.G = p.g.G; a.H = p.g.H; a.Hs = p.g.Kp; a.nq = p.g.nq; a.Np = p.g.Np; a.nwg = p.g.nwg;
+    for (int d = 0; d < 2; ++d) { a.whh3[d] = p.whh3[d]; a.bhh[d] = p.bhh[d]; a.out[d] = p.out[d]; }
+    a.xp = p.xp; a.lens = p.lens_dev; a.hpack3 = p.hpack3; a.cnt = p.counters; a.err = p.err; a.dbg = p.dbg;
+    a.B = p.B; a.T = p.T; a.G = p.g.G; a.H = p.g.H; a.Hs = p.g.Kp; a.npair = ceil_div(p.g.nq, 2); a.Np = p.g.Np; a.nwg = p.g.nwg;
     const int nz = ceil_div(p.B, 32);
     switch (p.g.kind) {
         case DSMI_RNN_GRU: return launch_kind<DSMI_RNN_GRU>(a, p.g.D, nz, s, p.ev);

@@ -1,0 +1,67 @@
+// Experiment: fp32-equivalent product through 6 bf16 MFMAs (hi/mid/lo split) vs the f32 MFMA.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cmath>
+#include <vector>
+#include <random>
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+
+__device__ inline void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
+    h = (__bf16)x; float r = x - (float)h; m = (__bf16)r; r = r - (float)m; l = (__bf16)r;
+}
+
+// C[32][32] = A[32][K] * B[32][K]^T ; one wave
+__global__ void k(const float* A, const float* B, float* C6, float* C3, float* C32, int K) {
+    const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+    f32x16 a6, a3, a32;
+    for (int i = 0; i < 16; ++i) { a6[i] = 0; a3[i] = 0; a32[i] = 0; }
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        bf16x8 ah, am, al, bh, bm, bl;
+        for (int j = 0; j < 8; ++j) {
+            __bf16 x, y, z;
+            split3(A[r * K + k0 + 8 * h + j], x, y, z); ah[j] = x; am[j] = y; al[j] = z;
+            split3(B[r * K + k0 + 8 * h + j], x, y, z); bh[j] = x; bm[j] = y; bl[j] = z;
+        }
+        // small terms first
+        a6 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, a6, 0, 0, 0);
+        a6 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, a6, 0, 0, 0);
+        a6 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, a6, 0, 0, 0);
+        a6 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, a6, 0, 0, 0);
+        a6 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, a6, 0, 0, 0);
+        a6 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, a6, 0, 0, 0);
+        a3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, a3, 0, 0, 0);
+        a3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, a3, 0, 0, 0);
+        a3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, a3, 0, 0, 0);
+        for (int j = 0; j < 8; ++j)
+            a32 = __builtin_amdgcn_mfma_f32_32x32x2f32(A[r * K + k0 + 2 * j + h], B[r * K + k0 + 2 * j + h], a32, 0, 0, 0);
+    }
+    for (int i = 0; i < 16; ++i) {
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+        C6[row * 32 + r] = a6[i]; C3[row * 32 + r] = a3[i]; C32[row * 32 + r] = a32[i];
+    }
+}
+
+int main() {
+    const int K = 800;
+    std::mt19937 g(1);
+    std::uniform_real_distribution<float> uw(-0.035f, 0.035f), uh(-1.f, 1.f);
+    std::vector<float> A(32 * K), B(32 * K);
+    for (auto& v : A) v = uw(g);
+    for (auto& v : B) v = uh(g);
+    float *dA, *dB, *d6, *d3, *d32;
+    hipMalloc(&dA, A.size() * 4); hipMalloc(&dB, B.size() * 4); hipMalloc(&d6, 4096); hipMalloc(&d3, 4096); hipMalloc(&d32, 4096);
+    hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dB, B.data(), B.size() * 4, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, dA, dB, d6, d3, d32, K);
+    std::vector<float> c6(1024), c3(1024), c32(1024);
+    hipMemcpy(c6.data(), d6, 4096, hipMemcpyDeviceToHost); hipMemcpy(c3.data(), d3, 4096, hipMemcpyDeviceToHost); hipMemcpy(c32.data(), d32, 4096, hipMemcpyDeviceToHost);
+    double e6 = 0, e3 = 0, e32 = 0, mag = 0;
+    for (int i = 0; i < 32; ++i) for (int j = 0; j < 32; ++j) {
+        double ref = 0; for (int kk = 0; kk < K; ++kk) ref += (double)A[i * K + kk] * (double)B[j * K + kk];
+        e6 = fmax(e6, fabs(c6[i * 32 + j] - ref)); e3 = fmax(e3, fabs(c3[i * 32 + j] - ref)); e32 = fmax(e32, fabs(c32[i * 32 + j] - ref));
+        mag = fmax(mag, fabs(ref));
+    }
+    printf("max|ref|=%.4f  err bf16x6=%.3e  bf16x3=%.3e  f32mfma=%.3e\n", mag, e6, e3, e32);
+    return 0;
+}

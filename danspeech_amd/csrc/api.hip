@@ -113,6 +113,8 @@ extern "C" int dsmi_model_create(const dsmi_model_desc* d, int device, dsmi_mode
         m->n_cus = hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount : 0;
         const char* mode = std::getenv("DSMI_RNN_MODE");      // "steps" forces one launch per time step
         m->rnn_mode = (mode && std::string(mode) == "steps") ? 0 : 1;
+        const char* gm = std::getenv("DSMI_GEMM_MODE");       // "f32" forces the fp32-MFMA GEMM
+        m->gemm_mode = (gm && std::string(gm) == "f32") ? 0 : 1;
     }
     *out = m;
     return DSMI_OK;
@@ -208,6 +210,7 @@ extern "C" int dsmi_model_finalize(dsmi_model* m) {
         }
         int rc;
         if ((rc = upload(m, wih, &r.wih))) return rc;
+        if ((rc = upload(m, pack_gemm_w3(wih.data(), g.Np, r.K, r.ldw), &r.wih3))) return rc;
         if ((rc = upload(m, bih, &r.bih))) return rc;
         for (int dd = 0; dd < g.D; ++dd) {
             if ((rc = upload(m, pack_whh(g, wh[dd]->data.data()), &r.whh[dd]))) return rc;
@@ -307,6 +310,11 @@ extern "C" int dsmi_reserve(dsmi_model* m, int max_B, int max_T) {
         const size_t n = (size_t)2 * m->geom.D * ceil_div(max_B, 32) * ceil_div(m->geom.nq, 2) * 3 * 64 * 8;
         if ((rc = ws_alloc(m, &m->hpack3, n))) return rc;
         HIP_OK(m, hipMemset(m->hpack3, 0, n * sizeof(uint16_t)));
+    }
+    {
+        const size_t mt = (size_t)max_B * ceil_div(std::max(To, 1), 128) + ceil_div((int)rows, 128) + 1;
+        const size_t kt = (size_t)ceil_div(std::max(m->I0, m->Hs), 32);
+        if ((rc = ws_alloc(m, &m->a3, mt * kt * 3 * 4096))) return rc;
     }
     if ((rc = ws_alloc(m, &m->pcnt, (size_t)m->geom.D * ceil_div(max_B, 32) * std::max(To, 1)))) return rc;
     if ((rc = ws_alloc(m, &m->perr, (size_t)4))) return rc;
@@ -421,6 +429,8 @@ static GemmLaunch xproj_gemm(dsmi_model* m, int l, int B, int To) {
     GemmLaunch gl{};
     const RnnW& r = m->rnn[l];
     gl.w = r.wih; gl.bias = r.bih; gl.c = m->xp;
+    gl.w3 = m->gemm_mode == 1 ? r.wih3 : nullptr;
+    gl.a3 = m->a3;
     gl.M = To * B; gl.N = m->geom.Np; gl.K = r.K; gl.ldw = r.ldw; gl.ldc = m->geom.Np;
     gl.B = B; gl.T = To;
     return gl;

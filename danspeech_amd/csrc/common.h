@@ -66,12 +66,15 @@ struct GemmLaunch {
     int mode;
     const float* a; const float* a2; const float* alpha; const float* beta;
     const float* w; const float* bias; float* c;
+    const uint16_t* w3 = nullptr;   // pack_gemm_w3 image of w: when set (with a3), the bf16x6 split-operand path runs
+    uint16_t* a3 = nullptr;         // workspace for the split A operand: [m-tiles][k-tiles][3][128][32] bf16
     int M, N, K;       // N, K as stored (W is [N][K] row-major, K % 4 == 0 guaranteed by packing)
     int lda, ldw, ldc;
     int B, T, ys;      // GEMM_A_CONV: batch, frames per clip, time stride
     EvPair ev;
 };
 void launch_gemm(const GemmLaunch& p, hipStream_t s);
+std::vector<uint16_t> pack_gemm_w3(const float* w, int N, int K, int ldw);
 
 // rnn_step.hip: one time step of both directions of one recurrent layer.
 struct RnnGeom {

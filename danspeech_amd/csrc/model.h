@@ -11,6 +11,7 @@ struct ConvW { float *wp = nullptr, *bias = nullptr, *bn_a = nullptr, *bn_b = nu
 
 struct RnnW {
     float* wih = nullptr;   // [Np][ldw] gate-permuted (see rnn_src_row), zero padded
+    uint16_t* wih3 = nullptr;  // the same as tiled three-term bf16 split (pack_gemm_w3)
     float* bih = nullptr;   // [Np]
     float* whh[2] = {nullptr, nullptr};  // packed MFMA operand stream per direction
     uint16_t* whh3[2] = {nullptr, nullptr};  // three-term bf16 split of the same, persistent kernel
@@ -63,10 +64,12 @@ struct dsmi_model {
     float* look_buf = nullptr;
     float* hpack = nullptr;
     uint16_t* hpack3 = nullptr;
+    uint16_t* a3 = nullptr;       // split A operand of the x-projection GEMM
     unsigned* pcnt = nullptr;     // persistent-kernel step counters [layers][D*ceil(B/32)][T]
     unsigned* perr = nullptr;     // persistent-kernel timeout word (device)
     unsigned* perr_host = nullptr; // pinned mirror, refreshed at the end of every forward
     int n_cus = 0;
+    int gemm_mode = 1;            // 1: bf16x6 split-operand GEMM, 0: fp32 MFMA GEMM
     int rnn_mode = 1;             // 1: persistent layer kernel when eligible, 0: one launch per step
     float* xin = nullptr;
     std::vector<int32_t> host_out_lens;   // output lengths of the batch being processed

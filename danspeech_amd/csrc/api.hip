@@ -115,6 +115,8 @@ extern "C" int dsmi_model_create(const dsmi_model_desc* d, int device, dsmi_mode
         m->rnn_mode = (mode && std::string(mode) == "steps") ? 0 : 1;
         const char* gm = std::getenv("DSMI_GEMM_MODE");       // "f32" forces the fp32-MFMA GEMM
         m->gemm_mode = (gm && std::string(gm) == "f32") ? 0 : 1;
+        const char* cm = std::getenv("DSMI_CONV_MODE");       // "f32" forces the fp32-MFMA conv for all layers
+        m->conv_mode = (cm && std::string(cm) == "f32") ? 0 : 1;
     }
     *out = m;
     return DSMI_OK;
@@ -180,6 +182,7 @@ extern "C" int dsmi_model_finalize(dsmi_model* m) {
         if (!w || !b || !bn_affine(m, "conv.seq_module." + std::to_string(3 * l + 1), s.co, s.co, a, bb)) return DSMI_ERR_NOT_READY;
         int rc;
         if ((rc = upload(m, pack_conv_weights(w->data.data(), l), &m->conv[l].wp))) return rc;
+        if (l > 0 && (rc = upload(m, pack_conv_w3(w->data.data(), s.co), &m->conv[l].wp3))) return rc;
         if ((rc = upload(m, b->data, &m->conv[l].bias))) return rc;
         if ((rc = upload(m, a, &m->conv[l].bn_a))) return rc;
         if ((rc = upload(m, bb, &m->conv[l].bn_b))) return rc;
@@ -289,6 +292,10 @@ extern "C" int dsmi_reserve(dsmi_model* m, int max_B, int max_T) {
     int rc;
     if ((rc = ws_alloc(m, &m->conv_buf[0], conv_max))) return rc;
     if ((rc = ws_alloc(m, &m->conv_buf[1], d.conv_layers > 1 ? conv_max : 1))) return rc;
+    for (int i = 0; i < 2; ++i) {   // split intermediates: layer 0 -> buf3[0], layer 1 -> buf3[1] (3-conv models)
+        const size_t n = i < d.conv_layers - 1 ? (size_t)max_B * m->conv_fo[i] * 3 * std::max(To, 1) * 32 : 1;
+        if ((rc = ws_alloc(m, &m->conv_buf3[i], n))) return rc;
+    }
     const size_t rows = (size_t)To * max_B;
     if ((rc = ws_alloc(m, &m->xp, rows * m->geom.Np))) return rc;
     for (int i = 0; i < 2; ++i)
@@ -361,22 +368,35 @@ static int check_batch(dsmi_model* m, const int32_t* lens, int B, int T) {
 
 static int run_conv(dsmi_model* m, const float* feat, int B, int T, int To, int ys, hipStream_t s, const float** out) {
     const float* x = feat;
+    const uint16_t* x3 = nullptr;
     int ti = T, xs = T;
-    for (int l = 0; l < m->desc.conv_layers; ++l) {
+    const int L = m->desc.conv_layers;
+    for (int l = 0; l < L; ++l) {
         const ConvSpec& sp = kConvSpecs[l];
-        ConvLaunch c;
-        c.x = x; c.y = m->conv_buf[l & 1]; c.wp = m->conv[l].wp; c.bias = m->conv[l].bias;
-        c.bn_a = m->conv[l].bn_a; c.bn_b = m->conv[l].bn_b; c.out_lens_dev = m->lens_dev;
-        c.B = B; c.ci = sp.ci; c.co = sp.co; c.fi = m->conv_fi[l]; c.fo = m->conv_fo[l];
-        c.ti = ti; c.to = To; c.xs = xs; c.ys = ys; c.layer = l;
-        {
-            double fl = 0, by = 0;
-            for (int i = 0; i < B; ++i) fl += 2.0 * sp.co * m->conv_fo[l] * (double)m->host_out_lens[i] * sp.ci * sp.kf * sp.kt;
-            by = 4.0 * B * ((double)sp.ci * m->conv_fi[l] * ti + (double)sp.co * m->conv_fo[l] * To);
+        double fl = 0;
+        for (int i = 0; i < B; ++i) fl += 2.0 * sp.co * m->conv_fo[l] * (double)m->host_out_lens[i] * sp.ci * sp.kf * sp.kt;
+        const double by = 4.0 * B * ((double)sp.ci * m->conv_fi[l] * ti + (double)sp.co * m->conv_fo[l] * To);
+        const bool next_bf16 = m->conv_mode == 1 && l + 1 < L;       // the consumer is a bf16x6 conv layer
+        if (x3) {
+            ConvBf16Launch c;
+            c.x3 = x3; c.wp3 = m->conv[l].wp3; c.bias = m->conv[l].bias; c.bn_a = m->conv[l].bn_a; c.bn_b = m->conv[l].bn_b;
+            c.out_lens_dev = m->lens_dev; c.y = next_bf16 ? nullptr : m->conv_buf[l & 1]; c.y3 = next_bf16 ? m->conv_buf3[l] : nullptr;
+            c.B = B; c.co = sp.co; c.fi = m->conv_fi[l]; c.fo = m->conv_fo[l]; c.ti = ti; c.to = To; c.ys = ys;
             c.ev = timer_arm(m, KK_CONV1 + l, true, fl, by);
+            launch_conv_bf16(c, s);
+            x = c.y; x3 = c.y3;
+        } else {
+            ConvLaunch c;
+            c.x = x; c.y = m->conv_buf[l & 1]; c.wp = m->conv[l].wp; c.bias = m->conv[l].bias;
+            c.bn_a = m->conv[l].bn_a; c.bn_b = m->conv[l].bn_b; c.out_lens_dev = m->lens_dev;
+            c.B = B; c.ci = sp.ci; c.co = sp.co; c.fi = m->conv_fi[l]; c.fo = m->conv_fo[l];
+            c.ti = ti; c.to = To; c.xs = xs; c.ys = ys; c.layer = l;
+            c.y3 = next_bf16 ? m->conv_buf3[l] : nullptr;
+            c.ev = timer_arm(m, KK_CONV1 + l, true, fl, by);
+            launch_conv(c, s);
+            x = c.y; x3 = c.y3;
         }
-        launch_conv(c, s);
-        x = c.y; ti = To; xs = ys;
+        ti = To; xs = ys;
     }
     *out = x;
     return DSMI_OK;

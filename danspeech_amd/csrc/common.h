@@ -50,9 +50,23 @@ struct ConvLaunch {
     const float* x; float* y; const float* wp; const float* bias; const float* bn_a; const float* bn_b;
     const int32_t* out_lens_dev;
     int B, ci, co, fi, fo, ti, to, xs, ys, layer;  // layer index selects the compile-time geometry
+    uint16_t* y3 = nullptr;   // optional: split channels-last output [B][fo][3][to][32] bf16 (32-channel layers)
     EvPair ev;
 };
 void launch_conv(const ConvLaunch& p, hipStream_t s);
+
+// conv_bf16.hip: the 32-input-channel conv layers on the bf16 MFMA with three-term split operands.
+struct ConvBf16Launch {
+    const uint16_t* x3;       // [B][fi][3][ti][32] bf16 (previous layer's split output)
+    const uint16_t* wp3;      // pack_conv_w3
+    const float* bias; const float* bn_a; const float* bn_b; const int32_t* out_lens_dev;
+    float* y;                 // [B][co][fo][ys] fp32 (last conv layer) ...
+    uint16_t* y3;             // ... or split channels-last for another bf16 conv layer (co == 32)
+    int B, co, fi, fo, ti, to, ys;
+    EvPair ev;
+};
+void launch_conv_bf16(const ConvBf16Launch& p, hipStream_t s);
+std::vector<uint16_t> pack_conv_w3(const float* w, int co_total);
 // Host-side weight packer: w [co][ci][kf][kt] -> kernel layout. Returns packed floats.
 std::vector<float> pack_conv_weights(const float* w, int layer);
 

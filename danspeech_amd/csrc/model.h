@@ -7,7 +7,7 @@ struct HostTensor {
     std::vector<float> data;
 };
 
-struct ConvW { float *wp = nullptr, *bias = nullptr, *bn_a = nullptr, *bn_b = nullptr; };
+struct ConvW { float *wp = nullptr, *bias = nullptr, *bn_a = nullptr, *bn_b = nullptr; uint16_t* wp3 = nullptr; };
 
 struct RnnW {
     float* wih = nullptr;   // [Np][ldw] gate-permuted (see rnn_src_row), zero padded
@@ -58,6 +58,7 @@ struct dsmi_model {
     int cap_B = 0, cap_T = 0;
     std::vector<void*> ws;
     float* conv_buf[2] = {nullptr, nullptr};
+    uint16_t* conv_buf3[2] = {nullptr, nullptr};   // split channels-last intermediates between conv layers
     float* xp = nullptr;
     float* hbuf[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     float* cst[2] = {nullptr, nullptr};
@@ -69,6 +70,7 @@ struct dsmi_model {
     unsigned* perr = nullptr;     // persistent-kernel timeout word (device)
     unsigned* perr_host = nullptr; // pinned mirror, refreshed at the end of every forward
     int n_cus = 0;
+    int conv_mode = 1;            // 1: bf16x6 conv for the 32-input-channel layers, 0: fp32 MFMA conv
     int gemm_mode = 1;            // 1: bf16x6 split-operand GEMM, 0: fp32 MFMA GEMM
     int rnn_mode = 1;             // 1: persistent layer kernel when eligible, 0: one launch per step
     float* xin = nullptr;

@@ -211,3 +211,39 @@ def test_features_window_and_pad_variants(native):
     feat, fr = fe.features(_dev(clip), n)
     np.testing.assert_allclose(feat.cpu().numpy()[0, 0], of.spectrogram(clip, normalize=False), rtol=0, atol=2e-5)
     fe.close()
+
+
+def test_wide_layer_takes_per_step_path_vs_oracle(native):
+    """H = 904 > 896: the persistent kernel is not eligible, the per-step fp32-MFMA path runs."""
+    from oracle import model as om
+    H = 904
+    sd = syn.make_state_dict(2, "gru", H, 1, seed=33, fc_gain=4.0)
+    cfg = _cfg(2, "gru", H, 1)
+    m = native.NativeModel(cfg, sd)
+    lens = np.array([60, 41], dtype=np.int32)
+    x = syn.make_features(2, 60, seed=34)
+    x[1, :, :, 41:] = 0
+    p, ol = m.forward(_dev(x), lens)
+    ref, ol_ref = om.forward(sd, cfg, x, lens)
+    assert np.array_equal(ol, ol_ref)
+    np.testing.assert_allclose(p.cpu().numpy(), ref, rtol=0, atol=1e-4)
+    m.close()
+
+
+def test_step_path_and_persistent_path_agree(native, monkeypatch):
+    """DSMI_RNN_MODE=steps (fp32 MFMA, one launch per step) vs the default persistent bf16x6 kernel."""
+    sd = syn.make_state_dict(2, "lstm", 64, 2, seed=35, fc_gain=4.0)
+    cfg = _cfg(2, "lstm", 64, 2)
+    lens = np.array([90, 77, 30], dtype=np.int32)
+    x = syn.make_features(3, 90, seed=36)
+    for b, L in enumerate(lens):
+        x[b, :, :, L:] = 0
+    m1 = native.NativeModel(cfg, sd)
+    p1, _ = m1.forward(_dev(x), lens)
+    monkeypatch.setenv("DSMI_RNN_MODE", "steps")
+    monkeypatch.setenv("DSMI_GEMM_MODE", "f32")
+    monkeypatch.setenv("DSMI_CONV_MODE", "f32")
+    m2 = native.NativeModel(cfg, sd)
+    p2, _ = m2.forward(_dev(x), lens)
+    np.testing.assert_allclose(p1.cpu().numpy(), p2.cpu().numpy(), rtol=0, atol=2e-5)
+    m1.close(); m2.close()

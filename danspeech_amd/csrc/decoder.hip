@@ -29,18 +29,29 @@ using namespace dsmi;
 
 namespace {
 
-constexpr int BT = 256;           // threads per utterance
+constexpr int BT = 1024;          // threads per utterance: the frame loop is latency-bound, so 16 waves hide it
+constexpr int NWAVE = BT / 64;
 constexpr int MAXCTX = kMaxOrder - 1;
 constexpr int F_EXISTS = 1, F_DELETED = 2;
+constexpr int MEMO_UNSET = 0x7fc00001;   // a NaN pattern no float computation produces
+
+// One prefix-trie node (64 bytes: one L2 line).  Children are found through a direct table
+// childtab[node][label] (-1: none), so a pair needs two dependent loads: the child id, then its record.
+struct __attribute__((aligned(64))) Node {
+    int parent, ch, tstep, dstate;
+    int nchild, flags, slot, memo;       // memo: bits of log10 P_lm(word ending here | ctx), or MEMO_UNSET
+    double lpc;
+    int ctx[MAXCTX];
+    int pad;
+};
+static_assert(sizeof(Node) == 64, "Node must be one 64-byte line");
 
 struct BeamArgs {
     const float* probs; const int32_t* sizes; int T, C, blank, space, beam, cutoff_top_n; float cutoff_prob;
     int has_lm, order; double alpha, beta;
     const LmEntry* lm_tab; uint64_t lm_mask; const int32_t* trie_next; const int32_t* trie_word; int unk, bos;
-    // per-utterance node pool (capacity ncap) and hash table (hsize, power of two)
-    int ncap, hsize;
-    int32_t *parent, *ch, *tstep, *dstate, *nchild, *flags, *slot, *ctx, *htab, *nnodes;
-    double* lpc;
+    int ncap;                    // per-utterance node pool capacity
+    Node* nodes; int32_t* childtab; int32_t* nnodes;
     // outputs
     int32_t *out_tok, *out_step, *out_len, *out_n; double* out_score;
 };
@@ -56,16 +67,19 @@ __device__ __forceinline__ uint64_t okey(double v) {   // order-preserving bits,
     uint64_t u = (uint64_t)__double_as_longlong(v);
     return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
 }
+__device__ __forceinline__ double unokey(uint64_t k) {
+    const uint64_t u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)u);
+}
 
-__device__ __forceinline__ uint32_t hmix(int parent, int c) {
-    uint32_t h = (uint32_t)parent * 0x9E3779B1u + (uint32_t)c * 0x85EBCA77u;
-    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
-    return h;
+__device__ __forceinline__ int wave_sum(int v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
 }
 
 __global__ __launch_bounds__(BT) void beam_kernel(BeamArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int C = a.C, BW = a.beam, NMAX = BW * (C + 1);
     // ---- LDS carve
     double* lp = reinterpret_cast<double*>(smem_raw);                 // [128]
@@ -76,84 +90,101 @@ __global__ __launch_bounds__(BT) void beam_kernel(BeamArgs a) {
     double* e_bcur = e_score + 2 * BW;                                // [BW]
     double* e_rep = e_bcur + BW;
     double* e_ext = e_rep + BW;
-    double* c_logp = e_ext + BW;                                      // [NMAX]
-    uint64_t* c_key = reinterpret_cast<uint64_t*>(c_logp + NMAX);     // [NMAX]
+    uint64_t* c_key = reinterpret_cast<uint64_t*>(e_ext + BW);        // [NMAX] 0 = no candidate, else okey(logp)
     uint64_t* su = c_key + NMAX;                                      // [2] scalars (radix prefix)
     int* e_node = reinterpret_cast<int*>(su + 2);                     // [2][BW]
     int* e_ch = e_node + 2 * BW;                                      // [2][BW]
-    int* c_child = e_ch + 2 * BW;                                     // [NMAX]
+    int* e_ds = e_ch + 2 * BW;                                        // [2][BW] dictionary state of the entry's node
+    int* c_child = e_ds + 2 * BW;                                     // [NMAX]
     int* c_surv = c_child + NMAX;                                     // [NMAX]
-    int* use = c_surv + NMAX;                                         // [128]
-    unsigned* hist = reinterpret_cast<unsigned*>(use + 128);          // [256]
-    int* scan = reinterpret_cast<int*>(hist + 256);                   // [BT + 1]
-    int* si = scan + BT + 1;                                          // [8] scalars
+    int* newn = c_surv + NMAX;                                        // [BW] nodes created this frame
+    int* use = newn + BW;                                             // [128]
+    unsigned* hist = reinterpret_cast<unsigned*>(use + 128);          // [2][256]
+    int* wtot = reinterpret_cast<int*>(hist + 512);                   // [NWAVE + 1]
+    int* si = wtot + NWAVE + 1;                                       // [8] scalars
 #define s_nb si[0]
 #define s_full si[1]
 #define s_m si[2]
 #define s_nuse si[3]
 #define s_kk si[4]
+#define s_done si[5]
+#define s_nnew si[6]
 #define s_mincut sd[0]
 #define s_prefix su[0]
 
     // ---- per-utterance global state
-    const size_t nb0 = (size_t)b * a.ncap;
-    int32_t* parent = a.parent + nb0; int32_t* chn = a.ch + nb0; int32_t* tstep = a.tstep + nb0;
-    int32_t* dstate = a.dstate + nb0; int32_t* nchild = a.nchild + nb0; int32_t* flags = a.flags + nb0;
-    int32_t* slot = a.slot + nb0; int32_t* ctx = a.ctx + nb0 * MAXCTX; double* lpc = a.lpc + nb0;
-    int32_t* htab = a.htab + (size_t)b * a.hsize;
+    Node* nodes = a.nodes + (size_t)b * a.ncap;
+    int32_t* childtab = a.childtab + (size_t)b * a.ncap * C;
     int32_t* nnodes = a.nnodes + b;
-    const unsigned hmask = (unsigned)a.hsize - 1;
     const int T = a.sizes ? min(a.sizes[b], a.T) : a.T;
     const float* pb = a.probs + (size_t)b * a.T * C;
     const int NCTX = a.order - 1;
 
-    for (int i = tid; i < a.hsize; i += BT) htab[i] = -1;
+    if (tid < C) childtab[tid] = -1;
     if (tid == 0) {
-        parent[0] = -1; chn[0] = -1; tstep[0] = 0; dstate[0] = 0; nchild[0] = 0; flags[0] = F_EXISTS; slot[0] = 0; lpc[0] = -INFINITY;
-        for (int k = 0; k < MAXCTX; ++k) ctx[k] = a.bos;
+        Node r{};
+        r.parent = -1; r.ch = -1; r.tstep = 0; r.dstate = 0; r.nchild = 0; r.flags = F_EXISTS; r.slot = 0; r.memo = MEMO_UNSET;
+        r.lpc = -INFINITY;
+        for (int k = 0; k < MAXCTX; ++k) r.ctx[k] = a.bos;
+        nodes[0] = r;
         *nnodes = 1;
-        e_node[0] = 0; e_ch[0] = -1; e_bprev[0] = 0.0; e_nbprev[0] = -INFINITY; e_score[0] = 0.0;
+        e_node[0] = 0; e_ch[0] = -1; e_ds[0] = 0; e_bprev[0] = 0.0; e_nbprev[0] = -INFINITY; e_score[0] = 0.0;
         s_nb = 1;
     }
+    float pnext = (tid < C && T > 0) ? pb[tid] : 0.f;     // next frame's row, fetched one frame ahead
     __syncthreads();
     int cur = 0;
 
     for (int t = 0; t < T; ++t) {
         const int nb = s_nb;
         double* bprev = e_bprev + cur * BW; double* nbprev = e_nbprev + cur * BW; double* score = e_score + cur * BW;
-        int* node = e_node + cur * BW; int* ech = e_ch + cur * BW;
+        int* node = e_node + cur * BW; int* ech = e_ch + cur * BW; int* eds = e_ds + cur * BW;
         const float* pr = pb + (size_t)t * C;
         // ---- 1. log-probabilities and vocabulary pruning (decoder_utils get_pruned_log_probs)
-        for (int c = tid; c < C; c += BT) { lp[c] = log((double)pr[c] + 1.17549435e-38); use[c] = 1; }
-        __syncthreads();
+        if (tid < C) { lp[tid] = log((double)pnext + 1.17549435e-38); use[tid] = 1; }
+        if (tid < C && t + 1 < T) pnext = pr[C + tid];
+        for (int i = tid; i < nb; i += BT) { e_bcur[i] = -INFINITY; e_rep[i] = -INFINITY; e_ext[i] = -INFINITY; }
+        if (wid == 1) {
+            // ---- min_cutoff / full_beam (scorer only)
+            double mn = INFINITY;
+            if (a.has_lm) {
+                for (int i = lane; i < nb; i += 64) mn = fmin(mn, score[i]);
+                for (int o = 32; o > 0; o >>= 1) mn = fmin(mn, __shfl_xor(mn, o, 64));
+            }
+            if (lane == 0) {
+                s_full = 0; s_mincut = -INFINITY;
+                if (a.has_lm) {
+                    const float pbl = pr[a.blank];
+                    const double blp = pbl > 0.f ? log((double)pbl) : -INFINITY;
+                    s_mincut = mn + blp - fmax(0.0, a.beta);
+                    s_full = nb == BW;
+                }
+            }
+        }
         if (tid == 0) {
             s_nuse = C;
             if (a.cutoff_prob < 1.0f || a.cutoff_top_n < C) {
                 // selection by repeated maximum: C is small (<= 128)
-                for (int c = 0; c < C; ++c) use[c] = 0;
+                bool used[128];
+                for (int c = 0; c < C; ++c) used[c] = false;
                 double cum = 0.0; int len = 0;
                 const int maxlen = a.cutoff_prob < 1.0f ? C : a.cutoff_top_n;
                 while (len < maxlen) {
                     int best = -1; float bv = -1.f;
-                    for (int c = 0; c < C; ++c) if (!use[c] && pr[c] > bv) { bv = pr[c]; best = c; }
+                    for (int c = 0; c < C; ++c) if (!used[c] && pr[c] > bv) { bv = pr[c]; best = c; }
                     if (best < 0) break;
-                    use[best] = 1; ++len; cum += (double)bv;
+                    used[best] = true; ++len; cum += (double)bv;
                     if (a.cutoff_prob < 1.0f && (cum >= (double)a.cutoff_prob || len >= a.cutoff_top_n)) break;
                 }
-                s_nuse = len;
-            }
-            // ---- min_cutoff / full_beam (scorer only)
-            s_full = 0; s_mincut = -INFINITY;
-            if (a.has_lm) {
-                double mn = INFINITY;
-                for (int i = 0; i < nb; ++i) mn = fmin(mn, score[i]);
-                const double blp = pr[a.blank] > 0.f ? log((double)pr[a.blank]) : -INFINITY;
-                s_mincut = mn + blp - fmax(0.0, a.beta);
-                s_full = nb == BW;
+                s_nuse = -len;     // negative: the mask below still has to be applied
+                for (int c = 0; c < C; ++c) c_surv[c] = used[c];
             }
         }
-        for (int i = tid; i < nb; i += BT) { e_bcur[i] = -INFINITY; e_rep[i] = -INFINITY; e_ext[i] = -INFINITY; }
         __syncthreads();
+        if (s_nuse < 0) {
+            if (tid < C) use[tid] = c_surv[tid];
+            __syncthreads();
+        }
         const bool full = s_full != 0;
         const double mincut = s_mincut;
 
@@ -161,43 +192,52 @@ __global__ __launch_bounds__(BT) void beam_kernel(BeamArgs a) {
         const int NP = nb * C;
         for (int idx = tid; idx < NP; idx += BT) {
             const int i = idx / C, c = idx - i * C;
-            c_key[idx] = 0; c_child[idx] = -2;
-            if (!use[c]) continue;
-            const double l = lp[c], sc = score[i];
-            if (full && l + sc < mincut) continue;
-            if (c == a.blank) { e_bcur[i] = l + sc; continue; }
-            const int lastc = ech[i];
-            if (c == lastc) e_rep[i] = l + nbprev[i];
-            const int pn = node[i];
-            // child lookup in the prefix trie
-            int child = -1;
-            for (unsigned s = hmix(pn, c) & hmask;; s = (s + 1) & hmask) {
-                const int id = htab[s];
-                if (id < 0) break;
-                if (parent[id] == pn && chn[id] == c) { child = id; break; }
-            }
-            const bool alive = child >= 0 && !(flags[child] & F_DELETED);
-            const int ds = dstate[pn];
-            if (!alive && a.has_lm) {   // dictionary: a new child needs an arc (space: a word must end here)
-                const bool ok = c == a.space ? a.trie_word[ds] >= 0 : a.trie_next[(size_t)ds * C + c] >= 0;
-                if (!ok) continue;
-            }
-            double logp = -INFINITY;
-            if (c == lastc) { if (bprev[i] > -INFINITY) logp = l + bprev[i]; }
-            else logp = l + sc;
-            if (a.has_lm && c == a.space) {
-                const int w = a.trie_word[ds];
-                double lm = kOovScore;
-                if (w >= 0) lm = (double)lm_cond_log10(a.lm_tab, a.lm_mask, ctx + (size_t)pn * MAXCTX, NCTX, w, a.unk) / (double)kLog10E;
-                logp += lm * a.alpha;
-                logp += a.beta;
-            }
-            if (alive) {
-                if (lpc[child] < l) { lpc[child] = l; tstep[child] = t; }
-                if (flags[child] & F_EXISTS) { e_ext[slot[child]] = logp; continue; }
-            }
-            c_logp[idx] = logp; c_child[idx] = alive ? child : (child >= 0 ? -3 - child : -1);   // <= -3: reuse deleted id
-            c_key[idx] = okey(logp);
+            uint64_t key = 0; int cc = -2;
+            do {
+                if (!use[c]) break;
+                const double l = lp[c], sc = score[i];
+                if (full && l + sc < mincut) break;
+                if (c == a.blank) { e_bcur[i] = l + sc; break; }
+                const int lastc = ech[i];
+                if (c == lastc) e_rep[i] = l + nbprev[i];
+                const int pn = node[i];
+                const int ds = eds[i];
+                // independent loads first: child id, dictionary arc, memoised LM score of the parent
+                const int child = childtab[(size_t)pn * C + c];
+                const bool sp = a.has_lm && c == a.space;
+                int arc = 0, memo = 0;
+                if (a.has_lm) arc = c == a.space ? a.trie_word[ds] : a.trie_next[(size_t)ds * C + c];
+                if (sp) memo = nodes[pn].memo;
+                int cflags = F_DELETED, cslot = -1;
+                if (child >= 0) {
+                    Node* cn = nodes + child;
+                    cflags = cn->flags; cslot = cn->slot;
+                    if (!(cflags & F_DELETED) && cn->lpc < l) { cn->lpc = l; cn->tstep = t; }
+                }
+                const bool alive = !(cflags & F_DELETED);
+                if (!alive && a.has_lm && arc < 0) break;   // dictionary: a new child needs an arc (space: a word must end here)
+                double logp = -INFINITY;
+                if (c == lastc) { if (bprev[i] > -INFINITY) logp = l + bprev[i]; }
+                else logp = l + sc;
+                if (sp) {
+                    double lm = kOovScore;
+                    if (arc >= 0) {
+                        float l10;
+                        if (memo != MEMO_UNSET) l10 = __int_as_float(memo);
+                        else {
+                            l10 = lm_cond_log10(a.lm_tab, a.lm_mask, nodes[pn].ctx, NCTX, arc, a.unk);
+                            nodes[pn].memo = __float_as_int(l10);
+                        }
+                        lm = (double)l10 / (double)kLog10E;
+                    }
+                    logp += lm * a.alpha;
+                    logp += a.beta;
+                }
+                if (alive && (cflags & F_EXISTS)) { e_ext[cslot] = logp; break; }
+                cc = alive ? child : (child >= 0 ? -3 - child : -1);   // <= -3: reuse deleted id
+                key = okey(logp);
+            } while (false);
+            c_key[idx] = key; c_child[idx] = cc;
         }
         __syncthreads();
         // entries themselves
@@ -205,7 +245,7 @@ __global__ __launch_bounds__(BT) void beam_kernel(BeamArgs a) {
             const double nbc = lse2(e_rep[i], e_ext[i]);
             e_rep[i] = nbc;                         // now nb_cur
             const double s = lse2(e_bcur[i], nbc);
-            c_logp[NP + i] = s; c_child[NP + i] = node[i]; c_key[NP + i] = okey(s);
+            c_child[NP + i] = node[i]; c_key[NP + i] = okey(s);
         }
         __syncthreads();
         const int N = NP + nb;
@@ -214,133 +254,178 @@ __global__ __launch_bounds__(BT) void beam_kernel(BeamArgs a) {
         {
             int cnt = 0;
             for (int idx = tid; idx < N; idx += BT) cnt += c_key[idx] != 0;
-            for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-            if ((tid & 63) == 0) scan[tid >> 6] = cnt;
+            cnt = wave_sum(cnt);
+            if (lane == 0) wtot[wid] = cnt;
+            if (tid < 256) hist[tid] = 0;
             __syncthreads();
-            if (tid == 0) s_m = scan[0] + scan[1] + scan[2] + scan[3];
+            if (tid == 0) {
+                int m = 0;
+                for (int w = 0; w < NWAVE; ++w) m += wtot[w];
+                s_m = m; s_prefix = 0; s_kk = BW; s_done = 0;
+            }
             __syncthreads();
         }
         const int M = s_m;
         if (M <= BW) {
             for (int idx = tid; idx < N; idx += BT) c_surv[idx] = c_key[idx] != 0;
         } else {
-            if (tid == 0) { s_prefix = 0; s_kk = BW; }
-            for (int pass = 0; pass < 8; ++pass) {
+            // radix select, 8 bits per pass from the top; stops as soon as the threshold bin is taken whole
+            int pass = 0;
+            for (; pass < 8; ++pass) {
                 const int shift = 56 - 8 * pass;
-                hist[tid] = 0;
-                __syncthreads();
+                unsigned* h = hist + (pass & 1) * 256;
+                unsigned* hn = hist + ((pass + 1) & 1) * 256;
                 const uint64_t pre = s_prefix;
                 for (int idx = tid; idx < N; idx += BT) {
                     const uint64_t k = c_key[idx];
-                    if (k != 0 && (pass == 0 || (k >> (shift + 8)) == pre)) atomicAdd(&hist[(unsigned)(k >> shift) & 255u], 1u);
+                    if (k != 0 && (pass == 0 || (k >> (shift + 8)) == pre)) atomicAdd(&h[(unsigned)(k >> shift) & 255u], 1u);
                 }
+                if (tid >= 256 && tid < 512) hn[tid - 256] = 0;
                 __syncthreads();
-                if (tid == 0) {
-                    unsigned kk = (unsigned)s_kk, cum = 0;
-                    int d = 255;
-                    for (; d > 0; --d) { if (cum + hist[d] >= kk) break; cum += hist[d]; }
-                    s_kk = (int)(kk - cum);
-                    s_prefix = (pre << 8) | (unsigned)d;
-                }
-                __syncthreads();
-            }
-            const uint64_t thr = s_prefix;
-            const int need = (int)s_kk;          // how many of the keys equal to thr survive
-            // ties at the threshold: (character asc, candidate index asc)
-            for (int idx = tid; idx < N; idx += BT) {
-                const uint64_t k = c_key[idx];
-                int sv = k > thr;
-                if (k == thr) {
-                    const int myc = idx < NP ? idx % C : e_ch[cur * BW + (idx - NP)];
-                    int rank = 0;
-                    for (int j = 0; j < N; ++j) {
-                        if (c_key[j] != thr || j == idx) continue;
-                        const int oc = j < NP ? j % C : e_ch[cur * BW + (j - NP)];
-                        rank += (oc < myc) || (oc == myc && j < idx);
+                if (wid == 0) {
+                    // lane l owns bins 4l .. 4l+3; suffix sums from the top bin down
+                    const unsigned h0 = h[4 * lane], h1 = h[4 * lane + 1], h2 = h[4 * lane + 2], h3 = h[4 * lane + 3];
+                    const unsigned mine = h0 + h1 + h2 + h3;
+                    unsigned suf = mine;                         // inclusive suffix sum over lanes >= lane
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const unsigned v = __shfl_down(suf, o, 64);
+                        if (lane + o < 64) suf += v;
                     }
-                    sv = rank < need;
+                    const unsigned kk = (unsigned)s_kk;
+                    const unsigned long long bal = __ballot(suf >= kk);
+                    const int owner = 63 - __builtin_clzll(bal);   // highest lane whose suffix reaches kk
+                    if (lane == owner) {
+                        unsigned cum = suf - mine;               // keys in bins above this lane's
+                        int d; unsigned hd;
+                        if (cum + h3 >= kk) { d = 3; hd = h3; }
+                        else { cum += h3; if (cum + h2 >= kk) { d = 2; hd = h2; }
+                        else { cum += h2; if (cum + h1 >= kk) { d = 1; hd = h1; }
+                        else { cum += h1; d = 0; hd = h0; } } }
+                        s_kk = (int)(kk - cum);
+                        s_prefix = (pre << 8) | (unsigned)(4 * lane + d);
+                        s_done = hd == kk - cum;                 // the whole bin survives: no deeper pass needed
+                    }
                 }
-                c_surv[idx] = sv;
+                __syncthreads();
+                if (s_done) break;
+            }
+            if (pass < 8) {
+                const int shift = 56 - 8 * pass;
+                const uint64_t thr = s_prefix;
+                for (int idx = tid; idx < N; idx += BT) {
+                    const uint64_t k = c_key[idx];
+                    c_surv[idx] = k != 0 && (k >> shift) >= thr;
+                }
+            } else {
+                const uint64_t thr = s_prefix;
+                const int need = (int)s_kk;          // how many of the keys equal to thr survive
+                // ties at the threshold: (character asc, candidate index asc)
+                for (int idx = tid; idx < N; idx += BT) {
+                    const uint64_t k = c_key[idx];
+                    int sv = k > thr;
+                    if (k == thr) {
+                        const int myc = idx < NP ? idx % C : ech[idx - NP];
+                        int rank = 0;
+                        for (int j = 0; j < N; ++j) {
+                            if (c_key[j] != thr || j == idx) continue;
+                            const int oc = j < NP ? j % C : ech[j - NP];
+                            rank += (oc < myc) || (oc == myc && j < idx);
+                        }
+                        sv = rank < need;
+                    }
+                    c_surv[idx] = sv;
+                }
             }
         }
         __syncthreads();
         // ---- deterministic slot numbers: exclusive scan of the survivor flags in index order
         const int per = (N + BT - 1) / BT;
-        const int i0 = tid * per, i1 = min(i0 + per, N);
+        const int i0 = min(tid * per, N), i1 = min(i0 + per, N);
         int local = 0;
         for (int idx = i0; idx < i1; ++idx) local += c_surv[idx];
-        scan[tid] = local;
-        __syncthreads();
-        if (tid == 0) {
-            int acc = 0;
-            for (int i = 0; i < BT; ++i) { const int v = scan[i]; scan[i] = acc; acc += v; }
-            scan[BT] = acc;
+        int incl = local;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += v;
         }
+        if (lane == 63) wtot[wid] = incl;
+        if (tid == 0) s_nnew = 0;
         __syncthreads();
-        const int nnext = scan[BT];
+        int wbase = 0, nnext = 0;
+        for (int w = 0; w < NWAVE; ++w) { const int v = wtot[w]; if (w < wid) wbase += v; nnext += v; }
         const int nxt = cur ^ 1;
         // ---- 4a. commit survivors (new nodes first so that child counts are up before any removal)
         {
-            int pos = scan[tid];
+            int pos = wbase + incl - local;
             for (int idx = i0; idx < i1; ++idx) {
                 if (!c_surv[idx]) continue;
                 const int sl = pos++;
+                const double lg = unokey(c_key[idx]);
                 if (idx >= NP) {                                   // an entry that stays
                     const int i = idx - NP;
-                    e_node[nxt * BW + sl] = node[i]; e_ch[nxt * BW + sl] = ech[i];
-                    e_bprev[nxt * BW + sl] = e_bcur[i]; e_nbprev[nxt * BW + sl] = e_rep[i]; e_score[nxt * BW + sl] = c_logp[idx];
-                    slot[node[i]] = sl;
+                    e_node[nxt * BW + sl] = node[i]; e_ch[nxt * BW + sl] = ech[i]; e_ds[nxt * BW + sl] = eds[i];
+                    e_bprev[nxt * BW + sl] = e_bcur[i]; e_nbprev[nxt * BW + sl] = e_rep[i]; e_score[nxt * BW + sl] = lg;
+                    nodes[node[i]].slot = sl;
                     continue;
                 }
                 const int i = idx / C, c = idx - i * C;
                 const int pn = node[i];
                 int id = c_child[idx];
-                const double l = lp[c];
+                int nds;
                 if (id >= 0) {                                     // dormant node (kept alive by descendants) comes back
-                    atomicOr(&flags[id], F_EXISTS);
+                    atomicOr(&nodes[id].flags, F_EXISTS);
+                    nds = nodes[id].dstate;
                 } else {
                     const bool reuse = id <= -3;
                     id = reuse ? -3 - id : atomicAdd(nnodes, 1);
-                    parent[id] = pn; chn[id] = c; tstep[id] = t; lpc[id] = l; nchild[id] = 0; flags[id] = F_EXISTS;
-                    const int ds = dstate[pn];
+                    const int ds = eds[i];
                     const bool sp = a.has_lm && c == a.space;
-                    dstate[id] = a.has_lm ? (sp ? 0 : a.trie_next[(size_t)ds * C + c]) : 0;
+                    nds = a.has_lm ? (sp ? 0 : a.trie_next[(size_t)ds * C + c]) : 0;
                     const int w = sp ? a.trie_word[ds] : -1;
+                    Node r;
+                    r.parent = pn; r.ch = c; r.tstep = t; r.dstate = nds; r.nchild = 0; r.flags = F_EXISTS; r.slot = sl; r.memo = MEMO_UNSET;
+                    r.lpc = lp[c]; r.pad = 0;
+                    const Node* pnode = nodes + pn;
                     for (int k = 0; k < MAXCTX; ++k) {
-                        int v = ctx[(size_t)pn * MAXCTX + k];
-                        if (sp) v = k + 1 < NCTX ? ctx[(size_t)pn * MAXCTX + k + 1] : (k + 1 == NCTX ? w : a.bos);
-                        ctx[(size_t)id * MAXCTX + k] = v;
+                        int v = pnode->ctx[k];
+                        if (sp) v = k + 1 < NCTX ? pnode->ctx[k + 1] : (k + 1 == NCTX ? w : a.bos);
+                        r.ctx[k] = v;
                     }
-                    atomicAdd(&nchild[pn], 1);
+                    nodes[id] = r;
+                    atomicAdd(&nodes[pn].nchild, 1);
                     if (!reuse) {
-                        for (unsigned s = hmix(pn, c) & hmask;; s = (s + 1) & hmask)
-                            if (atomicCAS(&htab[s], -1, id) == -1) break;
+                        childtab[(size_t)pn * C + c] = id;
+                        newn[atomicAdd(&s_nnew, 1)] = id;
                     }
                 }
-                slot[id] = sl;
-                e_node[nxt * BW + sl] = id; e_ch[nxt * BW + sl] = c;
-                e_bprev[nxt * BW + sl] = -INFINITY; e_nbprev[nxt * BW + sl] = c_logp[idx]; e_score[nxt * BW + sl] = c_logp[idx];
+                nodes[id].slot = sl;
+                e_node[nxt * BW + sl] = id; e_ch[nxt * BW + sl] = c; e_ds[nxt * BW + sl] = nds;
+                e_bprev[nxt * BW + sl] = -INFINITY; e_nbprev[nxt * BW + sl] = lg; e_score[nxt * BW + sl] = lg;
             }
         }
-        __syncthreads();
         // ---- 4b. PathTrie::remove for the entries that fell out
         for (int i = tid; i < nb; i += BT) {
             if (c_surv[NP + i]) continue;
-            int n = node[i];
-            atomicAnd(&flags[n], ~F_EXISTS);
-            slot[n] = -1;
+            Node* n = nodes + node[i];
+            atomicAnd(&n->flags, ~F_EXISTS);
+            n->slot = -1;
         }
         __syncthreads();
+        {   // fresh nodes start with an empty child row
+            const int nnew = s_nnew;
+            for (int q = tid; q < nnew * C; q += BT) { const int j = q / C; childtab[(size_t)newn[j] * C + (q - j * C)] = -1; }
+        }
         for (int i = tid; i < nb; i += BT) {
             if (c_surv[NP + i]) continue;
             int n = node[i];
             while (n > 0) {
-                if (atomicAdd(&nchild[n], 0) != 0) break;
-                const int f = atomicAdd(&flags[n], 0);
+                Node* r = nodes + n;
+                if (atomicAdd(&r->nchild, 0) != 0) break;
+                const int f = atomicAdd(&r->flags, 0);
                 if (f & F_EXISTS) break;
-                if (atomicOr(&flags[n], F_DELETED) & F_DELETED) break;    // someone else unlinked it
-                const int p = parent[n];
-                if (atomicSub(&nchild[p], 1) != 1) break;
+                if (atomicOr(&r->flags, F_DELETED) & F_DELETED) break;    // someone else unlinked it
+                const int p = r->parent;
+                if (atomicSub(&nodes[p].nchild, 1) != 1) break;
                 n = p;
             }
         }
@@ -357,9 +442,9 @@ __global__ __launch_bounds__(BT) void beam_kernel(BeamArgs a) {
             for (int i = tid; i < nb; i += BT) {
                 const int n = node[i];
                 if (n != 0 && ech[i] != a.space) {
-                    const int w = a.trie_word[dstate[n]];
+                    const int w = a.trie_word[nodes[n].dstate];
                     double lm = kOovScore;
-                    if (w >= 0) lm = (double)lm_cond_log10(a.lm_tab, a.lm_mask, ctx + (size_t)n * MAXCTX, NCTX, w, a.unk) / (double)kLog10E;
+                    if (w >= 0) lm = (double)lm_cond_log10(a.lm_tab, a.lm_mask, nodes[n].ctx, NCTX, w, a.unk) / (double)kLog10E;
                     double s = lm * a.alpha;
                     s += a.beta;
                     score[i] += s;
@@ -374,10 +459,10 @@ __global__ __launch_bounds__(BT) void beam_kernel(BeamArgs a) {
                 rank += score[j] > score[i] || (score[j] == score[i] && (ech[j] < ech[i] || (ech[j] == ech[i] && j < i)));
             }
             int len = 0;
-            for (int n = node[i]; n > 0; n = parent[n]) ++len;
+            for (int n = node[i]; n > 0; n = nodes[n].parent) ++len;
             const size_t o = ((size_t)b * BW + rank) * a.T;
             int k = len;
-            for (int n = node[i]; n > 0; n = parent[n]) { --k; a.out_tok[o + k] = chn[n]; a.out_step[o + k] = tstep[n]; }
+            for (int n = node[i]; n > 0; n = nodes[n].parent) { --k; a.out_tok[o + k] = nodes[n].ch; a.out_step[o + k] = nodes[n].tstep; }
             a.out_len[(size_t)b * BW + rank] = len;
             a.out_score[(size_t)b * BW + rank] = score[i];
         }
@@ -501,28 +586,18 @@ extern "C" int dsmi_beam(dsmi_decoder* d, const float* probs, const int32_t* siz
     const int C = (int)d->labels.size();
     if (!probs || !tokens || !tsteps || !lens || !scores || B < 1 || To < 1 || beam < 1) { d->err = "bad beam arguments"; return DSMI_ERR_INVALID; }
     const size_t NMAX = (size_t)beam * (C + 1);
-    const size_t lds = sizeof(double) * (128 + 2 + 6 * (size_t)beam + 3 * (size_t)beam + NMAX) + sizeof(uint64_t) * (NMAX + 2) +
-                       sizeof(int) * (4 * (size_t)beam + 2 * NMAX + 128) + sizeof(unsigned) * 256 + sizeof(int) * (BT + 1 + 8) + 64;
+    const size_t lds = sizeof(double) * (128 + 2 + 6 * (size_t)beam + 3 * (size_t)beam) + sizeof(uint64_t) * (NMAX + 2) +
+                       sizeof(int) * (6 * (size_t)beam + 2 * NMAX + (size_t)beam + 128) + sizeof(unsigned) * 512 +
+                       sizeof(int) * (NWAVE + 1 + 8) + 64;
     if (lds > 160 * 1024 - 256) { d->err = "beam_width * (n_labels + 1) exceeds the on-chip candidate buffer"; return DSMI_ERR_CAPACITY; }
     DEC_HIP(d, hipSetDevice(d->device));
     hipStream_t s = (hipStream_t)stream;
     // ---- workspace carve
     const int ncap = 2 + To * beam;
-    int hsize = 16;
-    while (hsize < 2 * ncap) hsize <<= 1;
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    const size_t n_i32 = (size_t)B * ncap;
     size_t off = 0;
-    size_t o_parent = off; off += al(n_i32 * 4);
-    size_t o_ch = off; off += al(n_i32 * 4);
-    size_t o_tstep = off; off += al(n_i32 * 4);
-    size_t o_dstate = off; off += al(n_i32 * 4);
-    size_t o_nchild = off; off += al(n_i32 * 4);
-    size_t o_flags = off; off += al(n_i32 * 4);
-    size_t o_slot = off; off += al(n_i32 * 4);
-    size_t o_ctx = off; off += al(n_i32 * 4 * MAXCTX);
-    size_t o_lpc = off; off += al(n_i32 * 8);
-    size_t o_htab = off; off += al((size_t)B * hsize * 4);
+    size_t o_nodes = off; off += al((size_t)B * ncap * sizeof(Node));
+    size_t o_child = off; off += al((size_t)B * ncap * C * 4);
     size_t o_nn = off; off += al((size_t)B * 4);
     size_t o_sizes = off; off += al((size_t)B * 4);
     size_t o_tok = off; off += al((size_t)B * beam * To * 4);
@@ -543,10 +618,8 @@ extern "C" int dsmi_beam(dsmi_decoder* d, const float* probs, const int32_t* siz
     a.cutoff_top_n = cutoff_top_n; a.cutoff_prob = (float)cutoff_prob;
     a.has_lm = d->has_lm ? 1 : 0; a.order = d->has_lm ? d->lm.order : 1; a.alpha = d->alpha; a.beta = d->beta;
     a.lm_tab = d->d_tab; a.lm_mask = d->lm.mask; a.trie_next = d->d_next; a.trie_word = d->d_word; a.unk = d->lm.unk; a.bos = d->lm.bos;
-    a.ncap = ncap; a.hsize = hsize;
-    a.parent = (int32_t*)(w + o_parent); a.ch = (int32_t*)(w + o_ch); a.tstep = (int32_t*)(w + o_tstep); a.dstate = (int32_t*)(w + o_dstate);
-    a.nchild = (int32_t*)(w + o_nchild); a.flags = (int32_t*)(w + o_flags); a.slot = (int32_t*)(w + o_slot); a.ctx = (int32_t*)(w + o_ctx);
-    a.lpc = (double*)(w + o_lpc); a.htab = (int32_t*)(w + o_htab); a.nnodes = (int32_t*)(w + o_nn);
+    a.ncap = ncap;
+    a.nodes = (Node*)(w + o_nodes); a.childtab = (int32_t*)(w + o_child); a.nnodes = (int32_t*)(w + o_nn);
     a.out_tok = (int32_t*)(w + o_tok); a.out_step = (int32_t*)(w + o_step); a.out_len = (int32_t*)(w + o_len); a.out_n = (int32_t*)(w + o_n);
     a.out_score = (double*)(w + o_score);
     a.sizes = nullptr;

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Timing/sanity of the BASELINE.json configs through the public surface (synthetic weights/LM).
+    python tools/run_configs.py [2 3 4 5]
+"""
+import os, sys, time, tempfile
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from danspeech_amd import synthetic as syn
+from danspeech_amd.deepspeech.model import DeepSpeech
+from danspeech_amd import Recognizer
+
+
+def build(H, L, lm_order=None, beam=None, n_words=5000):
+    sd = syn.make_state_dict(2, "gru", H, L, seed=0, fc_gain=8.0)
+    m = DeepSpeech("cfg", rnn_hidden_size=H, rnn_layers=L).load_state_dict(sd)
+    rec = Recognizer(model=m)
+    if lm_order:
+        path = os.path.join(tempfile.gettempdir(), "syn%d.arpa" % lm_order)
+        if not os.path.exists(path):
+            syn.make_arpa(path, order=lm_order, n_words=n_words, seed=11, ngrams_per_order=20000)
+        rec.update_decoder(lm=path, beam_width=beam)
+    return rec
+
+
+def run(name, rec, B, seconds, reps=3):
+    clips = [syn.make_clip(i, int(seconds * 16000)) for i in range(B)]
+    rec.recognize_batch(clips)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = rec.recognize_batch(clips)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    print("%-52s %8.1f ms/batch  %9.0f audio-s/s  (host->device PCM copy included)" % (name, dt * 1e3, B * seconds / dt), flush=True)
+    return out
+
+
+which = [int(a) for a in sys.argv[1:]] or [2, 3, 4, 5]
+if 2 in which:
+    run("config 2: cfgA greedy B=32 x 10 s", build(800, 5), 32, 10.0)
+if 3 in which:
+    run("config 3: cfgA + 3-gram beam=64 B=32 x 10 s", build(800, 5, 3, 64), 32, 10.0)
+if 4 in which:
+    run("config 4: 7 x BiGRU1200 + 5-gram beam=128 B=64 x 10 s", build(1200, 7, 5, 128), 64, 10.0, reps=2)
+if 5 in which:
+    run("config 5 (one GPU's share): cfgA + 3-gram beam=64 B=128 x 30 s", build(800, 5, 3, 64), 128, 30.0, reps=1)

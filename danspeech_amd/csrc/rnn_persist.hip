@@ -47,6 +47,8 @@ struct PersistArgs {
     const float* bhh[2]; const float* xp; float* out[2];
     const int32_t* lens; uint16_t* hpack3; unsigned* cnt; unsigned* err;
     int B, T, G, H, Hs, npair, Np, nwg;
+    int nz;                    // batch tiles of 32 clips, all walked by every workgroup each step
+    int d0, nd;                // first direction of this launch, directions in the layer (chains are numbered over the layer)
     unsigned long long* dbg;   // diagnostics build only: per-wave accumulated phase times [wg][wave][8]
 };
 
@@ -62,7 +64,9 @@ __device__ __forceinline__ float psigmoid(float v) { return 1.f / (1.f + expf(-v
         }                                                                                 \
     } while (0)
 
-template <int KIND, int NPW, bool STAMP = false>
+constexpr int PMAXZ = 8;               // batch tiles per launch (B <= 256)
+
+template <int KIND, int NPW, bool MULTI, bool STAMP = false>
 __global__ __launch_bounds__(PNT) void rnn_persist_kernel(PersistArgs p) {
     unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long tlast = STAMP ? __builtin_amdgcn_s_memrealtime() : 0;
@@ -73,16 +77,17 @@ __global__ __launch_bounds__(PNT) void rnn_persist_kernel(PersistArgs p) {
     float* red = plds;                               // [PNW][32][32]
     float* hstage = red + PNW * 32 * 32;             // [PU][32]
     int& s_dead = *reinterpret_cast<int*>(hstage + PU * 32);
+    // MULTI: per-tile recurrent state of the epilogue threads (a single tile keeps it in registers)
+    float* st_h = hstage + PU * 32 + 32;             // [PMAXZ][PU*32]
+    float* st_c = st_h + PMAXZ * PU * 32;            // [PMAXZ][PU*32]
+    int* st_len = reinterpret_cast<int*>(st_c + PMAXZ * PU * 32);   // [PMAXZ][PU*32]
     const int tid = threadIdx.x, lane = tid & 63;
     const int v = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, hk = lane >> 5;
-    const int w = blockIdx.x, d = blockIdx.y, z = blockIdx.z;
-    const int b0 = z * 32;
-    const int nb = min(32, p.B - b0);
+    const int w = blockIdx.x, d = p.d0 + blockIdx.y;
+    const int nz = MULTI ? p.nz : 1;
     const int GU = p.G * PU;
     const size_t xcol = (size_t)d * p.nwg * GU + (size_t)w * GU;
-    const int chain = d * gridDim.z + z;
-    unsigned* cnt = p.cnt + (size_t)chain * p.T;
     if (tid == 0) s_dead = 0;
 
     // ---- resident operand: this wave's pairs of the split W_hh (three 1-KiB planes per 16 k)
@@ -98,23 +103,38 @@ __global__ __launch_bounds__(PNT) void rnn_persist_kernel(PersistArgs p) {
         }
     }
     // packed split state, [parity][chain][pair][plane][hk][batch j][8 bf16]; accessed ONLY through sc1 buffer ops
-    const size_t hp_par = (size_t)gridDim.y * gridDim.z * p.npair * 3072;    // bytes per parity
+    const size_t hp_par = (size_t)p.nd * p.nz * p.npair * 3072;    // bytes per parity
     const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.hpack3, 0, (int)(2 * hp_par), 0x00020000);
-    const unsigned hchain = (unsigned)((size_t)chain * p.npair * 3072);
 
-    // epilogue role: threads 0..255 own (unit u = tid>>5, batch bl = tid&31)
+    // epilogue role: threads 0..255 own (unit u = tid>>5, batch bl = tid&31) of every tile
     const int eu = tid >> 5, ebl = tid & 31;
-    const int eunit = w * PU + eu, eb = b0 + ebl;
-    const bool eact = tid < PU * 32 && ebl < nb && eunit < p.H;
+    const int eunit = w * PU + eu;
+    const bool eunit_ok = tid < PU * 32 && eunit < p.H;
     float bh[NG];
 #pragma unroll
-    for (int g = 0; g < NG; ++g) bh[g] = eact ? p.bhh[d][g * p.H + eunit] : 0.f;
-    const int mylen = eact ? p.lens[eb] : 0;
+    for (int g = 0; g < NG; ++g) bh[g] = eunit_ok ? p.bhh[d][g * p.H + eunit] : 0.f;
+    int mylen = (eunit_ok && ebl < p.B) ? p.lens[ebl] : 0;
     float hprev_own = 0.f, cprev_own = 0.f;   // this thread's h_{t-1}, c_{t-1}
+    if (MULTI && tid < PU * 32) {
+        for (int z = 0; z < nz; ++z) {
+            const int eb = z * 32 + ebl;
+            st_h[z * PU * 32 + tid] = 0.f; st_c[z * PU * 32 + tid] = 0.f;
+            st_len[z * PU * 32 + tid] = (eunit_ok && eb < p.B) ? p.lens[eb] : 0;
+        }
+    }
     __syncthreads();
 
     for (int s = 0; s < p.T; ++s) {
         const int t = d == 0 ? s : p.T - 1 - s;
+      for (int z = 0; z < nz; ++z) {
+        const int b0 = z * 32;
+        const int nb = min(32, p.B - b0);
+        const int eb = b0 + ebl;
+        const bool eact = eunit_ok && ebl < nb;
+        const int chain = d * p.nz + z;
+        unsigned* cnt = p.cnt + (size_t)chain * p.T;
+        const unsigned hchain = (unsigned)((size_t)chain * p.npair * 3072);
+        if (MULTI && tid < PU * 32) { mylen = st_len[z * PU * 32 + tid]; hprev_own = st_h[z * PU * 32 + tid]; cprev_own = st_c[z * PU * 32 + tid]; }
         // x-projection operands of this step do not depend on other workgroups: request them first
         float xg[NG];
 #pragma unroll
@@ -205,6 +225,7 @@ __global__ __launch_bounds__(PNT) void rnn_persist_kernel(PersistArgs p) {
                 }
                 if (t >= mylen) hn = 0.f;         // pad_packed_sequence zero; the reverse chain stays at 0 until len-1
                 hprev_own = hn;
+                if (MULTI) { st_h[z * PU * 32 + tid] = hn; if (KIND == DSMI_RNN_LSTM) st_c[z * PU * 32 + tid] = cprev_own; }
                 p.out[d][((size_t)t * p.B + eb) * p.Hs + eunit] = hn;
             } else if (ebl < nb && eunit < p.Hs) {
                 p.out[d][((size_t)t * p.B + eb) * p.Hs + eunit] = 0.f;     // padding units of the last workgroup
@@ -236,27 +257,34 @@ __global__ __launch_bounds__(PNT) void rnn_persist_kernel(PersistArgs p) {
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(&cnt[s], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         PSTAMP(5);   // publish + drain + signal
+      }
     }
     if (STAMP && lane == 0) {
-        unsigned long long* o = p.dbg + ((size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * PNW + v) * 8;
+        unsigned long long* o = p.dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * PNW + v) * 8;
         for (int k = 0; k < 6; ++k) o[k] = tacc[k];
     }
 }
 
 template <int KIND>
-bool launch_kind(const PersistArgs& a, int D, int nz, hipStream_t s, const EvPair& ev) {
+bool launch_kind(const PersistArgs& a, int ny, hipStream_t s, const EvPair& ev) {
     const int npw = ceil_div(a.npair, PNW);
-    const dim3 grid(a.nwg, D, nz), block(PNT);
-#define LAUNCH_P(N, ST)                                                                                              \
+    const dim3 grid(a.nwg, ny, 1), block(PNT);
+#define LAUNCH_P(N, MU, ST)                                                                                          \
     do {                                                                                                             \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rnn_persist_kernel<KIND, N, ST>),                     \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rnn_persist_kernel<KIND, N, MU, ST>),                 \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)PERSIST_LDS);                      \
-        DSMI_LAUNCH((rnn_persist_kernel<KIND, N, ST>), grid, block, PERSIST_LDS, s, ev, a);                           \
+        DSMI_LAUNCH((rnn_persist_kernel<KIND, N, MU, ST>), grid, block, PERSIST_LDS, s, ev, a);                       \
     } while (0)
-    if (a.dbg) { if (npw > 7) return false; LAUNCH_P(7, true); return true; }
-    if (npw <= 2) LAUNCH_P(2, false);
-    else if (npw <= 4) LAUNCH_P(4, false);
-    else if (npw <= 7) LAUNCH_P(7, false);
+    if (a.dbg) { if (npw > 7 || a.nz > 1) return false; LAUNCH_P(7, false, true); return true; }
+    if (a.nz > 1) {
+        if (npw <= 4) LAUNCH_P(4, true, false);
+        else if (npw <= 7) LAUNCH_P(7, true, false);
+        else return false;
+        return true;
+    }
+    if (npw <= 2) LAUNCH_P(2, false, false);
+    else if (npw <= 4) LAUNCH_P(4, false, false);
+    else if (npw <= 7) LAUNCH_P(7, false, false);
     else return false;
     return true;
 }
@@ -267,7 +295,8 @@ bool launch_kind(const PersistArgs& a, int D, int nz, hipStream_t s, const EvPai
 bool rnn_persist_eligible(const RnnGeom& g, int B, int n_cus) {
     if (g.U != PU || (g.H % 8) != 0) return false;
     if (ceil_div(ceil_div(g.nq, 2), PNW) > 7) return false;
-    return g.nwg * g.D * ceil_div(B, 32) <= n_cus;
+    if (ceil_div(B, 32) > PMAXZ) return false;
+    return g.nwg * g.D <= n_cus;
 }
 
 static inline uint16_t bf16_rne(float x) {
@@ -316,11 +345,11 @@ bool launch_rnn_persist(const RnnPersistLaunch& p, hipStream_t s) {
     for (int d = 0; d < 2; ++d) { a.whh3[d] = p.whh3[d]; a.bhh[d] = p.bhh[d]; a.out[d] = p.out[d]; }
     a.xp = p.xp; a.lens = p.lens_dev; a.hpack3 = p.hpack3; a.cnt = p.counters; a.err = p.err; a.dbg = p.dbg;
     a.B = p.B; a.T = p.T; a.G = p.g.G; a.H = p.g.H; a.Hs = p.g.Kp; a.npair = ceil_div(p.g.nq, 2); a.Np = p.g.Np; a.nwg = p.g.nwg;
-    const int nz = ceil_div(p.B, 32);
+    a.nz = ceil_div(p.B, 32); a.d0 = 0; a.nd = p.g.D;
     switch (p.g.kind) {
-        case DSMI_RNN_GRU: return launch_kind<DSMI_RNN_GRU>(a, p.g.D, nz, s, p.ev);
-        case DSMI_RNN_LSTM: return launch_kind<DSMI_RNN_LSTM>(a, p.g.D, nz, s, p.ev);
-        default: return launch_kind<DSMI_RNN_TANH>(a, p.g.D, nz, s, p.ev);
+        case DSMI_RNN_GRU: return launch_kind<DSMI_RNN_GRU>(a, p.g.D, s, p.ev);
+        case DSMI_RNN_LSTM: return launch_kind<DSMI_RNN_LSTM>(a, p.g.D, s, p.ev);
+        default: return launch_kind<DSMI_RNN_TANH>(a, p.g.D, s, p.ev);
     }
 }
 

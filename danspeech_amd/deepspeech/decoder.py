@@ -30,6 +30,15 @@ class Decoder(object):
             space_index = labels.index(' ')
         self.space_index = space_index
         self._native = None
+        # id -> code point table for the common case of one-character labels
+        self._code_points = (np.array([ord(c) for c in labels], dtype="<u4")
+                             if all(len(c) == 1 for c in labels) else None)
+
+    def _to_string(self, ids):
+        """Label ids (int array) -> text."""
+        if self._code_points is not None:
+            return self._code_points[ids].tobytes().decode("utf-32-le")
+        return "".join(self.int_to_char[int(i)] for i in ids)
 
     def _dec(self, device_index):
         from .. import _native
@@ -78,7 +87,7 @@ class GreedyDecoder(Decoder):
         dec = self._dec(probs.device.index or 0)
         sz = None if sizes is None else np.asarray(torch.as_tensor(sizes).cpu()).astype(np.int32)
         res = dec.greedy(probs, sz)
-        strings = [["".join(self.int_to_char[int(i)] for i in ids)] for ids, _ in res]
+        strings = [[self._to_string(ids)] for ids, _ in res]
         offsets = [[torch.from_numpy(off.astype(np.int32))] for _, off in res]
         return strings, offsets
 
@@ -111,12 +120,13 @@ class BeamCTCDecoder(Decoder):
                                    cutoff_prob=self.cutoff_prob)
         self.last_scores = sc      # the reference drops ctcdecode's scores (decoder.py:140); kept for inspection
         strings, offsets = [], []
+        ts_t = torch.from_numpy(ts)
         for b in range(tok.shape[0]):
             su, ou = [], []
             for p in range(tok.shape[1]):
                 n = int(ln[b, p])
-                su.append("".join(self.int_to_char[int(i)] for i in tok[b, p, :n]) if n > 0 else "")
-                ou.append(torch.from_numpy(ts[b, p, :n].copy()) if n > 0 else torch.tensor([], dtype=torch.int))
+                su.append(self._to_string(tok[b, p, :n]) if n > 0 else "")
+                ou.append(ts_t[b, p, :n])
             strings.append(su)
             offsets.append(ou)
         return strings, offsets

@@ -247,3 +247,26 @@ def test_step_path_and_persistent_path_agree(native, monkeypatch):
     p2, _ = m2.forward(_dev(x), lens)
     np.testing.assert_allclose(p1.cpu().numpy(), p2.cpu().numpy(), rtol=0, atol=2e-5)
     m1.close(); m2.close()
+
+
+@pytest.mark.parametrize("kind,B", [("gru", 70), ("lstm", 64), ("rnn", 33)])
+def test_multi_tile_batches_in_the_persistent_kernel_vs_oracle(native, kind, B):
+    """B > 32: every workgroup of the persistent kernel walks several 32-clip tiles per step
+    (ragged last tile, ragged lengths); compared with the oracle and with the per-step path."""
+    from oracle import model as om
+    H = 48
+    sd = syn.make_state_dict(2, kind, H, 2, seed=41, fc_gain=4.0)
+    cfg = _cfg(2, kind, H, 2)
+    rng = np.random.default_rng(42)
+    lens = rng.integers(9, 50, size=B).astype(np.int32)
+    lens[0] = 50
+    lens = np.sort(lens)[::-1].copy()
+    x = syn.make_features(B, 50, seed=43)
+    for b, L in enumerate(lens):
+        x[b, :, :, L:] = 0
+    m = native.NativeModel(cfg, sd)
+    p, ol = m.forward(_dev(x), lens)
+    ref, ol_ref = om.forward(sd, cfg, x, lens)
+    assert np.array_equal(ol, ol_ref)
+    np.testing.assert_allclose(p.cpu().numpy(), ref, rtol=0, atol=1e-4)
+    m.close()

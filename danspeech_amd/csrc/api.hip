@@ -417,13 +417,20 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
         for (int dd = 0; dd < 2; ++dd) { pl.whh3[dd] = m->rnn[l].whh3[dd]; pl.bhh[dd] = m->rnn[l].bhh[dd]; pl.out[dd] = m->hbuf[dst][dd]; }
         pl.xp = m->xp; pl.lens_dev = m->lens_dev; pl.hpack3 = m->hpack3; pl.counters = m->pcnt; pl.err = m->perr; pl.B = B; pl.T = To;
         (void)hipMemsetAsync(m->pcnt, 0, sizeof(unsigned) * (size_t)m->geom.D * ceil_div(B, 32) * To, s);
-        pl.ev = timer_arm(m, KK_PERSIST, true, 2.0 * Dd * GH * m->desc.rnn_hidden_size * sumlen,
-                          4.0 * Dd * (GH * m->desc.rnn_hidden_size + (double)To * B * (GH + 2.0 * m->desc.rnn_hidden_size)));
         // Persistent kernels need every workgroup co-resident, so two of them must never share
         // the device (e.g. two handles on two streams): chain them through a per-device event.
+        // A layer too wide for both directions at once runs them one after the other.
+        const int ny = m->geom.nwg * m->geom.D <= m->n_cus ? m->geom.D : 1;
         hipEvent_t gate = persist_gate(m->device);
         if (gate) (void)hipStreamWaitEvent(s, gate, 0);
-        const bool ok = launch_rnn_persist(pl, s);
+        bool ok = true;
+        for (int d0 = 0; d0 < m->geom.D && ok; d0 += ny) {
+            const double part = (double)ny;
+            pl.d0 = d0; pl.ny = ny;
+            pl.ev = timer_arm(m, KK_PERSIST, true, 2.0 * part * GH * m->desc.rnn_hidden_size * sumlen,
+                              4.0 * part * (GH * m->desc.rnn_hidden_size + (double)To * B * (GH + 2.0 * m->desc.rnn_hidden_size)));
+            ok = launch_rnn_persist(pl, s);
+        }
         if (gate) (void)hipEventRecord(gate, s);
         if (ok) return;
     }
@@ -697,7 +704,8 @@ extern "C" int dsmi_debug_step_stamps(dsmi_model* m, int layer, int B, int To, i
 // ---- diagnostics: accumulated per-wave phase times (100 MHz ticks) of one persistent layer launch;
 // stamps_host[D*nwg][8 waves][8]: 0 loop head, 1 wait, 2 h load + MFMA, 3 LDS + barrier, 4 cell, 5 publish.
 extern "C" int dsmi_debug_persist_stamps(dsmi_model* m, int layer, int B, int To, uint64_t* stamps_host, int64_t n_words) {
-    if (!m || !m->finalized || B > 32 || layer < 0 || layer >= m->desc.rnn_layers || !rnn_persist_eligible(m->geom, B, m->n_cus)) return DSMI_ERR_INVALID;
+    if (!m || !m->finalized || B > 32 || layer < 0 || layer >= m->desc.rnn_layers || !rnn_persist_eligible(m->geom, B, m->n_cus) ||
+        m->geom.nwg * m->geom.D > m->n_cus) return DSMI_ERR_INVALID;
     int Tin = To;
     while (seq_len(m, Tin) < To) Tin += 1;
     int rc;
@@ -715,6 +723,7 @@ extern "C" int dsmi_debug_persist_stamps(dsmi_model* m, int layer, int B, int To
     pl.g = m->geom;
     for (int dd = 0; dd < 2; ++dd) { pl.whh3[dd] = m->rnn[layer].whh3[dd]; pl.bhh[dd] = m->rnn[layer].bhh[dd]; pl.out[dd] = m->hbuf[0][dd]; }
     pl.xp = m->xp; pl.lens_dev = m->lens_dev; pl.hpack3 = m->hpack3; pl.counters = m->pcnt; pl.err = m->perr; pl.B = B; pl.T = To;
+    pl.d0 = 0; pl.ny = m->geom.D;
     for (int rep = 0; rep < 2; ++rep) {     // first pass warms up, second is stamped
         HIP_OK(m, hipMemset(m->pcnt, 0, sizeof(unsigned) * (size_t)m->geom.D * To));
         pl.dbg = rep ? dbg : nullptr;

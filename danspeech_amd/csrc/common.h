@@ -133,6 +133,7 @@ struct RnnPersistLaunch {
     unsigned* counters;          // [D * ceil(B/32)][T], zeroed before the launch
     unsigned* err;               // one word, set on a wait timeout
     int B, T;
+    int d0 = 0, ny = 1;          // this launch covers directions d0 .. d0+ny-1 (grid = nwg x ny workgroups, all co-resident)
     EvPair ev;
     unsigned long long* dbg = nullptr;   // diagnostics: accumulated per-wave phase times
 };

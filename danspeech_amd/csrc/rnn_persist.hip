@@ -164,26 +164,34 @@ __global__ __launch_bounds__(PNT) void rnn_persist_kernel(PersistArgs p) {
             PSTAMP(1);   // waiting for the other workgroups
             // ---- B operand: split h_{s-1}, this wave's pairs, sc1 loads only (lane = hk*32 + j)
             const unsigned hbase = (unsigned)(((s - 1) & 1) * hp_par) + hchain + (unsigned)lane * 16u;
-            bf16x8 hv[NPW][3];
+            // (the widest layers take the state in two halves so that W_hh + h + accumulators fit 256 VGPRs)
+            constexpr int CH = NPW > 7 ? (NPW + 1) / 2 : NPW;
 #pragma unroll
-            for (int i = 0; i < NPW; ++i) {
-                const int pq = min(p0 + i, p1 - 1);
+            for (int c0 = 0; c0 < NPW; c0 += CH) {
+                bf16x8 hv[CH][3];
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    hv[i][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
-                        hrs, hbase + (unsigned)(pq * 3 + pl) * 1024u, 0, 16));
-            }
-            // x . w = sum over the six cross products that matter (mid.lo, lo.mid, lo.lo < 2^-24), small terms first
+                for (int i = 0; i < CH; ++i) {
+                    if (c0 + i < NPW) {
+                        const int pq = min(p0 + c0 + i, p1 - 1);
 #pragma unroll
-            for (int i = 0; i < NPW; ++i) {
-                if (p0 + i < p1) {
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[i][1], hv[i][1], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[i][2], hv[i][0], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[i][0], hv[i][2], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[i][1], hv[i][0], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[i][0], hv[i][1], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[i][0], hv[i][0], acc, 0, 0, 0);
+                        for (int pl = 0; pl < 3; ++pl)
+                            hv[i][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                                hrs, hbase + (unsigned)(pq * 3 + pl) * 1024u, 0, 16));
+                    }
                 }
+                // x . w = sum over the six cross products that matter (mid.lo, lo.mid, lo.lo < 2^-24), small terms first
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {
+                    if (c0 + i < NPW && p0 + c0 + i < p1) {
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[c0 + i][1], hv[i][1], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[c0 + i][2], hv[i][0], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[c0 + i][0], hv[i][2], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[c0 + i][1], hv[i][0], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[c0 + i][0], hv[i][1], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[c0 + i][0], hv[i][0], acc, 0, 0, 0);
+                    }
+                }
+                if (CH < NPW) __builtin_amdgcn_sched_barrier(0);
             }
         }
         PSTAMP(2);   // h load + MFMA chain
@@ -279,24 +287,27 @@ bool launch_kind(const PersistArgs& a, int ny, hipStream_t s, const EvPair& ev) 
     if (a.nz > 1) {
         if (npw <= 4) LAUNCH_P(4, true, false);
         else if (npw <= 7) LAUNCH_P(7, true, false);
+        else if (npw <= 10) LAUNCH_P(10, true, false);
         else return false;
         return true;
     }
     if (npw <= 2) LAUNCH_P(2, false, false);
     else if (npw <= 4) LAUNCH_P(4, false, false);
     else if (npw <= 7) LAUNCH_P(7, false, false);
+    else if (npw <= 10) LAUNCH_P(10, false, false);
     else return false;
     return true;
 }
 
 }  // namespace
 
-// H up to 896 (7 pairs of 16 k per wave): wider layers take the per-step path for now.
+// H up to 1280 (10 pairs of 16 k per wave); every workgroup of a launch must own a CU, so a layer whose
+// two directions do not fit together (H > 1024 on 256 CUs) runs them as two launches, one after the other.
 bool rnn_persist_eligible(const RnnGeom& g, int B, int n_cus) {
     if (g.U != PU || (g.H % 8) != 0) return false;
-    if (ceil_div(ceil_div(g.nq, 2), PNW) > 7) return false;
+    if (ceil_div(ceil_div(g.nq, 2), PNW) > 10) return false;
     if (ceil_div(B, 32) > PMAXZ) return false;
-    return g.nwg * g.D <= n_cus;
+    return g.nwg <= n_cus;
 }
 
 static inline uint16_t bf16_rne(float x) {
@@ -345,11 +356,11 @@ bool launch_rnn_persist(const RnnPersistLaunch& p, hipStream_t s) {
     for (int d = 0; d < 2; ++d) { a.whh3[d] = p.whh3[d]; a.bhh[d] = p.bhh[d]; a.out[d] = p.out[d]; }
     a.xp = p.xp; a.lens = p.lens_dev; a.hpack3 = p.hpack3; a.cnt = p.counters; a.err = p.err; a.dbg = p.dbg;
     a.B = p.B; a.T = p.T; a.G = p.g.G; a.H = p.g.H; a.Hs = p.g.Kp; a.npair = ceil_div(p.g.nq, 2); a.Np = p.g.Np; a.nwg = p.g.nwg;
-    a.nz = ceil_div(p.B, 32); a.d0 = 0; a.nd = p.g.D;
+    a.nz = ceil_div(p.B, 32); a.d0 = p.d0; a.nd = p.g.D;
     switch (p.g.kind) {
-        case DSMI_RNN_GRU: return launch_kind<DSMI_RNN_GRU>(a, p.g.D, s, p.ev);
-        case DSMI_RNN_LSTM: return launch_kind<DSMI_RNN_LSTM>(a, p.g.D, s, p.ev);
-        default: return launch_kind<DSMI_RNN_TANH>(a, p.g.D, s, p.ev);
+        case DSMI_RNN_GRU: return launch_kind<DSMI_RNN_GRU>(a, p.ny, s, p.ev);
+        case DSMI_RNN_LSTM: return launch_kind<DSMI_RNN_LSTM>(a, p.ny, s, p.ev);
+        default: return launch_kind<DSMI_RNN_TANH>(a, p.ny, s, p.ev);
     }
 }
 

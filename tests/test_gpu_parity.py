@@ -213,13 +213,16 @@ def test_features_window_and_pad_variants(native):
     fe.close()
 
 
-def test_wide_layer_takes_per_step_path_vs_oracle(native):
-    """H = 904 > 896: the persistent kernel is not eligible, the per-step fp32-MFMA path runs."""
+@pytest.mark.parametrize("H,why", [(904, "10 k-pairs per wave, h taken in two halves"),
+                                   (1200, "config 4 width: 2 x 150 workgroups > 256 CUs, one launch per direction"),
+                                   (100, "H % 8 != 0: per-step fp32-MFMA fallback"),
+                                   (1288, "H > 1280: per-step fp32-MFMA fallback")])
+def test_wide_and_odd_layers_vs_oracle(native, H, why):
     from oracle import model as om
-    H = 904
     sd = syn.make_state_dict(2, "gru", H, 1, seed=33, fc_gain=4.0)
     cfg = _cfg(2, "gru", H, 1)
     m = native.NativeModel(cfg, sd)
+    m.set_profiling(2)
     lens = np.array([60, 41], dtype=np.int32)
     x = syn.make_features(2, 60, seed=34)
     x[1, :, :, 41:] = 0
@@ -227,6 +230,11 @@ def test_wide_layer_takes_per_step_path_vs_oracle(native):
     ref, ol_ref = om.forward(sd, cfg, x, lens)
     assert np.array_equal(ol, ol_ref)
     np.testing.assert_allclose(p.cpu().numpy(), ref, rtol=0, atol=1e-4)
+    ks = m.kernel_stats()
+    if "fallback" in why:
+        assert ks["rnn_step"]["launches"] == int(ol[0]) and "rnn_layer_persistent" not in ks
+    else:
+        assert ks["rnn_layer_persistent"]["launches"] == (2 if H == 1200 else 1) and "rnn_step" not in ks
     m.close()
 
 

@@ -202,6 +202,12 @@ def main():
                        "clips_per_gpu": B, "clip_seconds": c["seconds"], "parallelism": "utterance-dp%d" % world,
                        "batches_in_flight": P},
             "roofline": roof,
+            # every sampled kernel kind: mean dispatch time and ALGORITHMIC rates (SURVEY 8(d) FLOPs and bytes);
+            # conv1/conv2 are the "conv front end" the north star asks GB/s for (HBM spec 8000 GB/s)
+            "kernels": {k: {"avg_us": round(v["avg_us"], 2), "launches_per_step": v["launches"] // args.steps,
+                            "tflops": round(v["flops_per_launch"] / (v["avg_us"] * 1e-6) / 1e12, 2),
+                            "gbps": round(v["bytes_per_launch"] / (v["avg_us"] * 1e-6) / 1e9, 1)}
+                        for k, v in sorted(stats.items()) if v["samples"] and v["avg_us"] > 0} if stats else None,
             "sample_transcript_len": len(out[0]) if out else None,
         }
         if world == 1 and not args.no_cpu_baseline:

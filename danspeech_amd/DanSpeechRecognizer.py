@@ -106,6 +106,31 @@ class DanSpeechRecognizer(object):
         else:
             return decoded_output[0][0]
 
+    def transcribe_files(self, paths, show_all=False):
+        """``transcribe_batch([load_audio(p) for p in paths])`` without decoding the files on the host:
+        the WAV frames go to the GPU as bytes and ``dsmi_features`` applies ``load_audio``'s sample-width
+        conversion and saturating stereo fold (resources.py:302-303).  Files are grouped by
+        (sample width, channels); every group is one batch."""
+        import torch
+        from .audio.resources import read_wav_frames
+        if len(paths) == 0:
+            return []
+        loaded = [read_wav_frames(p) for p in paths]
+        groups = {}
+        for i, (raw, width, nch) in enumerate(loaded):
+            groups.setdefault((width, nch), []).append(i)
+        res = [None] * len(paths)
+        for (width, nch), idxs in groups.items():
+            idxs = sorted(idxs, key=lambda i: -len(loaded[i][0]))       # stable: longest first
+            feats, frames = self.audio_parser.parse_wav_frames([loaded[i][0] for i in idxs], width, nch)
+            out, output_sizes = self.model(feats, torch.from_numpy(frames.astype(np.int32)))
+            decoded_output, _ = self.decoder.decode(out, output_sizes)
+            for pos, i in enumerate(idxs):
+                res[i] = decoded_output[pos] if show_all else decoded_output[pos][0]
+        if show_all and self.lm == 'greedy':
+            warnings.warn("You are trying to get all beams but no LM has been instantiated.", NoLmInstantiatedWarning)
+        return res
+
     def transcribe_batch(self, recordings, show_all=False):
         """Batched ``transcribe``: clips are sorted by length (pack_padded_sequence's order,
         reference model.py:117), run as ONE batch, and results return in the caller's order."""

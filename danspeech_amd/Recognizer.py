@@ -34,6 +34,10 @@ class Recognizer(object):
         """``recognize`` for a list of clips in one batched pass over the GPU."""
         return self.danspeech_recognizer.transcribe_batch(audio_list, show_all=show_all)
 
+    def recognize_files(self, paths, show_all=False):
+        """``[recognize(load_audio(p)) for p in paths]`` in batched passes, WAV decoding on the GPU."""
+        return self.danspeech_recognizer.transcribe_files(paths, show_all=show_all)
+
     def update_model(self, model):
         self.danspeech_recognizer.update_model(model)
         print("DanSpeech model updated to: {0}".format(model.model_name))

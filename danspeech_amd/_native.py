@@ -280,8 +280,13 @@ class NativeFrontend:
         except Exception:
             pass
 
-    def features(self, pcm_dev, n_samples, t_stride=None):
-        """pcm_dev: 1-D CUDA tensor (int16/float32/float64), clips back to back.
+    PCM_STEREO = 16
+    WAV_WIDTH_DTYPE = {1: 3, 2: 0, 3: 4, 4: 5}       # sample width in bytes -> DSMI_PCM_{U8,I16,I24,I32}
+
+    def features(self, pcm_dev, n_samples, t_stride=None, wav_format=None):
+        """pcm_dev: 1-D CUDA tensor (int16/float32/float64), clips back to back; or, with
+        ``wav_format=(sample_width, channels)``, a uint8 tensor holding the raw frames of PCM WAV
+        files back to back (``n_samples`` then counts frames; stereo is folded on the device).
         -> (feat [B,1,F,t_stride] float32 CUDA, frames int32[B])."""
         import torch
         n_samples = np.ascontiguousarray(n_samples, dtype=np.int64)
@@ -289,7 +294,15 @@ class NativeFrontend:
         frames = 1 + n_samples // self.hop
         if t_stride is None:
             t_stride = int(frames.max())
-        dt = {torch.int16: 0, torch.float32: 1, torch.float64: 2}[pcm_dev.dtype]
+        if wav_format is None:
+            dt = {torch.int16: 0, torch.float32: 1, torch.float64: 2}[pcm_dev.dtype]
+        else:
+            width, channels = wav_format
+            if pcm_dev.dtype != torch.uint8 or width not in self.WAV_WIDTH_DTYPE or channels not in (1, 2):
+                raise ValueError("raw WAV frames: uint8 tensor, sample width 1..4, one or two channels")
+            if int(n_samples.sum()) * width * channels != pcm_dev.numel():
+                raise ValueError("frame counts do not add up to the size of the byte buffer")
+            dt = self.WAV_WIDTH_DTYPE[width] | (self.PCM_STEREO if channels == 2 else 0)
         feat = torch.empty((B, 1, self.n_freq, t_stride), dtype=torch.float32, device=pcm_dev.device)
         fr = np.empty(B, dtype=np.int32)
         rc = lib().dsmi_features(self._h, pcm_dev.data_ptr(), dt, _np_ptr(n_samples), B, feat.data_ptr(),

@@ -47,6 +47,15 @@ class SpectrogramAudioParser(AudioParser):
         pcm = torch.from_numpy(np.concatenate(recs)).to("cuda:%d" % self.device)
         return self._frontend().features(pcm, n)
 
+    def parse_wav_frames(self, raws, width, channels):
+        """Raw PCM WAV frames (``read_wav_frames``; one common sample width / channel count) ->
+        same result as ``parse_batch([load_audio(f) for f in files])`` with the decoding on the GPU."""
+        import torch
+        n = np.array([len(r) // (width * channels) for r in raws], dtype=np.int64)
+        buf = np.frombuffer(b"".join(raws), dtype=np.uint8)
+        pcm = torch.from_numpy(buf.copy()).to("cuda:%d" % self.device)
+        return self._frontend().features(pcm, n, wav_format=(width, channels))
+
     def parse_audio(self, recording):
         feat, frames = self.parse_batch([recording])
         return feat[0, 0, :, :int(frames[0])]

@@ -25,14 +25,18 @@ def _frames_to_int(buf, width):
     raise ValueError("unsupported sample width %d" % width)
 
 
-def load_audio(path, duration=None, offset=None):
-    """PCM WAV -> float64 numpy array ready for ``Recognizer.recognize``."""
+def read_wav_frames(path, duration=None, offset=None):
+    """The byte stream ``load_audio`` decodes, undecoded: (raw frames, sample width, channels).
+
+    Same chunked reading as resources.py:41-57 (4096-frame chunks, optional duration/offset at
+    the pinned 16 kHz).  The bytes can go to the GPU as they are: ``dsmi_features`` decodes the
+    sample width and folds two channels (``Recognizer.recognize_files``)."""
     try:
         reader = wave.open(path, "rb")
     except (wave.Error, EOFError):
         raise ValueError("Audio file could not be read as PCM WAV; AIFF/FLAC decoding is outside this package's scope")
     with reader:
-        nch, width, rate = reader.getnchannels(), reader.getsampwidth(), reader.getframerate()
+        nch, width = reader.getnchannels(), reader.getsampwidth()
         assert 1 <= nch <= 2, "Audio must be mono or stereo"
         chunk = 4096
         seconds_per_buffer = (chunk + 0.0) / 16000      # SpeechFile pins sampling_rate = 16000 (resources.py:192)
@@ -53,13 +57,19 @@ def load_audio(path, duration=None, offset=None):
                 if duration and elapsed_time > duration:
                     break
                 parts.append(buf)
-        data = _frames_to_int(b"".join(parts), width)
-        if nch == 2:
-            if width == 1:
-                raise ValueError("8-bit stereo WAV is not supported")
-            data = data.reshape(-1, 2)
-            lim = 1 << (8 * width - 1)
-            data = np.clip(data[:, 0] + data[:, 1], -lim, lim - 1)     # audioop.tomono(buf, width, 1, 1) saturates
+    if nch == 2 and width == 1:
+        raise ValueError("8-bit stereo WAV is not supported")
+    return b"".join(parts), width, nch
+
+
+def load_audio(path, duration=None, offset=None):
+    """PCM WAV -> float64 numpy array ready for ``Recognizer.recognize``."""
+    raw, width, nch = read_wav_frames(path, duration=duration, offset=offset)
+    data = _frames_to_int(raw, width)
+    if nch == 2:
+        data = data.reshape(-1, 2)
+        lim = 1 << (8 * width - 1)
+        data = np.clip(data[:, 0] + data[:, 1], -lim, lim - 1)     # audioop.tomono(buf, width, 1, 1) saturates
     return data.astype(float)
 
 

@@ -33,7 +33,31 @@ namespace {
 
 constexpr int FT = 8;   // frames per workgroup
 
-template <typename T> __device__ __forceinline__ double ld(const void* p, int64_t i) { return (double)((const T*)p)[i]; }
+// One integer sample of a WAV frame stream (resources.py:551-554 for the 8-bit bias).
+__device__ __forceinline__ int64_t ld_int(const void* p, int base, int64_t i) {
+    switch (base) {
+        case DSMI_PCM_I16: return ((const int16_t*)p)[i];
+        case DSMI_PCM_U8: return (int64_t)((const uint8_t*)p)[i] - 128;
+        case DSMI_PCM_I32: return ((const int32_t*)p)[i];
+        default: {
+            const uint8_t* q = (const uint8_t*)p + 3 * i;
+            const int32_t v = (int32_t)q[0] | ((int32_t)q[1] << 8) | ((int32_t)q[2] << 16);
+            return v >= (1 << 23) ? v - (1 << 24) : v;
+        }
+    }
+}
+
+// Sample i of a clip at its integer scale as float64 (load_audio, resources.py:630-640); two channels fold
+// into the saturating sum of audioop.tomono(buf, width, 1, 1) (resources.py:302-303).
+__device__ __forceinline__ double ld_sample(const void* p, int dtype, int64_t i) {
+    if (dtype == DSMI_PCM_F64) return ((const double*)p)[i];
+    if (dtype == DSMI_PCM_F32) return (double)((const float*)p)[i];
+    const int base = dtype & 15;
+    if (!(dtype & DSMI_PCM_STEREO)) return (double)ld_int(p, base, i);
+    const int64_t lim = base == DSMI_PCM_I16 ? (1ll << 15) : (base == DSMI_PCM_I24 ? (1ll << 23) : (1ll << 31));
+    const int64_t v = ld_int(p, base, 2 * i) + ld_int(p, base, 2 * i + 1);
+    return (double)(v < -lim ? -lim : (v > lim - 1 ? lim - 1 : v));
+}
 
 __global__ __launch_bounds__(256) void stft_logmag_kernel(const void* pcm, int dtype, const int64_t* offs, const int64_t* nsamp,
                                                           const double* tw, const double* win, int n_fft, int hop, int n_freq,
@@ -57,8 +81,7 @@ __global__ __launch_bounds__(256) void stft_logmag_kernel(const void* pcm, int d
             if (s < 0) { if (pad_mode == DSMI_PAD_REFLECT) s = -s; else ok = false; }
             else if (s >= N) { if (pad_mode == DSMI_PAD_REFLECT) s = 2 * (N - 1) - s; else ok = false; }
             if (ok) {
-                v = dtype == DSMI_PCM_I16 ? ld<int16_t>(pcm, off + s) : (dtype == DSMI_PCM_F32 ? ld<float>(pcm, off + s) : ld<double>(pcm, off + s));
-                v *= win[n];
+                v = ld_sample(pcm, dtype, off + s) * win[n];
             }
         }
         s_x[i] = v;
@@ -176,7 +199,11 @@ extern "C" int dsmi_features(dsmi_frontend* m, const void* pcm, int dtype, const
     if (!m) return DSMI_ERR_INVALID;
     auto bad = [&](int code, const char* msg) { m->err = msg; return code; };
     dsmi_frontend* f = m;
-    if (!pcm || !n_samples || !feat || B < 1 || dtype < 0 || dtype > 2) return bad(DSMI_ERR_INVALID, "bad features arguments");
+    const int base = dtype & 15;
+    const bool stereo_ok = base == DSMI_PCM_I16 || base == DSMI_PCM_I24 || base == DSMI_PCM_I32;
+    if (!pcm || !n_samples || !feat || B < 1 || dtype < 0 || base > DSMI_PCM_I32 || (dtype & ~(15 | DSMI_PCM_STEREO)) ||
+        ((dtype & DSMI_PCM_STEREO) && !stereo_ok))
+        return bad(DSMI_ERR_INVALID, "bad features arguments (8-bit and float PCM cannot be stereo)");
     hipStream_t s = (hipStream_t)stream;
     if (hipSetDevice(m->device) != hipSuccess) return bad(DSMI_ERR_HIP, "hipSetDevice failed");
     std::vector<int64_t> host(2 * (size_t)B);

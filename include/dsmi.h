@@ -50,7 +50,13 @@ typedef enum {
 
 enum { DSMI_RNN_GRU = 0, DSMI_RNN_LSTM = 1, DSMI_RNN_TANH = 2 };
 enum { DSMI_WIN_HAMMING = 0, DSMI_WIN_HANN = 1, DSMI_WIN_BLACKMAN = 2, DSMI_WIN_BARTLETT = 3 };
-enum { DSMI_PCM_I16 = 0, DSMI_PCM_F32 = 1, DSMI_PCM_F64 = 2 };
+/* Sample formats of dsmi_features.  The last three and DSMI_PCM_STEREO are the raw frames of a PCM WAV
+ * file as danspeech.audio.load_audio reads them (resources.py:22-61): little-endian, unsigned 8-bit
+ * biased by 128 (resources.py:551-554), and for two channels interleaved L,R frames folded on the
+ * device into the SATURATING sum L+R of audioop.tomono(buf, width, 1, 1) (resources.py:302-303).
+ * OR DSMI_PCM_STEREO into I16 / I24 / I32; sample counts and offsets are then in frames. */
+enum { DSMI_PCM_I16 = 0, DSMI_PCM_F32 = 1, DSMI_PCM_F64 = 2, DSMI_PCM_U8 = 3, DSMI_PCM_I24 = 4, DSMI_PCM_I32 = 5,
+       DSMI_PCM_STEREO = 16 };
 enum { DSMI_PAD_REFLECT = 0, DSMI_PAD_CONSTANT = 1 };
 
 /* Mirrors the arguments of DeepSpeech.__init__ (model.py:293-294) plus audio_conf
@@ -102,7 +108,8 @@ int dsmi_seq_lens(const dsmi_model* m, const int32_t* lens_host, int n, int32_t*
 
 /* ---- SpectrogramAudioParser (parsers.py:37-72), batched.
  * pcm_dev: B clips back to back, clip b has n_samples_host[b] samples starting at
- * sample offset sum(n_samples_host[:b]); dtype DSMI_PCM_*.
+ * sample offset sum(n_samples_host[:b]); dtype DSMI_PCM_* (float arrays as load_audio returns
+ * them, or a WAV file's raw frames: the file never has to be decoded on the host).
  * feat_dev: [B][n_freq][t_stride] float32, frames past a clip's own count are zero.
  * frames_host[b] = 1 + n_samples[b] / hop.  Asynchronous on `stream`. */
 int dsmi_frontend_create(const dsmi_frontend_desc* desc, int device, dsmi_frontend** out);

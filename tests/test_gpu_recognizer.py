@@ -119,3 +119,66 @@ def test_decoders_standalone_api(golden):
     strings, offsets = b.decode(torch.from_numpy(g["probs"]), torch.from_numpy(g["sizes"]))
     assert len(strings) == g["probs"].shape[0] and all(len(s) == 8 for s in strings)
     assert strings[0][0] == str(g["strings"][0])      # peaky probabilities: best beam = greedy path
+
+
+# ---- the audio front door on the device ---------------------------------------
+
+def _wav_bytes(samples, width):
+    """Little-endian frames of the given sample width from int64 sample values (interleaved if 2-D)."""
+    v = np.asarray(samples, dtype=np.int64).reshape(-1)
+    if width == 1:
+        return (v + 128).astype(np.uint8).tobytes()
+    if width == 2:
+        return v.astype("<i2").tobytes()
+    if width == 4:
+        return v.astype("<i4").tobytes()
+    u = (v & 0xFFFFFF).astype(np.uint32)
+    return np.stack([u & 255, (u >> 8) & 255, (u >> 16) & 255], axis=1).astype(np.uint8).tobytes()
+
+
+@pytest.mark.parametrize("width,channels", [(1, 1), (2, 1), (2, 2), (3, 1), (3, 2), (4, 1), (4, 2)])
+def test_raw_wav_frames_decoded_on_device_equal_host_load_audio(width, channels):
+    """dsmi_features on a file's raw frames == dsmi_features on load_audio's float64 output, bit for bit
+    (same STFT kernel; only the sample decode and the saturating L+R fold move to the GPU)."""
+    from danspeech_amd import _native
+    from danspeech_amd.audio.resources import _frames_to_int
+    rng = np.random.default_rng(50 + 10 * width + channels)
+    lim = 1 << (8 * width - 1)
+    raws, refs, n = [], [], []
+    for frames in (4000, 1777):
+        v = rng.integers(-lim, lim, size=(frames, channels))
+        v[:50] = lim - 1          # L+R overflows: the fold must saturate, both ways
+        v[50:100] = -lim
+        raw = _wav_bytes(v, width)
+        d = _frames_to_int(raw, width)
+        if channels == 2:
+            d = d.reshape(-1, 2)
+            d = np.clip(d[:, 0] + d[:, 1], -lim, lim - 1)
+        raws.append(raw); refs.append(d.astype(np.float64)); n.append(frames)
+    fe = _native.NativeFrontend()
+    n = np.array(n, dtype=np.int64)
+    a, fa = fe.features(torch.from_numpy(np.frombuffer(b"".join(raws), dtype=np.uint8).copy()).cuda(), n, wav_format=(width, channels))
+    b, fb = fe.features(torch.from_numpy(np.concatenate(refs)).cuda(), n)
+    assert np.array_equal(fa, fb)
+    assert torch.equal(a, b)
+    fe.close()
+
+
+def test_recognize_files_equals_recognize_of_load_audio():
+    """Config 1 through the device front door: the stereo example file's frames go to the GPU undecoded."""
+    from danspeech_amd import Recognizer
+    from danspeech_amd.audio import load_audio
+    m, sd, cfg = _model("frontdoor", 64, 2, seed=71)
+    rec = Recognizer(model=m)
+    want = rec.recognize(load_audio(WAV))
+    got = rec.recognize_files([WAV, WAV])
+    assert got == [want, want] and isinstance(want, str)
+    with pytest.raises(_feature_error()):
+        from danspeech_amd import _native
+        fe = _native.NativeFrontend()
+        fe.features(torch.zeros(8, dtype=torch.uint8).cuda(), np.array([4], dtype=np.int64), wav_format=(1, 2))
+
+
+def _feature_error():
+    from danspeech_amd import _native
+    return (ValueError, _native.DsmiError)

@@ -106,6 +106,33 @@ class DanSpeechRecognizer(object):
         else:
             return decoded_output[0][0]
 
+    def transcribe_long(self, recording, energy_threshold=600, step=1024, pause_threshold=0.55, phrase_threshold=0.2,
+                        max_batch=32, show_all=False):
+        """Long-form transcription: the energy gate of the reference's
+        example_scripts/video_transcribe_simulation.py:68-143 cuts the recording into phrases
+        (``dsmi_segment``: hop energies on the GPU), the phrases are transcribed in batches of at most
+        ``max_batch`` (longest first), and ``[(start_sample, end_sample, transcription), ...]`` comes back
+        in time order.  The recording is uploaded once; phrases are sliced on the device."""
+        import torch
+        parser = self.audio_parser
+        pcm = torch.from_numpy(np.ascontiguousarray(recording, dtype=np.float64)).to("cuda:%d" % parser.device)
+        hop_seconds = step / float(parser.sampling_rate)
+        segs = parser._frontend().segment(pcm, energy_threshold=energy_threshold, step=step,
+                                          pause_hops=int(np.ceil(pause_threshold / hop_seconds)),
+                                          phrase_hops=int(np.ceil(phrase_threshold / hop_seconds)))
+        res = [None] * len(segs)
+        order = sorted(range(len(segs)), key=lambda i: -(int(segs[i][1]) - int(segs[i][0])))
+        for k in range(0, len(order), max_batch):
+            idxs = order[k:k + max_batch]
+            n = np.array([int(segs[i][1] - segs[i][0]) for i in idxs], dtype=np.int64)
+            cat = torch.cat([pcm[int(segs[i][0]):int(segs[i][1])] for i in idxs])
+            feats, frames = parser._frontend().features(cat, n)
+            out, output_sizes = self.model(feats, torch.from_numpy(frames.astype(np.int32)))
+            decoded_output, _ = self.decoder.decode(out, output_sizes)
+            for pos, i in enumerate(idxs):
+                res[i] = (int(segs[i][0]), int(segs[i][1]), decoded_output[pos] if show_all else decoded_output[pos][0])
+        return res
+
     def transcribe_files(self, paths, show_all=False):
         """``transcribe_batch([load_audio(p) for p in paths])`` without decoding the files on the host:
         the WAV frames go to the GPU as bytes and ``dsmi_features`` applies ``load_audio``'s sample-width

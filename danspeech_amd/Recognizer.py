@@ -34,6 +34,15 @@ class Recognizer(object):
         """``recognize`` for a list of clips in one batched pass over the GPU."""
         return self.danspeech_recognizer.transcribe_batch(audio_list, show_all=show_all)
 
+    def recognize_long(self, audio_data, energy_threshold=600, step=1024, pause_threshold=0.55, phrase_threshold=0.2,
+                       max_batch=32, show_all=False):
+        """Segment a long recording with the reference example's energy gate
+        (example_scripts/video_transcribe_simulation.py:68-143) and transcribe the phrases in batches:
+        ``[(start_sample, end_sample, transcription), ...]`` in time order."""
+        return self.danspeech_recognizer.transcribe_long(audio_data, energy_threshold=energy_threshold, step=step,
+                                                         pause_threshold=pause_threshold, phrase_threshold=phrase_threshold,
+                                                         max_batch=max_batch, show_all=show_all)
+
     def recognize_files(self, paths, show_all=False):
         """``[recognize(load_audio(p)) for p in paths]`` in batched passes, WAV decoding on the GPU."""
         return self.danspeech_recognizer.transcribe_files(paths, show_all=show_all)

@@ -68,6 +68,8 @@ _PROTOS = {
     "dsmi_frontend_destroy": (None, [_vp]),
     "dsmi_frontend_last_error": (C.c_char_p, [_vp]),
     "dsmi_features": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _vp]),
+    "dsmi_segment": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, C.c_int, C.c_double, C.c_int, C.c_int, _vp, _vp, C.c_int,
+                               C.POINTER(C.c_int), _vp, _vp]),
     "dsmi_decoder_create": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.c_int, C.c_int, C.POINTER(_vp)]),
     "dsmi_decoder_destroy": (None, [_vp]),
     "dsmi_decoder_last_error": (C.c_char_p, [_vp]),
@@ -310,6 +312,34 @@ class NativeFrontend:
         if rc != 0:
             raise DsmiError(rc, (lib().dsmi_frontend_last_error(self._h) or b"").decode())
         return feat, fr
+
+
+def _segment(self, pcm_dev, energy_threshold=600, step=1024, pause_hops=9, phrase_hops=4, wav_format=None,
+             max_segments=None, return_energies=False):
+    """dsmi_segment over ONE recording resident on the GPU -> int64 [n,2] sample ranges [start, end)
+    (and the float64 hop energies)."""
+    import torch
+    if wav_format is None:
+        dt = {torch.int16: 0, torch.float32: 1, torch.float64: 2}[pcm_dev.dtype]
+        n = pcm_dev.numel()
+    else:
+        width, channels = wav_format
+        dt = self.WAV_WIDTH_DTYPE[width] | (self.PCM_STEREO if channels == 2 else 0)
+        n = pcm_dev.numel() // (width * channels)
+    nhops = max((n - 1) // step, 0) if n > step else 0
+    cap = int(max_segments) if max_segments is not None else nhops // 2 + 1
+    st = np.zeros(max(cap, 1), dtype=np.int64); en = np.zeros(max(cap, 1), dtype=np.int64)
+    e = np.zeros(max(nhops, 1), dtype=np.float64)
+    found = C.c_int(0)
+    rc = lib().dsmi_segment(self._h, pcm_dev.data_ptr(), dt, n, int(step), float(energy_threshold), int(pause_hops),
+                            int(phrase_hops), _np_ptr(st), _np_ptr(en), cap, C.byref(found), _np_ptr(e), _stream())
+    if rc != 0:
+        raise DsmiError(rc, (lib().dsmi_frontend_last_error(self._h) or b"").decode())
+    seg = np.stack([st[:found.value], en[:found.value]], axis=1)
+    return (seg, e[:nhops]) if return_energies else seg
+
+
+NativeFrontend.segment = _segment
 
 
 class NativeDecoder:

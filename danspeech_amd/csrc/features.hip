@@ -144,7 +144,100 @@ __global__ __launch_bounds__(1024) void normalize_kernel(float* feat, const int6
     }
 }
 
+// Hop energies for dsmi_segment: one wave per hop.  numpy sums a contiguous float64 array pairwise:
+// blocks of 128 elements, each with 8 strided accumulators combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)),
+// blocks combined by halving.  Lane = block*8 + accumulator reproduces that order for step = 128 * 2^k
+// (k <= 3 in one pass; longer hops loop over groups of 8 blocks and finish the tree in lane 0's registers).
+__global__ __launch_bounds__(256) void hop_energy_kernel(const void* pcm, int dtype, int64_t nhops, int step, double* energy) {
+    const int lane = threadIdx.x & 63;
+    const int64_t hop = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (hop >= nhops) return;
+    const int nblk = step / 128;                 // power of two
+    const int blk = lane >> 3, acc = lane & 7;
+    double part[8];                              // sums of groups of 8 blocks (step <= 8192)
+    int ngroups = 0;
+    for (int g0 = 0; g0 < nblk; g0 += 8, ++ngroups) {
+        double r = 0.0;
+        if (g0 + blk < nblk) {
+            const int64_t base = hop * step + (int64_t)(g0 + blk) * 128 + acc;
+            const double x0 = ld_sample(pcm, dtype, base);
+            r = __dmul_rn(x0, x0);
+            for (int j = 1; j < 16; ++j) {
+                const double x = ld_sample(pcm, dtype, base + 8 * j);
+                r = __dadd_rn(r, __dmul_rn(x, x));
+            }
+        }
+        // accumulators of a block, then blocks pairwise (a + b == b + a exactly, so xor-shuffles keep the tree)
+        for (int o = 1; o < 64; o <<= 1) {
+            if (o >= 8 && (o >> 3) >= nblk) break;
+            r = __dadd_rn(r, __shfl_xor(r, o, 64));
+        }
+        part[ngroups] = r;
+    }
+    for (int n = ngroups; n > 1; n >>= 1)
+        for (int i = 0; i < n / 2; ++i) part[i] = __dadd_rn(part[2 * i], part[2 * i + 1]);
+    if (lane == 0) energy[hop] = sqrt(part[0] / (double)step);
+}
+
 }  // namespace
+
+extern "C" int dsmi_segment(dsmi_frontend* f, const void* pcm, int dtype, int64_t n_samples, int step, double energy_threshold,
+                            int pause_hops, int phrase_hops, int64_t* seg_start, int64_t* seg_end, int max_segments,
+                            int* n_segments, double* energies_host, void* stream) {
+    if (!f) return DSMI_ERR_INVALID;
+    auto bad = [&](int code, const char* msg) { f->err = msg; return code; };
+    const int base = dtype & 15;
+    const bool stereo_ok = base == DSMI_PCM_I16 || base == DSMI_PCM_I24 || base == DSMI_PCM_I32;
+    if (!pcm || !seg_start || !seg_end || !n_segments || max_segments < 0 || n_samples < 0 || dtype < 0 || base > DSMI_PCM_I32 ||
+        (dtype & ~(15 | DSMI_PCM_STEREO)) || ((dtype & DSMI_PCM_STEREO) && !stereo_ok))
+        return bad(DSMI_ERR_INVALID, "bad segment arguments");
+    if (step < 128 || step > 8192 || (step & (step - 1)) != 0) return bad(DSMI_ERR_INVALID, "step must be 128 * 2^k, at most 8192");
+    if (hipSetDevice(f->device) != hipSuccess) return bad(DSMI_ERR_HIP, "hipSetDevice failed");
+    hipStream_t s = (hipStream_t)stream;
+    *n_segments = 0;
+    // hops i with i*step + step < n_samples  (video_transcribe_simulation.py:94)
+    const int64_t nhops = n_samples > step ? (n_samples - 1) / step : 0;
+    if (nhops == 0) return DSMI_OK;
+    double* e_dev = nullptr;
+    if (hipMalloc((void**)&e_dev, sizeof(double) * nhops) != hipSuccess) return bad(DSMI_ERR_NOMEM, "hipMalloc failed");
+    hipLaunchKernelGGL(hop_energy_kernel, dim3((unsigned)((nhops + 3) / 4)), dim3(256), 0, s, pcm, dtype, nhops, step, e_dev);
+    std::vector<double> e(nhops);
+    const bool ok = hipMemcpyAsync(e.data(), e_dev, sizeof(double) * nhops, hipMemcpyDeviceToHost, s) == hipSuccess &&
+                    hipStreamSynchronize(s) == hipSuccess && hipGetLastError() == hipSuccess;
+    (void)hipFree(e_dev);
+    if (!ok) return bad(DSMI_ERR_HIP, "hop energy kernel failed");
+    if (energies_host) std::copy(e.begin(), e.end(), energies_host);
+    // ---- the script's state machine (:84-143), one pass over the hop energies
+    bool is_speaking = false;
+    int64_t frames_counter = 0, pause_count = 0, start_index = 0, iterator = 0;
+    int found = 0;
+    for (int64_t i = 0; i < nhops; ++i) {
+        const double energy = e[i];
+        if (energy > energy_threshold && !is_speaking) {
+            is_speaking = true;
+            start_index = iterator - 2 * (int64_t)step;
+            if (start_index < 0) start_index = iterator;
+        }
+        iterator += step;
+        if (is_speaking) {
+            ++frames_counter;
+            if (energy > energy_threshold) pause_count = 0;
+            else ++pause_count;
+        }
+        if (pause_count > pause_hops && is_speaking) {
+            if (frames_counter - pause_count > phrase_hops) {
+                if (found < max_segments) { seg_start[found] = start_index; seg_end[found] = iterator; }
+                ++found;
+            }
+            is_speaking = false;
+            frames_counter = 0;
+            pause_count = 0;
+        }
+    }
+    *n_segments = found;
+    if (found > max_segments) return bad(DSMI_ERR_CAPACITY, "more phrases than max_segments");
+    return DSMI_OK;
+}
 
 extern "C" int dsmi_frontend_create(const dsmi_frontend_desc* d, int device, dsmi_frontend** out) {
     if (!d || !out) { g_fe_error = "null argument"; return DSMI_ERR_INVALID; }

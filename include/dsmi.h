@@ -118,6 +118,22 @@ const char* dsmi_frontend_last_error(const dsmi_frontend* f);
 int dsmi_features(dsmi_frontend* f, const void* pcm_dev, int pcm_dtype, const int64_t* n_samples_host,
                   int B, float* feat_dev, int t_stride, int32_t* frames_host, void* stream);
 
+/* ---- Offline long-form segmentation: the energy gate of
+ * example_scripts/video_transcribe_simulation.py:68-143 over one recording.
+ * Hop i covers samples [i*step, (i+1)*step) for every i with (i+1)*step < n_samples (:94); its energy is
+ * sqrt(sum(x*x)/step) in float64 (:100), summed in numpy's pairwise order so that comparisons with
+ * energy_threshold fall exactly as they do in the script.  A phrase starts at the first hop above the
+ * threshold, two hops early when that is not negative (:103-113), ends once more than pause_hops
+ * consecutive hops stay at or below it (:119-128), and is reported when it held more than phrase_hops
+ * hops apart from that pause (:131-132).  A phrase still open at the end of the audio is dropped, as in
+ * the script.  step must be 128 * 2^k.  seg_start/seg_end_host[max_segments] receive sample ranges
+ * [start, end); *n_segments the number found (DSMI_ERR_CAPACITY if more than max_segments).
+ * energies_host (optional, one float64 per hop) receives the hop energies.  Synchronous. */
+int dsmi_segment(dsmi_frontend* f, const void* pcm_dev, int pcm_dtype, int64_t n_samples, int step,
+                 double energy_threshold, int pause_hops, int phrase_hops,
+                 int64_t* seg_start_host, int64_t* seg_end_host, int max_segments, int* n_segments,
+                 double* energies_host, void* stream);
+
 /* ---- DeepSpeech.forward (model.py:496-515), eval mode.
  * feat_dev [B][1][n_freq][T] float32 (T = max frames, zero past each clip's length),
  * lens_host[B] sorted descending.  probs_dev [B][T_out][n_labels] float32 softmax

@@ -182,3 +182,62 @@ def test_recognize_files_equals_recognize_of_load_audio():
 def _feature_error():
     from danspeech_amd import _native
     return (ValueError, _native.DsmiError)
+
+
+# ---- offline long-form segmentation --------------------------------------------
+
+def _long_recording(seconds=50, seed=90):
+    """Noise floor well under the gate with speech-like bursts of various lengths, some shorter than
+    the phrase threshold, some separated by pauses shorter than the pause threshold, one at t=0 and one
+    running into the end of the recording (dropped, as in the script)."""
+    rng = np.random.default_rng(seed)
+    n = seconds * 16000
+    x = rng.normal(0, 60, n)
+    t = 0
+    spans = [(0, 9000)]
+    t = 30000
+    while t < n - 40000:
+        dur = int(rng.choice([1500, 4000, 12000, 30000, 70000]))
+        spans.append((t, t + dur))
+        t += dur + int(rng.choice([3000, 7000, 12000, 25000]))
+    spans.append((n - 9000, n))
+    for a, b in spans:
+        b = min(b, n)
+        x[a:b] += rng.normal(0, 2500, b - a)
+    return np.round(x)
+
+
+@pytest.mark.parametrize("step", [1024, 512, 2048])
+def test_segmentation_equals_the_script_restatement(step):
+    from danspeech_amd import _native
+    from oracle import segmentation as oseg
+    audio = _long_recording()
+    want, e_want = oseg.segment(audio, energy_threshold=600, step=step)
+    fe = _native.NativeFrontend()
+    hop_s = step / 16000.0
+    kw = dict(energy_threshold=600, step=step, pause_hops=int(np.ceil(0.55 / hop_s)), phrase_hops=int(np.ceil(0.2 / hop_s)))
+    got, e_got = fe.segment(torch.from_numpy(audio).cuda(), return_energies=True, **kw)
+    assert np.array_equal(e_got, e_want)                      # bit-exact: numpy's summation order is reproduced
+    assert len(want) >= 3 and [tuple(int(v) for v in r) for r in got] == want
+    # int16 samples on the device give the same phrases
+    got16 = fe.segment(torch.from_numpy(audio.astype(np.int16)).cuda(), **kw)
+    assert np.array_equal(got16, got)
+    # degenerate inputs: shorter than one hop, and silence
+    assert len(fe.segment(torch.zeros(step, dtype=torch.float64).cuda(), **kw)) == 0
+    assert len(fe.segment(torch.zeros(40 * step, dtype=torch.float64).cuda(), **kw)) == 0
+    with pytest.raises(_native.DsmiError):
+        fe.segment(torch.from_numpy(audio).cuda(), step=1000)
+    fe.close()
+
+
+def test_recognize_long_equals_per_phrase_recognize():
+    from danspeech_amd import Recognizer
+    from oracle import segmentation as oseg
+    audio = _long_recording(seconds=30, seed=91)
+    m, sd, cfg = _model("longform", 64, 2, seed=72)
+    rec = Recognizer(model=m)
+    got = rec.recognize_long(audio, max_batch=3)
+    want_segs, _ = oseg.segment(audio)
+    assert [(a, b) for a, b, _ in got] == want_segs and len(got) >= 3
+    for a, b, text in got:
+        assert text == rec.recognize(audio[a:b])

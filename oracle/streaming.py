@@ -1,0 +1,184 @@
+"""numpy restatement of the reference's chunked unidirectional inference (TEST INFRASTRUCTURE ONLY).
+
+Follows, line by line:
+
+* ``MaskConvStream.forward``     reference danspeech/deepspeech/model.py:171-201
+* ``BatchRNNStream.forward``     model.py:219-238
+* ``LookaheadStream.forward``    model.py:256-283
+* ``streaming_forward``          model.py:517-537
+* ``InferenceSpectrogramAudioParser.parse_audio / reset``   danspeech/audio/parsers.py:102-170
+* ``DanSpeechRecognizer.streaming_transcribe``              danspeech/DanSpeechRecognizer.py:144-216
+
+Pinned by tests/golden/g8_streaming.npz (the reference's own streaming model run on seeded weights and
+chunked seeded features, tools/gen_golden.py g8).  The parser's STFT is librosa's (absent here): the
+restatement follows librosa.stft(center=False) semantics and is unpinned like oracle/features.py.
+Only 2-conv streaming models exist in the reference: streaming_init sizes the first RNN layer for two
+conv layers whatever ``conv_layers`` says (model.py:476-484) and builds a plain MaskConv for one.
+"""
+import numpy as np
+
+from danspeech_amd.synthetic import CONV_SPECS
+from . import model as om
+
+
+class StreamingModel(object):
+    """State + forward of a DeepSpeech built with streaming_inference_model=True."""
+
+    def __init__(self, sd, cfg):
+        assert cfg["conv_layers"] == 2 and not cfg["bidirectional"]
+        self.sd, self.cfg = sd, cfg
+        self.reset()
+
+    def reset(self):
+        self.left = [None, None]                  # MaskConvStream.left_1 / left_2
+        self.hidden = [None] * self.cfg["rnn_layers"]
+        self.la_buf = None                        # LookaheadStream.hidden_states_buffer
+
+    # model.py:171-201
+    def _conv(self, x, is_first, is_last):
+        sd = self.sd
+        for li in range(2):
+            _, _, _, _, sf, st, pf, pt = CONV_SPECS[li]
+            if is_first:
+                x = np.concatenate([np.zeros(x.shape[:3] + (5,), np.float32), x], axis=3)
+            elif is_last:
+                x = np.concatenate([x, np.zeros(x.shape[:3] + (5,), np.float32)], axis=3)
+            if not is_first:
+                x = np.concatenate([self.left[li], x], axis=3)
+            if not is_last:
+                self.left[li] = x[:, :, :, -10:].copy()
+            x = om.conv2d(x, sd["conv.seq_module.%d.weight" % (3 * li)], sd["conv.seq_module.%d.bias" % (3 * li)], (sf, st), (pf, pt))
+            a, b = om._bn_affine(sd, "conv.seq_module.%d" % (3 * li + 1))
+            x = x * a.reshape(1, -1, 1, 1) + b.reshape(1, -1, 1, 1)
+            x = np.clip(x, np.float32(0), np.float32(20)).astype(np.float32)
+        return x
+
+    # model.py:219-238 with torch.nn.{GRU,LSTM,RNN} cell math (oracle/model.py rnn_direction), carried state
+    def _rnn(self, l, x, is_last):
+        sd, kind = self.sd, self.cfg["rnn_type"]
+        if l > 0:
+            a, b = om._bn_affine(sd, "rnns.%d.batch_norm.module" % l)
+            x = (x * a + b).astype(np.float32)
+        p = "rnns.%d.rnn." % l
+        w_ih, w_hh, b_ih, b_hh = sd[p + "weight_ih_l0"], sd[p + "weight_hh_l0"], sd[p + "bias_ih_l0"], sd[p + "bias_hh_l0"]
+        T, B, _ = x.shape
+        H = w_hh.shape[1]
+        h, c = self.hidden[l] if self.hidden[l] is not None else (np.zeros((B, H), np.float32), np.zeros((B, H), np.float32))
+        gi_all = (x.reshape(T * B, -1) @ w_ih.T + b_ih).reshape(T, B, -1).astype(np.float32)
+        out = np.zeros((T, B, H), np.float32)
+        for t in range(T):
+            gi = gi_all[t]
+            gh = (h @ w_hh.T + b_hh).astype(np.float32)
+            if kind == "gru":
+                r = om._sigmoid(gi[:, :H] + gh[:, :H])
+                z = om._sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+                n = np.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:]).astype(np.float32)
+                h = ((np.float32(1) - z) * n + z * h).astype(np.float32)
+            elif kind == "lstm":
+                g = gi + gh
+                i_ = om._sigmoid(g[:, :H]); f_ = om._sigmoid(g[:, H:2 * H])
+                g_ = np.tanh(g[:, 2 * H:3 * H]).astype(np.float32); o_ = om._sigmoid(g[:, 3 * H:])
+                c = (f_ * c + i_ * g_).astype(np.float32)
+                h = (o_ * np.tanh(c)).astype(np.float32)
+            else:
+                h = np.tanh(gi + gh).astype(np.float32)
+            out[t] = h
+        self.hidden[l] = None if is_last else (h, c)
+        return out
+
+    # model.py:256-283
+    def _lookahead(self, x, is_last, is_first):
+        ctx = self.cfg["context"]
+        if self.la_buf is None or is_first:
+            self.la_buf = x
+            return None
+        out = np.concatenate([self.la_buf, x], axis=0)
+        self.la_buf = x[-(ctx - 1):]
+        n_out = out.shape[0] if is_last else out.shape[0] - (ctx - 1)
+        if n_out < 1:
+            raise RuntimeError("Calculated padded input size per channel is smaller than the kernel size")
+        if is_last:
+            out = np.concatenate([out, np.zeros((ctx - 1,) + out.shape[1:], np.float32)], axis=0)
+        key = "lookahead.conv.weight" if "lookahead.conv.weight" in self.sd else "lookahead.0.conv.weight"
+        w = self.sd[key][:, 0, :]
+        y = np.zeros((n_out,) + out.shape[1:], np.float32)
+        for k in range(ctx):
+            y += out[k:k + n_out] * w[:, k]
+        if is_last:
+            self.la_buf = None
+        return np.clip(y, np.float32(0), np.float32(20)).astype(np.float32)
+
+    # model.py:517-537
+    def forward(self, x, is_first, is_last):
+        """x [1,1,F,T] float32 -> probs [1,T_out,C] float32, or None while the lookahead is buffering."""
+        y = self._conv(x.astype(np.float32), is_first, is_last)
+        B, C, F, T = y.shape
+        y = y.reshape(B, C * F, T).transpose(2, 0, 1).copy()
+        for l in range(self.cfg["rnn_layers"]):
+            y = self._rnn(l, y, is_last)
+        y = self._lookahead(y, is_last, is_first)
+        if y is None:
+            return None
+        a, b = om._bn_affine(self.sd, "fc.0.module.0")
+        y = (y * a + b).astype(np.float32)
+        T = y.shape[0]
+        logits = (y.reshape(T * B, -1) @ self.sd["fc.0.module.1.weight"].T).reshape(T, B, -1).transpose(1, 0, 2)
+        return om.softmax(logits.astype(np.float32))
+
+
+class StreamingParser(object):
+    """InferenceSpectrogramAudioParser (parsers.py:75-170)."""
+
+    DATASET_MEAN = 5.492418704733003        # parsers.py:89-90 ("estimated from the NST dataset")
+    DATASET_STD = 1.7552755216970917
+    ALPHA_INCREMENT = 0.1                   # parsers.py:94
+
+    def __init__(self, sampling_rate=16000, window_size=0.02, window_stride=0.01):
+        self.n_fft = int(sampling_rate * window_size)
+        self.hop = int(sampling_rate * window_stride)
+        n = self.n_fft
+        self.window = (0.54 - 0.46 * np.cos(2 * np.pi * np.arange(n) / (n - 1))).astype(np.float64)   # symmetric hamming
+        self.reset()
+
+    def reset(self):
+        self.buffer = None
+        self.input_mean = 0
+        self.input_std = 0
+        self.alpha = 0
+
+    def frames(self, part):
+        """The framing half of parse_audio (parsers.py:112-133): -> samples that go through the STFT."""
+        part = np.asarray(part, dtype=np.float64)
+        if self.buffer is not None:
+            part = np.concatenate((self.buffer, part), axis=None)
+        extra = len(part) % self.hop
+        extra_arr = None
+        if extra != 0:
+            extra_arr = part[-extra:]
+            part = part[:-extra]
+        self.buffer = part[-self.hop:]
+        if extra != 0:
+            self.buffer = np.concatenate((self.buffer, extra_arr), axis=None)
+        return part
+
+    def parse_audio(self, part, is_last=False):
+        if is_last and len(part) < self.n_fft:
+            self.reset()
+            return []
+        y = self.frames(part)
+        nfr = 1 + (len(y) - self.n_fft) // self.hop                    # librosa.stft(center=False)
+        idx = np.arange(self.n_fft)[None, :] + self.hop * np.arange(nfr)[:, None]
+        D = np.fft.rfft(y[idx] * self.window, axis=1).T.astype(np.complex64)
+        spect = np.log1p(np.abs(D).astype(np.float32))
+        self.alpha += self.ALPHA_INCREMENT
+        self.input_mean = (self.input_mean + np.mean(spect)) / 2
+        self.input_std = (self.input_std + np.std(spect)) / 2
+        if self.alpha < 1.0:
+            mean = self.input_mean * self.alpha + (1 - self.alpha) * self.DATASET_MEAN
+            std = self.input_std * self.alpha + (1 - self.alpha) * self.DATASET_STD
+        else:
+            mean = self.input_mean
+            std = self.input_std
+        spect -= mean
+        spect /= std
+        return spect

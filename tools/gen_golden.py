@@ -228,9 +228,45 @@ def g6_audio():
     print("load_audio:", len(y), y.min(), y.max(), y.dtype)
 
 
+def stream_state_dict(sd):
+    """synthetic (non-streaming unidirectional) names -> the streaming model's: LookaheadStream is a
+    direct attribute (model.py:490), not the first module of a Sequential (model.py:407-411)."""
+    return {("lookahead.conv.weight" if k == "lookahead.0.conv.weight" else k): v for k, v in sd.items()}
+
+
+def g8_streaming():
+    """DeepSpeech(streaming_inference_model=True).streaming_forward (model.py:517-537) over chunked
+    feature streams: MaskConvStream / BatchRNNStream / LookaheadStream carried state, first pass without
+    output, last pass with the right padding, and a second utterance on the same model (state reset)."""
+    out = {}
+    # only 2-conv streaming models work in the reference: streaming_init sizes the first RNN for two conv
+    # layers whatever conv_layers says (model.py:476-484), and the 1-conv branch builds a plain MaskConv
+    cases = [("gru", 2, [86, 39, 39, 52, 25]), ("lstm", 2, [70, 45, 40]), ("rnn", 2, [64, 41])]
+    for kind, cl, chunks in cases:
+        H, L, ctx = 32, 3, 6
+        tag = "%s_c%d" % (kind, cl)
+        sd = syn.make_state_dict(cl, kind, H, L, bidirectional=False, context=ctx, seed=81, fc_gain=4.0)
+        m = DeepSpeech("golden-stream", rnn_type=supported_rnns[kind], rnn_hidden_size=H, rnn_layers=L,
+                       bidirectional=False, context=ctx, conv_layers=cl, streaming_inference_model=True)
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in stream_state_dict(sd).items()})
+        m.eval()
+        for utt in range(2):                      # the second utterance checks that is_last resets every state
+            for ci, T in enumerate(chunks):
+                x = syn.make_features(1, T, seed=8100 + 100 * utt + ci)
+                with torch.no_grad():
+                    y = m(torch.from_numpy(x), ci == 0, ci == len(chunks) - 1)
+                key = "%s_u%d_k%d" % (tag, utt, ci)
+                out["probs_" + key] = np.zeros((0,), np.float32) if y is None else y.numpy()[0]
+        out["chunks_" + tag] = np.array(chunks, dtype=np.int32)
+    save("g8_streaming", **out)
+    for k in sorted(out):
+        if k.startswith("probs_gru_c2_u0"):
+            print(k, out[k].shape)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4s", "g4f", "g5", "g6"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4s", "g4f", "g5", "g6", "g8"]
     fns = dict(g1=g1_seq_lens, g2=g2_conv, g3=g3_batch_rnn, g4s=g4_forward_small,
-               g4f=g4_forward_full, g5=g5_greedy, g6=g6_audio)
+               g4f=g4_forward_full, g5=g5_greedy, g6=g6_audio, g8=g8_streaming)
     for w in which:
         fns[w]()

@@ -21,6 +21,7 @@ PAD_MODES = {"reflect": 0, "constant": 1}
 DSMI_ERR_CONV = -2
 DSMI_ERR_NOT_READY = -3
 DSMI_ERR_UNSORTED = -4
+DSMI_ERR_CAPACITY = -8
 
 
 class NativeLibraryMissing(RuntimeError):
@@ -68,6 +69,12 @@ _PROTOS = {
     "dsmi_frontend_destroy": (None, [_vp]),
     "dsmi_frontend_last_error": (C.c_char_p, [_vp]),
     "dsmi_features": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, _vp]),
+    "dsmi_features_stream": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, _vp, _vp, C.c_int, _vp, _vp]),
+    "dsmi_stream_create": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "dsmi_stream_destroy": (None, [_vp]),
+    "dsmi_stream_last_error": (C.c_char_p, [_vp]),
+    "dsmi_stream_reset": (C.c_int, [_vp]),
+    "dsmi_stream_forward": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp]),
     "dsmi_segment": (C.c_int, [_vp, _vp, C.c_int, C.c_int64, C.c_int, C.c_double, C.c_int, C.c_int, _vp, _vp, C.c_int,
                                C.POINTER(C.c_int), _vp, _vp]),
     "dsmi_decoder_create": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.c_int, C.c_int, C.POINTER(_vp)]),
@@ -340,6 +347,77 @@ def _segment(self, pcm_dev, energy_threshold=600, step=1024, pause_hops=9, phras
 
 
 NativeFrontend.segment = _segment
+
+
+def _features_stream(self, pcm_dev, state):
+    """dsmi_features_stream: one chunk of the streaming parser.  ``state`` = float64[3] (input_mean, input_std,
+    alpha), updated in place.  -> feat [n_freq, frames] float32 CUDA."""
+    import torch
+    dt = {torch.int16: 0, torch.float32: 1, torch.float64: 2}[pcm_dev.dtype]
+    n = pcm_dev.numel()
+    n_fft = 2 * (self.n_freq - 1)
+    nfr = 1 + (n - n_fft) // self.hop if n >= n_fft else 0
+    feat = torch.empty((self.n_freq, max(nfr, 1)), dtype=torch.float32, device=pcm_dev.device)
+    fr = np.zeros(1, dtype=np.int32)
+    rc = lib().dsmi_features_stream(self._h, pcm_dev.data_ptr(), dt, n, _np_ptr(state), feat.data_ptr(), feat.shape[1],
+                                    _np_ptr(fr), _stream())
+    if rc != 0:
+        raise DsmiError(rc, (lib().dsmi_frontend_last_error(self._h) or b"").decode())
+    return feat[:, :int(fr[0])]
+
+
+NativeFrontend.features_stream = _features_stream
+
+
+class NativeStream:
+    """Owns one dsmi_stream handle: the carried state of one utterance streamed through a unidirectional model."""
+
+    def __init__(self, model):
+        self.model = model
+        h = _vp()
+        rc = lib().dsmi_stream_create(model._h, C.byref(h))
+        if rc != 0:
+            raise DsmiError(rc, (lib().dsmi_stream_last_error(None) or b"").decode())
+        self._h = h
+
+    def _check(self, rc):
+        if rc != 0:
+            raise DsmiError(rc, (lib().dsmi_stream_last_error(self._h) or b"").decode())
+
+    def forward(self, feat, is_first, is_last):
+        """feat: CUDA float32 [F,T] (or [1,1,F,T]) -> probs [1,T_out,C] CUDA, or None while the lookahead buffers."""
+        import torch
+        feat = feat.reshape(feat.shape[-2], feat.shape[-1]).contiguous()
+        assert feat.is_cuda and feat.dtype == torch.float32
+        T = feat.shape[1]
+        cap = T + 4 * int(self.model.desc.context) + 2048 if not hasattr(self, "_cap") else self._cap
+        while True:
+            probs = torch.empty((cap, self.model.n_labels), dtype=torch.float32, device=feat.device)
+            tout = np.zeros(1, dtype=np.int32)
+            rc = lib().dsmi_stream_forward(self._h, feat.data_ptr(), T, int(bool(is_first)), int(bool(is_last)),
+                                           probs.data_ptr(), cap, _np_ptr(tout), _stream())
+            if rc == DSMI_ERR_CAPACITY and cap < (1 << 24):
+                # nothing was consumed: the capacity check precedes every state update of the lookahead
+                cap *= 4
+                continue
+            self._check(rc)
+            break
+        n = int(tout[0])
+        return probs[:n].unsqueeze(0) if n > 0 else None
+
+    def reset(self):
+        self._check(lib().dsmi_stream_reset(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().dsmi_stream_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class NativeDecoder:

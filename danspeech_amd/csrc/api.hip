@@ -131,7 +131,10 @@ extern "C" int dsmi_model_load_tensor(dsmi_model* m, const char* name, const flo
     size_t n = 1;
     for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
     t.data.assign(data, data + n);
-    m->tensors[name] = std::move(t);
+    // LookaheadStream is a direct attribute of a streaming model (model.py:490), the first module of a
+    // Sequential otherwise (model.py:407-411): one weight, two names
+    const std::string key = std::string(name) == "lookahead.conv.weight" ? "lookahead.0.conv.weight" : name;
+    m->tensors[key] = std::move(t);
     return DSMI_OK;
 }
 

@@ -118,6 +118,8 @@ struct RnnStepLaunch {
     const int32_t* lens_dev;     // [B] output lengths
     float* hpack;                // [2][D][ceil(B/32)][nq][64][4] packed state (double-buffered by step parity)
     int B, T, step;
+    const float* hcarry = nullptr;   // unidirectional streaming: [B][Hs] state of the previous chunk (step 0 continues from it)
+    int pbase = 0;                   // parity offset of hpack, so that a chunk's step 0 reads what the previous chunk's last step wrote
     EvPair ev;
     unsigned long long* dbg = nullptr;   // diagnostics: per-wave timestamps [D*nwg][8 waves][8]
 };

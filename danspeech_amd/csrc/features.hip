@@ -32,6 +32,7 @@ static thread_local std::string g_fe_error;
 namespace {
 
 constexpr int FT = 8;   // frames per workgroup
+constexpr int PAD_NONE = 2;   // internal third pad mode: no centre padding
 
 // One integer sample of a WAV frame stream (resources.py:551-554 for the 8-bit bias).
 __device__ __forceinline__ int64_t ld_int(const void* p, int base, int64_t i) {
@@ -67,10 +68,11 @@ __global__ __launch_bounds__(256) void stft_logmag_kernel(const void* pcm, int d
     double* s_x = sm + 2 * n_fft;      // [n_fft][FT]  (frame fastest: one broadcast b128-friendly row per tap)
     const int b = blockIdx.y, t0 = blockIdx.x * FT, tid = threadIdx.x;
     const int64_t N = nsamp[b], off = offs[b];
-    const int nfr = 1 + (int)(N / hop);
+    const bool centred = pad_mode != PAD_NONE;            // PAD_NONE: librosa.stft(center=False), the streaming parser
+    const int nfr = centred ? 1 + (int)(N / hop) : 1 + (int)((N - n_fft) / hop);
     if (t0 >= nfr) return;
     for (int i = tid; i < 2 * n_fft; i += 256) s_tw[i] = tw[i];
-    const int half = n_fft / 2;
+    const int half = centred ? n_fft / 2 : 0;
     for (int i = tid; i < n_fft * FT; i += 256) {
         const int f = i % FT, n = i / FT;
         const int t = t0 + f;
@@ -144,6 +146,25 @@ __global__ __launch_bounds__(1024) void normalize_kernel(float* feat, const int6
     }
 }
 
+// Streaming parser statistics: np.mean / np.std (population) over the [n_freq][nfr] chunk, one workgroup.
+__global__ __launch_bounds__(1024) void chunk_stats_kernel(const float* feat, int n_freq, int nfr, int t_stride, double* out2) {
+    __shared__ double sh[16];
+    const int tid = threadIdx.x, total = n_freq * nfr;
+    double s = 0.0;
+    for (int i = tid; i < total; i += 1024) s += (double)feat[(size_t)(i / nfr) * t_stride + i % nfr];
+    const double mean = block_sum(s, sh) / (double)total;
+    double q = 0.0;
+    for (int i = tid; i < total; i += 1024) { const double d = (double)feat[(size_t)(i / nfr) * t_stride + i % nfr] - mean; q += d * d; }
+    const double var = block_sum(q, sh) / (double)total;
+    if (tid == 0) { out2[0] = mean; out2[1] = sqrt(var); }
+}
+
+__global__ void chunk_normalize_kernel(float* feat, int n_freq, int nfr, int t_stride, float mean, float stdv) {
+    const int total = n_freq * t_stride;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x)
+        feat[i] = (i % t_stride < nfr) ? (feat[i] - mean) / stdv : 0.f;
+}
+
 // Hop energies for dsmi_segment: one wave per hop.  numpy sums a contiguous float64 array pairwise:
 // blocks of 128 elements, each with 8 strided accumulators combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)),
 // blocks combined by halving.  Lane = block*8 + accumulator reproduces that order for step = 128 * 2^k
@@ -180,6 +201,57 @@ __global__ __launch_bounds__(256) void hop_energy_kernel(const void* pcm, int dt
 }
 
 }  // namespace
+
+extern "C" int dsmi_features_stream(dsmi_frontend* f, const void* pcm, int dtype, int64_t n_samples, double* state3, float* feat,
+                                    int t_stride, int32_t* frames, void* stream) {
+    if (!f) return DSMI_ERR_INVALID;
+    auto bad = [&](int code, const char* msg) { f->err = msg; return code; };
+    const int base = dtype & 15;
+    const bool stereo_ok = base == DSMI_PCM_I16 || base == DSMI_PCM_I24 || base == DSMI_PCM_I32;
+    if (!pcm || !state3 || !feat || !frames || dtype < 0 || base > DSMI_PCM_I32 || (dtype & ~(15 | DSMI_PCM_STEREO)) ||
+        ((dtype & DSMI_PCM_STEREO) && !stereo_ok))
+        return bad(DSMI_ERR_INVALID, "bad streaming features arguments");
+    if (n_samples < f->n_fft) return bad(DSMI_ERR_INVALID, "fewer samples than one STFT window (the parser drops such a last chunk, parsers.py:106-110)");
+    const int nfr = 1 + (int)((n_samples - f->n_fft) / f->hop);
+    if (nfr > t_stride) return bad(DSMI_ERR_INVALID, "t_stride smaller than the chunk's frame count");
+    if (hipSetDevice(f->device) != hipSuccess) return bad(DSMI_ERR_HIP, "hipSetDevice failed");
+    hipStream_t s = (hipStream_t)stream;
+    if (f->cap < 2) {       // offs doubles as scratch for the statistics: [0] offset, [cap] n_samples, then two doubles
+        if (f->offs) { (void)hipStreamSynchronize(s); (void)hipFree(f->offs); f->offs = nullptr; }
+        if (hipMalloc((void**)&f->offs, sizeof(int64_t) * 4) != hipSuccess) return bad(DSMI_ERR_NOMEM, "hipMalloc failed");
+        f->cap = 2;
+    }
+    const int64_t host[2] = {0, n_samples};
+    if (hipMemcpyAsync(f->offs, &host[0], sizeof(int64_t), hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(f->offs + f->cap, &host[1], sizeof(int64_t), hipMemcpyHostToDevice, s) != hipSuccess)
+        return bad(DSMI_ERR_HIP, "hipMemcpyAsync failed");
+    const size_t lds = sizeof(double) * ((size_t)2 * f->n_fft + (size_t)f->n_fft * FT);
+    hipLaunchKernelGGL(stft_logmag_kernel, dim3(ceil_div(nfr, FT), 1), dim3(256), lds, s, pcm, dtype, f->offs, f->offs + f->cap,
+                       f->tw, f->win, f->n_fft, f->hop, f->n_freq, PAD_NONE, feat, t_stride);
+    double* stats_dev = nullptr;
+    if (hipMalloc((void**)&stats_dev, 2 * sizeof(double)) != hipSuccess) return bad(DSMI_ERR_NOMEM, "hipMalloc failed");
+    hipLaunchKernelGGL(chunk_stats_kernel, dim3(1), dim3(1024), 0, s, feat, f->n_freq, nfr, t_stride, stats_dev);
+    double st[2] = {0, 0};
+    const bool ok = hipMemcpyAsync(st, stats_dev, sizeof(st), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+    (void)hipFree(stats_dev);
+    if (!ok) return bad(DSMI_ERR_HIP, "streaming feature kernels failed");
+    // parsers.py:146-158 (np.mean / np.std of a float32 array are float32 values)
+    const double dataset_mean = 5.492418704733003, dataset_std = 1.7552755216970917, alpha_increment = 0.1;
+    double input_mean = state3[0], input_std = state3[1], alpha = state3[2];
+    alpha += alpha_increment;
+    input_mean = (input_mean + (double)(float)st[0]) / 2;
+    input_std = (input_std + (double)(float)st[1]) / 2;
+    double mean = input_mean, stdv = input_std;
+    if (alpha < 1.0) {
+        mean = input_mean * alpha + (1 - alpha) * dataset_mean;
+        stdv = input_std * alpha + (1 - alpha) * dataset_std;
+    }
+    state3[0] = input_mean; state3[1] = input_std; state3[2] = alpha;
+    hipLaunchKernelGGL(chunk_normalize_kernel, dim3(64), dim3(256), 0, s, feat, f->n_freq, nfr, t_stride, (float)mean, (float)stdv);
+    if (hipGetLastError() != hipSuccess) return bad(DSMI_ERR_HIP, "streaming feature kernels failed to launch");
+    *frames = nfr;
+    return DSMI_OK;
+}
 
 extern "C" int dsmi_segment(dsmi_frontend* f, const void* pcm, int dtype, int64_t n_samples, int step, double energy_threshold,
                             int pause_hops, int phrase_hops, int64_t* seg_start, int64_t* seg_end, int max_segments,

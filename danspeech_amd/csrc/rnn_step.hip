@@ -73,6 +73,8 @@ struct StepArgs {
     const int32_t* lens;
     float* hpack;              // [2 parity][D][ceil(B/32)][nq][64][4]: h in the B operand's lane order
     int B, T, step, G, H, U, Hs, nq, Np, nwg;
+    const float* hcarry;       // streaming (D = 1): [B][Hs] state carried in from the previous chunk, read at step 0
+    int pbase;                 // streaming: parity offset of the packed state so that chunks continue each other
     unsigned long long* dbg;   // diagnostics build only (STAMP = true)
 };
 
@@ -104,9 +106,11 @@ __global__ __launch_bounds__(NW * 64) void rnn_step_kernel(StepArgs p) {
     const int b0 = blockIdx.z * 32;
     const int t = d == 0 ? p.step : p.T - 1 - p.step;
     const int tprev = d == 0 ? t - 1 : t + 1;
-    const bool has_prev = tprev >= 0 && tprev < p.T;
+    const bool carry0 = p.step == 0 && p.hcarry != nullptr;       // BatchRNNStream: rnn(x, hx=previous_hidden), model.py:229
+    const bool has_prev = (tprev >= 0 && tprev < p.T) || carry0;
     float* outd = p.out[d];
-    const float* hprev = outd + (size_t)(has_prev ? tprev : 0) * p.B * p.Hs;
+    const float* hprev = carry0 ? p.hcarry : outd + (size_t)(has_prev ? tprev : 0) * p.B * p.Hs;
+    const int par = (p.step + p.pbase) & 1;
     const int nb = min(32, p.B - b0);
     const int GU = p.G * p.U;
     const size_t xcol = (size_t)d * p.nwg * GU + (size_t)w * GU;
@@ -118,7 +122,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_step_kernel(StepArgs p) {
     if (has_prev) {
         const f32x4* wp = reinterpret_cast<const f32x4*>(p.whh[d]) + ((size_t)w * p.nq) * 64 + lane;
         const f32x4* hq = reinterpret_cast<const f32x4*>(p.hpack) +
-                          ((((size_t)((p.step & 1) ^ 1) * gridDim.y + d) * gridDim.z + blockIdx.z) * p.nq) * 64 + lane;
+                          ((((size_t)(par ^ 1) * gridDim.y + d) * gridDim.z + blockIdx.z) * p.nq) * 64 + lane;
 #pragma unroll
         for (int i = 0; i < NQW; ++i) {
             const int q = min(q0 + i, q1 - 1);      // clamp: the duplicate is skipped below
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_step_kernel(StepArgs p) {
 
     // ---- 4. K-split reduction in fixed order + cell.  The new state goes to the layer output
     // (natural layout) and to the packed copy the next step's B operand reads.
-    float* hw = p.hpack + ((((size_t)(p.step & 1) * gridDim.y + d) * gridDim.z + blockIdx.z) * p.nq) * 256;
+    float* hw = p.hpack + ((((size_t)par * gridDim.y + d) * gridDim.z + blockIdx.z) * p.nq) * 256;
 #pragma unroll
     for (int i = 0; i < PP; ++i) {
         const int pr = tid + i * NT;
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_step_kernel(StepArgs p) {
             hn = (1.f - z) * n + z * hp[i];
         } else if (KIND == DSMI_RNN_LSTM) {
             float* cp = p.cst[d] + (size_t)b * p.Hs + unit;
-            const float c0 = p.step == 0 ? 0.f : *cp;
+            const float c0 = (p.step == 0 && !carry0) ? 0.f : *cp;
             const float ig = sigmoidf_(xg[i][0] + hg[0]);
             const float fg = sigmoidf_(xg[i][1] + hg[1]);
             const float gg = tanhf(xg[i][2] + hg[2]);
@@ -253,6 +257,7 @@ void launch_rnn_step(const RnnStepLaunch& p, hipStream_t s) {
         a.whh[d] = p.whh_packed[d]; a.bhh[d] = p.bhh[d]; a.out[d] = p.out[d]; a.cst[d] = p.cstate[d];
     }
     a.xp = p.xp; a.lens = p.lens_dev; a.B = p.B; a.T = p.T; a.step = p.step;
+    a.hcarry = p.hcarry; a.pbase = p.pbase;
     a.G = p.g.G; a.H = p.g.H; a.U = p.g.U; a.Hs = p.g.Kp; a.nq = p.g.nq; a.Np = p.g.Np; a.nwg = p.g.nwg;
     switch (p.g.kind) {
         case DSMI_RNN_GRU: launch_kind<DSMI_RNN_GRU>(a, p.g.D, s, p.ev); break;

@@ -118,6 +118,33 @@ const char* dsmi_frontend_last_error(const dsmi_frontend* f);
 int dsmi_features(dsmi_frontend* f, const void* pcm_dev, int pcm_dtype, const int64_t* n_samples_host,
                   int B, float* feat_dev, int t_stride, int32_t* frames_host, void* stream);
 
+/* ---- InferenceSpectrogramAudioParser.parse_audio (parsers.py:102-164), the arithmetic half: STFT of the
+ * samples WITHOUT centre padding (librosa.stft(center=False), :137-138: 1 + (n - n_fft)/hop frames), log1p|.|,
+ * then the adaptive normalisation of :146-161.  state3 = {input_mean, input_std, alpha} is read and updated
+ * exactly as the parser's attributes are (alpha += 0.1; running mean/std halved with the chunk's np.mean /
+ * np.std; while alpha < 1 they are mixed with the NST dataset statistics 5.492418704733003 /
+ * 1.7552755216970917, :89-94).  The sample bookkeeping of :112-133 (hop carry-over) stays with the caller.
+ * feat_dev [n_freq][t_stride]; *frames_host = frames written.  Synchronous (the statistics pass through
+ * the host).  Start an utterance with state3 = {0, 0, 0} (parser.reset(), :166-170). */
+int dsmi_features_stream(dsmi_frontend* f, const void* pcm_dev, int pcm_dtype, int64_t n_samples, double* state3,
+                         float* feat_dev, int t_stride, int32_t* frames_host, void* stream);
+
+/* ---- Chunked unidirectional inference: DeepSpeech(streaming_inference_model=True).streaming_forward
+ * (model.py:517-537) with the state MaskConvStream (:156-201), BatchRNNStream (:204-238) and LookaheadStream
+ * (:241-283) carry between calls.  One dsmi_stream = one utterance in flight (B = 1) on a unidirectional
+ * 2-conv model (the only streaming shape the reference can run: streaming_init, :427-494); a model serves any
+ * number of streams.  feat_dev [n_freq][T] float32 (one chunk of the streaming parser's output);
+ * probs_dev [T_out_cap][n_labels].  *T_out = frames written: 0 on the first pass (is_first), when the
+ * lookahead only buffers (streaming_forward returns None, :529-530).  is_last flushes the lookahead with its
+ * right padding and clears all carried state.  Asynchronous on `stream`. */
+typedef struct dsmi_stream dsmi_stream;
+int dsmi_stream_create(dsmi_model* m, dsmi_stream** out);
+void dsmi_stream_destroy(dsmi_stream* s);
+const char* dsmi_stream_last_error(const dsmi_stream* s);
+int dsmi_stream_reset(dsmi_stream* s);
+int dsmi_stream_forward(dsmi_stream* s, const float* feat_dev, int T, int is_first, int is_last, float* probs_dev,
+                        int T_out_cap, int32_t* T_out, void* stream);
+
 /* ---- Offline long-form segmentation: the energy gate of
  * example_scripts/video_transcribe_simulation.py:68-143 over one recording.
  * Hop i covers samples [i*step, (i+1)*step) for every i with (i+1)*step < n_samples (:94); its energy is

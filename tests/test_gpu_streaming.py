@@ -1,0 +1,99 @@
+"""GPU parity of the chunked unidirectional path through the C ABI:
+dsmi_stream_forward against the reference's own streaming model (tests/golden/g8_streaming.npz) and
+against oracle/streaming.py; dsmi_features_stream against the oracle's restatement of
+InferenceSpectrogramAudioParser.  Tolerance: 1e-4 on probabilities (BASELINE north_star), 2e-5 features."""
+import numpy as np
+import pytest
+
+from danspeech_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def native():
+    from danspeech_amd import _native
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    _native.lib()
+    return _native
+
+
+def _cfg(kind, H, L, ctx):
+    return dict(conv_layers=2, rnn_type=kind, rnn_hidden_size=H, rnn_layers=L, bidirectional=False, context=ctx)
+
+
+@pytest.mark.parametrize("kind", ["gru", "lstm", "rnn"])
+def test_stream_forward_g8(native, golden, kind):
+    g = golden("g8_streaming")
+    tag = "%s_c2" % kind
+    chunks = [int(v) for v in g["chunks_" + tag]]
+    H, L, ctx = 32, 3, 6
+    sd = syn.make_state_dict(2, kind, H, L, bidirectional=False, context=ctx, seed=81, fc_gain=4.0)
+    m = native.NativeModel(_cfg(kind, H, L, ctx), sd)
+    st = native.NativeStream(m)
+    for utt in range(2):                 # the second utterance runs on the state is_last left behind
+        for ci, T in enumerate(chunks):
+            x = torch.from_numpy(syn.make_features(1, T, seed=8100 + 100 * utt + ci)).cuda()
+            y = st.forward(x, ci == 0, ci == len(chunks) - 1)
+            ref = g["probs_%s_u%d_k%d" % (tag, utt, ci)]
+            if ci == 0:
+                assert y is None and ref.size == 0
+            else:
+                assert tuple(y.shape[1:]) == ref.shape
+                np.testing.assert_allclose(y[0].cpu().numpy(), ref, rtol=0, atol=1e-4)
+    st.close(); m.close()
+
+
+def test_stream_forward_vs_oracle_wide_model_many_chunks(native):
+    """H = 200 (several k-blocks per wave, padded to 8), context 20, 12 chunks of the real-time size
+    (39 spectrogram frames; Recognizer.py:598-612), odd and even chunk lengths (parity of the packed state)."""
+    from oracle import streaming as ost
+    H, L, ctx = 200, 2, 20
+    sd = syn.make_state_dict(2, "gru", H, L, bidirectional=False, context=ctx, seed=82, fc_gain=4.0)
+    cfg = _cfg("gru", H, L, ctx)
+    m = native.NativeModel(cfg, sd)
+    st = native.NativeStream(m)
+    om = ost.StreamingModel(sd, cfg)
+    chunks = [53] + [39, 40, 38, 39, 41, 39, 39, 44, 39, 39] + [17]
+    worst = 0.0
+    for ci, T in enumerate(chunks):
+        x = syn.make_features(1, T, seed=8300 + ci)
+        y = st.forward(torch.from_numpy(x).cuda(), ci == 0, ci == len(chunks) - 1)
+        ref = om.forward(x, ci == 0, ci == len(chunks) - 1)
+        assert (y is None) == (ref is None)
+        if ref is not None:
+            assert tuple(y.shape) == ref.shape
+            worst = max(worst, float(np.abs(y.cpu().numpy() - ref).max()))
+    print("streaming max |probs - oracle| = %.3g" % worst)
+    assert worst < 1e-4
+    # protocol errors: a chunk without is_first on a fresh / finished stream is refused and changes nothing
+    with pytest.raises(native.DsmiError):
+        st.forward(torch.from_numpy(syn.make_features(1, 39, seed=1)).cuda(), False, False)
+    st.close()
+    with pytest.raises(native.DsmiError):
+        native.NativeStream(native.NativeModel(dict(cfg, bidirectional=True), syn.make_state_dict(2, "gru", 16, 1, seed=3)))
+    m.close()
+
+
+def test_features_stream_vs_oracle(native):
+    from oracle import streaming as ost
+    fe = native.NativeFrontend()
+    p = ost.StreamingParser()
+    state = np.zeros(3, dtype=np.float64)
+    rng = np.random.default_rng(84)
+    for n in (8640, 6250, 6240, 7001, 12000, 6240, 6240, 6240, 6240, 6240, 6240, 900):     # alpha crosses 1.0 at the 10th chunk
+        part = np.round(rng.normal(0, 3000, n))
+        y = p.frames(part).copy()                    # the host-side sample bookkeeping (parsers.py:112-133)
+        p.buffer = p.buffer.copy()
+        p2 = ost.StreamingParser(); p2.__dict__.update({k: v for k, v in p.__dict__.items()})
+        p2.buffer = None
+        ref = p2.parse_audio(y)                      # arithmetic half on exactly these samples
+        p.input_mean, p.input_std, p.alpha = p2.input_mean, p2.input_std, p2.alpha
+        got = fe.features_stream(torch.from_numpy(y).cuda(), state).cpu().numpy()
+        assert got.shape == ref.shape
+        np.testing.assert_allclose(got, ref, rtol=0, atol=2e-5)
+        np.testing.assert_allclose(state, [p.input_mean, p.input_std, p.alpha], rtol=1e-6)
+    with pytest.raises(native.DsmiError):
+        fe.features_stream(torch.zeros(100, dtype=torch.float64).cuda(), state)
+    fe.close()

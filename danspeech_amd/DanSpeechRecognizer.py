@@ -13,7 +13,7 @@ import numpy as np
 
 from .deepspeech.decoder import GreedyDecoder, BeamCTCDecoder
 from .errors.recognizer_errors import ModelNotInitialized
-from .audio.parsers import SpectrogramAudioParser
+from .audio.parsers import SpectrogramAudioParser, InferenceSpectrogramAudioParser
 
 
 class NoLmInstantiatedWarning(Warning):
@@ -88,6 +88,94 @@ class DanSpeechRecognizer(object):
                                               cutoff_top_n=40, blank_index=self.labels.index('_'))
             else:
                 self.decoder = GreedyDecoder(labels=self.labels, blank_index=self.labels.index('_'))
+
+    # ---- streaming (DanSpeechRecognizer.py:97-216) -----------------------------------------------
+    def _device_index(self):
+        return int(str(self.model.device).split(":")[1]) if ":" in str(self.model.device) else 0
+
+    def enable_streaming(self, secondary_model=None, return_string_parts=True):
+        """DanSpeechRecognizer.py:97-127."""
+        self.full_output = []
+        self.iterating_transcript = ""
+        if secondary_model:
+            self.secondary_model = secondary_model.to(self.device)
+            self.secondary_model.eval()
+        else:
+            self.secondary_model = None
+        self.spectrograms = []
+        self.greedy_decoder = GreedyDecoder(labels=self.labels, blank_index=self.labels.index('_'))
+        self.audio_parser = InferenceSpectrogramAudioParser(audio_config=self.audio_config, device=self._device_index())
+        self.string_parts = bool(return_string_parts)
+
+    def disable_streaming(self, keep_secondary_model=False):
+        """DanSpeechRecognizer.py:129-136."""
+        self.audio_parser = SpectrogramAudioParser(self.audio_config, device=self._device_index())
+        self.greedy_decoder = None
+        self.reset_streaming_params()
+        self.string_parts = False
+        if not keep_secondary_model:
+            self.secondary_model = None
+
+    def reset_streaming_params(self):
+        self.iterating_transcript = ""
+        self.full_output = []
+        self.spectrograms = []
+
+    def streaming_transcribe(self, recording, is_last, is_first):
+        """DanSpeechRecognizer.py:144-216: one part of an utterance through the streaming model; greedy text of
+        the part (or the whole running text), and on ``is_last`` the final transcription (secondary model
+        on the collected spectrograms, or the LM decoder on the collected outputs, or the running text)."""
+        import torch
+        recording = self.audio_parser.parse_audio(recording, is_last)
+        out = ""
+        if len(recording) != 0:
+            if self.secondary_model:
+                self.spectrograms.append(recording)
+            recording = recording.view(1, 1, recording.size(0), recording.size(1))
+            recording = recording.to(self.device)
+            out = self.model(recording, is_first, is_last)
+            if is_first:
+                return ""
+            self.full_output.append(out)
+            decoded_out, _ = self.greedy_decoder.decode(out)
+            transcript = decoded_out[0][0]
+            # Collapsing characters hack
+            if self.iterating_transcript and transcript and self.iterating_transcript[-1] == transcript[0]:
+                self.iterating_transcript = self.iterating_transcript + transcript[1:]
+                transcript = transcript[1:]
+            else:
+                self.iterating_transcript += transcript
+            if self.string_parts:
+                out = transcript
+            else:
+                out = self.iterating_transcript
+        if is_last:
+            if len(self.iterating_transcript) > 1:
+                if self.secondary_model:
+                    final = torch.cat(self.spectrograms, dim=1)
+                    self.spectrograms = []
+                    final = final.view(1, 1, final.size(0), final.size(1))
+                    final = final.to(self.device)
+                    input_sizes = torch.IntTensor([final.size(3)]).int()
+                    out, _ = self.secondary_model(final, input_sizes)
+                    decoded_out, _ = self.decoder.decode(out)
+                    decoded_out = decoded_out[0][0]
+                    self.reset_streaming_params()
+                    return decoded_out
+                else:
+                    if self.lm != "greedy":
+                        final_out = torch.cat(self.full_output, dim=1)
+                        decoded_out, _ = self.decoder.decode(final_out)
+                        decoded_out = decoded_out[0][0]
+                        self.reset_streaming_params()
+                        return decoded_out
+                    else:
+                        out = self.iterating_transcript
+                        self.reset_streaming_params()
+                        return out
+            else:
+                return ""
+        return out
 
     def transcribe(self, recording, show_all=False):
         """DanSpeechRecognizer.py:218-231."""

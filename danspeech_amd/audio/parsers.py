@@ -59,3 +59,62 @@ class SpectrogramAudioParser(AudioParser):
     def parse_audio(self, recording):
         feat, frames = self.parse_batch([recording])
         return feat[0, 0, :, :int(frames[0])]
+
+
+class InferenceSpectrogramAudioParser(AudioParser):
+    """The streaming parser (reference danspeech/audio/parsers.py:75-170): spectrograms of consecutive
+    parts of a recording with one hop carried over, normalised with statistics that move from the NST
+    dataset's to the input's over the first second.
+
+    The sample bookkeeping (parsers.py:112-133) is host logic on a few hundred samples and stays here;
+    the STFT (no centre padding), log1p and the adaptive normalisation (parsers.py:136-161) run in
+    ``dsmi_features_stream`` and the spectrogram stays on the GPU."""
+
+    def __init__(self, audio_config=None, device=0):
+        super(InferenceSpectrogramAudioParser, self).__init__(audio_config)
+        self.n_fft = int(self.sampling_rate * self.window_size)
+        self.hop_length = int(self.sampling_rate * self.window_stride)
+        self.device = device
+        self.dataset_mean = 5.492418704733003        # applied inside dsmi_features_stream (parsers.py:89-90)
+        self.dataset_std = 1.7552755216970917
+        self.alpha_increment = 0.1
+        self._state = np.zeros(3, dtype=np.float64)  # input_mean, input_std, alpha
+        self.buffer = None
+        self.has_buffer = False
+        self._native = None
+
+    input_mean = property(lambda self: float(self._state[0]))
+    input_std = property(lambda self: float(self._state[1]))
+    alpha = property(lambda self: float(self._state[2]))
+
+    def _frontend(self):
+        if self._native is None:
+            from .. import _native
+            conf = dict(sampling_rate=self.sampling_rate, window_size=self.window_size, window_stride=self.window_stride,
+                        window=self.window, normalize=self.normalize)
+            self._native = _native.NativeFrontend(conf, device=self.device)
+        return self._native
+
+    def parse_audio(self, part_of_recording, is_last=False):
+        import torch
+        if is_last and len(part_of_recording) < self.n_fft:            # parsers.py:106-110
+            self.reset()
+            return []
+        part_of_recording = np.asarray(part_of_recording, dtype=np.float64)
+        if self.has_buffer:
+            part_of_recording = np.concatenate((self.buffer, part_of_recording), axis=None)
+        extra_samples = len(part_of_recording) % self.hop_length
+        if extra_samples != 0:
+            extra_samples_array = part_of_recording[-extra_samples:]
+            part_of_recording = part_of_recording[:-extra_samples]
+        self.buffer = part_of_recording[-self.hop_length:]
+        if extra_samples != 0:
+            self.buffer = np.concatenate((self.buffer, extra_samples_array), axis=None)
+        self.has_buffer = True
+        pcm = torch.from_numpy(np.ascontiguousarray(part_of_recording)).to("cuda:%d" % self.device)
+        return self._frontend().features_stream(pcm, self._state)
+
+    def reset(self):
+        self.buffer = None
+        self.has_buffer = False
+        self._state[:] = 0

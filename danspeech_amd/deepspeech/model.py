@@ -55,11 +55,16 @@ class DeepSpeech(object):
         if conv_layers > 3:
             raise ConvError("Maximum amount of convolutional layers supported by DanSpeech is 3")
         if self.streaming_model:
-            raise NotImplementedError(
-                "streaming_inference_model=True (chunked unidirectional inference, reference model.py:427-494) is "
-                "outside the recognize() hot path this package implements")
+            # streaming_init (model.py:427-494) always builds unidirectional layers, and only its 2-conv shape
+            # can run: the first RNN layer is sized for two conv layers whatever conv_layers says (:476-484)
+            # and the 1-conv branch builds a plain MaskConv that streaming_forward cannot call
+            if conv_layers != 2:
+                raise ConvError("streaming models exist only with 2 convolutional layers (reference streaming_init)")
+            self.bidirectional = False
+            self.forward = self.streaming_forward      # model.py:424-425
         self._state = None
         self._native = None
+        self._stream = None
         self.device = "cpu"
         self.training = False
 
@@ -70,6 +75,9 @@ class DeepSpeech(object):
             a = v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
             sd[k] = a
         self._state = sd
+        if self._stream is not None:
+            self._stream.close()
+            self._stream = None
         if self._native is not None:
             self._native.close()
             self._native = None
@@ -92,6 +100,9 @@ class DeepSpeech(object):
             index = dev.index if dev.index is not None else torch.cuda.current_device()
             if self._native is None or self._native.device != index:
                 from .. import _native
+                if self._stream is not None:
+                    self._stream.close()
+                    self._stream = None
                 if self._native is not None:
                     self._native.close()
                 self._native = _native.NativeModel(self._cfg(), self._state, device=index,
@@ -128,7 +139,23 @@ class DeepSpeech(object):
         probs, out_lens = self._native.forward(x, lengths.numpy())
         return probs, torch.from_numpy(out_lens.copy()).int()
 
-    __call__ = forward
+    def streaming_forward(self, x, is_first, is_last):
+        """model.py:517-537: one chunk [1,1,F,T] of the streaming parser's output -> probs [1,T_out,C], or None
+        on the first pass (the lookahead is still buffering).  Conv context, recurrent state and lookahead
+        buffer live in a ``dsmi_stream`` on the GPU between calls; ``is_last`` clears them."""
+        import torch
+        if self._native is None:
+            raise RuntimeError("this DeepSpeech runs only on an MI355X: call model.to('cuda') first (no CPU path)")
+        if self._stream is None:
+            from .. import _native
+            self._stream = _native.NativeStream(self._native)
+        x = torch.as_tensor(x, dtype=torch.float32).to(torch.device(self.device))
+        if x.dim() == 4 and x.shape[0] != 1:
+            raise ValueError("streaming handles a single sequence (MaskConvStream, model.py:159)")
+        return self._stream.forward(x, is_first, is_last)
+
+    def __call__(self, *args, **kwargs):
+        return self.forward(*args, **kwargs)
 
     def freeze_layers(self, number_to_freeze=0):
         raise NotImplementedError("training helpers live in the separate danspeech_training repository (reference README.md:19-21)")

@@ -182,3 +182,38 @@ class StreamingParser(object):
         spect -= mean
         spect /= std
         return spect
+
+
+class StreamingRecognizer(object):
+    """DanSpeechRecognizer.streaming_transcribe (DanSpeechRecognizer.py:144-216), greedy final text
+    (no secondary model, lm == "greedy"), on top of StreamingParser + StreamingModel."""
+
+    def __init__(self, sd, cfg, labels, string_parts=True):
+        self.parser = StreamingParser()
+        self.model = StreamingModel(sd, cfg)
+        self.labels = labels
+        self.string_parts = string_parts
+        self.iterating_transcript = ""
+
+    def streaming_transcribe(self, recording, is_last, is_first):
+        from . import decoder as od
+        spect = self.parser.parse_audio(recording, is_last)
+        out = ""
+        if len(spect) != 0:
+            probs = self.model.forward(spect[None, None], is_first, is_last)
+            if is_first:
+                return ""
+            transcript = od.greedy_decode(probs, None, self.labels, self.labels.index("_"))[0][0][0]
+            if self.iterating_transcript and transcript and self.iterating_transcript[-1] == transcript[0]:
+                self.iterating_transcript = self.iterating_transcript + transcript[1:]
+                transcript = transcript[1:]
+            else:
+                self.iterating_transcript += transcript
+            out = transcript if self.string_parts else self.iterating_transcript
+        if is_last:
+            if len(self.iterating_transcript) > 1:
+                out = self.iterating_transcript
+                self.iterating_transcript = ""
+                return out
+            return ""
+        return out

@@ -97,3 +97,111 @@ def test_features_stream_vs_oracle(native):
     with pytest.raises(native.DsmiError):
         fe.features_stream(torch.zeros(100, dtype=torch.float64).cuda(), state)
     fe.close()
+
+
+# ---- the Python surface: DeepSpeech(streaming_inference_model=True), enable_real_time_streaming -------
+
+def _stream_model(name, H, L, ctx, seed, kind="gru"):
+    from danspeech_amd.deepspeech.model import DeepSpeech
+    sd = syn.make_state_dict(2, kind, H, L, bidirectional=False, context=ctx, seed=seed, fc_gain=8.0)
+    m = DeepSpeech(name, rnn_type=kind, rnn_hidden_size=H, rnn_layers=L, conv_layers=2, context=ctx, bidirectional=False,
+                   streaming_inference_model=True).load_state_dict(sd)
+    return m, sd, _cfg(kind, H, L, ctx)
+
+
+def test_streaming_model_object_and_package_round_trip(tmp_path):
+    from danspeech_amd.deepspeech.model import DeepSpeech
+    from danspeech_amd.errors.model_errors import ConvError
+    from oracle import streaming as ost
+    m, sd, cfg = _stream_model("stream-pkg", 48, 2, 8, seed=85)
+    import torch as _t
+    path = str(tmp_path / "stream.pth")
+    _t.save(m.serialize(), path)
+    m2 = DeepSpeech.load_model(path).to("cuda")
+    assert m2.streaming_model and not m2.bidirectional
+    om = ost.StreamingModel(sd, cfg)
+    for ci, T in enumerate([60, 39, 39, 20]):
+        x = syn.make_features(1, T, seed=8500 + ci)
+        y = m2(_t.from_numpy(x), ci == 0, ci == 3)
+        ref = om.forward(x, ci == 0, ci == 3)
+        assert (y is None) == (ref is None)
+        if ref is not None:
+            np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=0, atol=1e-4)
+    with pytest.raises(ConvError):
+        DeepSpeech("bad", conv_layers=3, streaming_inference_model=True)
+
+
+@pytest.mark.parametrize("string_parts", [True, False])
+def test_real_time_streaming_over_a_recording_equals_oracle(string_parts):
+    from danspeech_amd import Recognizer
+    from oracle import streaming as ost
+    m, sd, cfg = _stream_model("stream-rt", 64, 2, 20, seed=86)
+    rec = Recognizer()
+    rec.enable_real_time_streaming(streaming_model=m, string_parts=string_parts)
+    audio = syn.make_clip(5, 16000 * 4 + 333)
+    got = list(rec.stream_recording(audio, chunk_samples=1024))
+    # the same chunking against the oracle pipeline
+    o = ost.StreamingRecognizer(sd, cfg, syn.DANSPEECH_LABELS, string_parts=string_parts)
+    general = 160 * 2 + 160 * ((20 - 1) * 2 - 1)
+    first = general + 160 * 15
+    want, data, pos, first_pass = [], audio[:0], 0, True
+    while pos < len(audio):
+        part = audio[pos:pos + 1024]; pos += len(part)
+        last = pos >= len(audio)
+        data = np.concatenate((data, part))
+        out = None
+        if first_pass:
+            if not last and len(data) >= first:
+                out = o.streaming_transcribe(data, False, True); first_pass = False; data = audio[:0]
+        elif last or len(data) >= general:
+            out = o.streaming_transcribe(data, last, False); data = audio[:0]
+        if out:
+            want.append((last, out))
+    assert got == want and len(got) >= 3 and got[-1][0] is True
+    rec.disable_real_time_streaming()
+    assert type(rec.danspeech_recognizer.audio_parser).__name__ == "SpectrogramAudioParser"
+
+
+def test_streaming_final_text_from_secondary_model_and_from_lm(tmp_path):
+    """is_last hands the collected spectrograms to the secondary (bidirectional) model, or the collected
+    probabilities to the LM decoder (DanSpeechRecognizer.py:190-210)."""
+    from danspeech_amd import Recognizer
+    from danspeech_amd.deepspeech.model import DeepSpeech
+    m, sd, cfg = _stream_model("stream-sec", 64, 2, 20, seed=87)
+    sd2 = syn.make_state_dict(2, "gru", 64, 2, seed=88, fc_gain=8.0)
+    second = DeepSpeech("second", rnn_hidden_size=64, rnn_layers=2).load_state_dict(sd2)
+    audio = syn.make_clip(6, 16000 * 3)
+    rec = Recognizer()
+    rec.enable_real_time_streaming(streaming_model=m, secondary_model=second)
+    out = list(rec.stream_recording(audio, chunk_samples=2048))
+    assert out[-1][0] is True
+    # the secondary model saw the concatenation of the streaming parser's spectrograms
+    from danspeech_amd.audio.parsers import InferenceSpectrogramAudioParser
+    p = InferenceSpectrogramAudioParser(m.audio_conf)
+    general = 160 * 2 + 160 * 37
+    specs, data, pos, first_pass = [], audio[:0], 0, True
+    while pos < len(audio):
+        part = audio[pos:pos + 2048]; pos += len(part)
+        last = pos >= len(audio)
+        data = np.concatenate((data, part))
+        if first_pass:
+            if not last and len(data) >= general + 2400:
+                specs.append(p.parse_audio(data, False)); first_pass = False; data = audio[:0]
+        elif last or len(data) >= general:
+            s = p.parse_audio(data, last)
+            if len(s):
+                specs.append(s)
+            data = audio[:0]
+    final = torch.cat(specs, dim=1)
+    probs, sizes = second.to("cuda")(final.view(1, 1, final.size(0), final.size(1)), torch.IntTensor([final.size(1)]))
+    from danspeech_amd.deepspeech.decoder import GreedyDecoder
+    want = GreedyDecoder(syn.DANSPEECH_LABELS, blank_index=syn.DANSPEECH_LABELS.index("_")).decode(probs, sizes)[0][0][0]
+    assert out[-1][1] == want
+    rec.disable_real_time_streaming()
+    # LM decoder on the concatenated streaming probabilities
+    path = str(tmp_path / "lm.arpa")
+    syn.make_arpa(path, order=3, n_words=300, seed=13, ngrams_per_order=800)
+    rec2 = Recognizer(model=_stream_model("stream-lm", 64, 2, 20, seed=87)[0], lm=path)
+    rec2.enable_real_time_streaming(streaming_model=rec2.danspeech_recognizer.model)
+    out2 = list(rec2.stream_recording(audio, chunk_samples=2048))
+    assert out2[-1][0] is True and isinstance(out2[-1][1], str)

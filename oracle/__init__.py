@@ -21,4 +21,11 @@ Pinning status
   (parlance, unpinned master; reference danspeech/deepspeech/decoder.py:95-100) and
   KenLM; restated from the published algorithm and anchored on brute-force CTC
   known-answer tests.
+* ``oracle.streaming`` model half (MaskConvStream / BatchRNNStream / LookaheadStream /
+  streaming_forward): PINNED by ``tests/golden/g8_streaming.npz`` (the reference's own
+  streaming model, ``tools/gen_golden.py g8``).  Parser half
+  (InferenceSpectrogramAudioParser): UNPINNED like ``oracle.features`` (librosa).
+* ``oracle.segmentation``: restates an example script that cannot be imported
+  (argparse + downloaded models) and has no recorded output: UNPINNED, anchored on
+  hand-traced known answers.
 """

@@ -71,6 +71,8 @@ static hipEvent_t persist_gate(int device) {
     return e;
 }
 
+constexpr float kF16Safe = 60000.f;    // below fp16's 65504 with room for rounding
+
 static int fail(dsmi_model* m, int code, const std::string& msg) {
     m->err = msg;
     return code;
@@ -219,6 +221,8 @@ extern "C" int dsmi_model_finalize(dsmi_model* m) {
         if ((rc = upload(m, pack_gemm_w3(wih.data(), g.Np, r.K, r.ldw), &r.wih3))) return rc;
         if ((rc = upload(m, bih, &r.bih))) return rc;
         for (int dd = 0; dd < g.D; ++dd) {
+            // the split-fp16 operands hold |x| < 65504 only: a model beyond that stays on the fp32 kernels
+            for (float v : wh[dd]->data) if (!(std::fabs(v) < kF16Safe)) m->rnn_mode = 0;
             if ((rc = upload(m, pack_whh(g, wh[dd]->data.data()), &r.whh[dd]))) return rc;
             if ((rc = upload(m, pack_whh3(g, wh[dd]->data.data()), &r.whh3[dd]))) return rc;
             if ((rc = upload(m, bh[dd]->data, &r.bhh[dd]))) return rc;

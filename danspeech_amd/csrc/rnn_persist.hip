@@ -6,11 +6,15 @@
 //     wave keeps its K-slice of W_hh in REGISTERS for all T steps, so the weights cross the
 //     fabric once per layer instead of once per step (the per-step launch re-fetches all of
 //     W_hh from Infinity Cache/HBM every step: profiles/r01_pmc_rnn_step.md);
-//   * the h . W_hh^T product runs on the bf16 MFMA (v_mfma_f32_32x32x16_bf16, 16x the fp32 MFMA
-//     rate) with BOTH operands split into three bf16 terms (x = hi + mid + lo, exact to 2^-24)
-//     and the six significant cross products accumulated in fp32: measured error vs an fp64
-//     reference 8.0e-7 at K = 800 against 1.0e-6 for the fp32 MFMA chain
-//     (tools/exp/bf16x6_test.hip), i.e. fp32-grade results at 6/16 of the fp32 MFMA time.
+//   * the h . W_hh^T product runs on the fp16 MFMA (v_mfma_f32_32x32x16_f16, 16x the fp32 MFMA
+//     rate) with BOTH operands split into two fp16 terms, x = hi + lo * 2^-11 (hi = fp16(x),
+//     lo = fp16((x - hi) * 2^11): 22 mantissa bits, lo kept scaled so that it stays a normal
+//     number), three products: hi.hi in one fp32 accumulator, hi.lo + lo.hi in a second one that
+//     is folded in with 2^-11 at the end (lo.lo < 2^-22 is dropped).  Measured error vs an fp64
+//     reference at K = 800: 2.6e-7, against 1.0e-6 for the fp32 MFMA chain and 8.0e-7 for the
+//     earlier three-term bf16 split with six products (tools/exp/bf16x6_test.hip): better than
+//     fp32-MFMA accuracy at 3/16 of its time.  Ranges are safe by construction: |h| <= 1 for
+//     every cell type, |W_hh| is checked at load time (fp16 max 65504).
 //     W_hh is split once on the host; each workgroup splits the 256 state values it produces
 //     and publishes them already in B-operand lane order;
 //   * the per-step all-to-all of h goes through the packed state buffer with the counter form
@@ -40,10 +44,11 @@ constexpr size_t PERSIST_LDS = 82 * 1024;   // > half of the CU's 160 KiB: at mo
 
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 
-using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+constexpr float kLoScale = 2048.f, kLoInv = 1.f / 2048.f;   // 2^11: the lo term is stored scaled
 
 struct PersistArgs {
-    const uint16_t* whh3[2];   // [wg][pair][plane 3][lane 64][8 bf16]: split W_hh in A-operand lane order
+    const uint16_t* whh3[2];   // [wg][pair][plane 2][lane 64][8 fp16]: split W_hh (hi, lo * 2^11) in A-operand lane order
     const float* bhh[2]; const float* xp; float* out[2];
     const int32_t* lens; uint16_t* hpack3; unsigned* cnt; unsigned* err;
     int B, T, G, H, Hs, npair, Np, nwg;
@@ -90,20 +95,20 @@ __global__ __launch_bounds__(PNT) void rnn_persist_kernel(PersistArgs p) {
     const size_t xcol = (size_t)d * p.nwg * GU + (size_t)w * GU;
     if (tid == 0) s_dead = 0;
 
-    // ---- resident operand: this wave's pairs of the split W_hh (three 1-KiB planes per 16 k)
+    // ---- resident operand: this wave's pairs of the split W_hh (two 1-KiB planes per 16 k)
     const int p0 = (v * p.npair) / PNW, p1 = ((v + 1) * p.npair) / PNW;
-    bf16x8 wv[NPW][3];
+    f16x8 wv[NPW][2];
     {
-        const u32x4* wp = reinterpret_cast<const u32x4*>(p.whh3[d]) + ((size_t)w * p.npair) * 192 + lane;
+        const u32x4* wp = reinterpret_cast<const u32x4*>(p.whh3[d]) + ((size_t)w * p.npair) * 128 + lane;
 #pragma unroll
         for (int i = 0; i < NPW; ++i) {
             const int pq = min(p0 + i, p1 - 1);
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) wv[i][pl] = __builtin_bit_cast(bf16x8, wp[((size_t)pq * 3 + pl) * 64]);
+            for (int pl = 0; pl < 2; ++pl) wv[i][pl] = __builtin_bit_cast(f16x8, wp[((size_t)pq * 2 + pl) * 64]);
         }
     }
-    // packed split state, [parity][chain][pair][plane][hk][batch j][8 bf16]; accessed ONLY through sc1 buffer ops
-    const size_t hp_par = (size_t)p.nd * p.nz * p.npair * 3072;    // bytes per parity
+    // packed split state, [parity][chain][pair][plane][hk][batch j][8 fp16]; accessed ONLY through sc1 buffer ops
+    const size_t hp_par = (size_t)p.nd * p.nz * p.npair * 2048;    // bytes per parity
     const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.hpack3, 0, (int)(2 * hp_par), 0x00020000);
 
     // epilogue role: threads 0..255 own (unit u = tid>>5, batch bl = tid&31) of every tile
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(PNT) void rnn_persist_kernel(PersistArgs p) {
         const bool eact = eunit_ok && ebl < nb;
         const int chain = d * p.nz + z;
         unsigned* cnt = p.cnt + (size_t)chain * p.T;
-        const unsigned hchain = (unsigned)((size_t)chain * p.npair * 3072);
+        const unsigned hchain = (unsigned)((size_t)chain * p.npair * 2048);
         if (MULTI && tid < PU * 32) { mylen = st_len[z * PU * 32 + tid]; hprev_own = st_h[z * PU * 32 + tid]; cprev_own = st_c[z * PU * 32 + tid]; }
         // x-projection operands of this step do not depend on other workgroups: request them first
         float xg[NG];
@@ -144,9 +149,9 @@ __global__ __launch_bounds__(PNT) void rnn_persist_kernel(PersistArgs p) {
 #pragma unroll
             for (int g = 0; g < NG; ++g) xg[g] = xr[g * PU];
         }
-        f32x16 acc;
+        f32x16 acc, acl;        // hi.hi ; (hi.lo + lo.hi) * 2^11
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acl[r] = 0.f; }
         PSTAMP(0);   // loop head + x-projection request
         if (s > 0) {
             // ---- wait until every workgroup of this chain has published h_{s-1}
@@ -164,41 +169,29 @@ __global__ __launch_bounds__(PNT) void rnn_persist_kernel(PersistArgs p) {
             PSTAMP(1);   // waiting for the other workgroups
             // ---- B operand: split h_{s-1}, this wave's pairs, sc1 loads only (lane = hk*32 + j)
             const unsigned hbase = (unsigned)(((s - 1) & 1) * hp_par) + hchain + (unsigned)lane * 16u;
-            // (the widest layers take the state in two halves so that W_hh + h + accumulators fit 256 VGPRs)
-            constexpr int CH = NPW > 7 ? (NPW + 1) / 2 : NPW;
+            f16x8 hv[NPW][2];
 #pragma unroll
-            for (int c0 = 0; c0 < NPW; c0 += CH) {
-                bf16x8 hv[CH][3];
+            for (int i = 0; i < NPW; ++i) {
+                const int pq = min(p0 + i, p1 - 1);
 #pragma unroll
-                for (int i = 0; i < CH; ++i) {
-                    if (c0 + i < NPW) {
-                        const int pq = min(p0 + c0 + i, p1 - 1);
+                for (int pl = 0; pl < 2; ++pl)
+                    hv[i][pl] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                        hrs, hbase + (unsigned)(pq * 2 + pl) * 1024u, 0, 16));
+            }
 #pragma unroll
-                        for (int pl = 0; pl < 3; ++pl)
-                            hv[i][pl] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
-                                hrs, hbase + (unsigned)(pq * 3 + pl) * 1024u, 0, 16));
-                    }
+            for (int i = 0; i < NPW; ++i) {
+                if (p0 + i < p1) {
+                    acl = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv[i][1], hv[i][0], acl, 0, 0, 0);
+                    acl = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv[i][0], hv[i][1], acl, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv[i][0], hv[i][0], acc, 0, 0, 0);
                 }
-                // x . w = sum over the six cross products that matter (mid.lo, lo.mid, lo.lo < 2^-24), small terms first
-#pragma unroll
-                for (int i = 0; i < CH; ++i) {
-                    if (c0 + i < NPW && p0 + c0 + i < p1) {
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[c0 + i][1], hv[i][1], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[c0 + i][2], hv[i][0], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[c0 + i][0], hv[i][2], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[c0 + i][1], hv[i][0], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[c0 + i][0], hv[i][1], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[c0 + i][0], hv[i][0], acc, 0, 0, 0);
-                    }
-                }
-                if (CH < NPW) __builtin_amdgcn_sched_barrier(0);
             }
         }
         PSTAMP(2);   // h load + MFMA chain
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i = (r & 3) + 8 * (r >> 2) + 4 * hk;
-            red[(v * 32 + i) * 32 + li] = acc[r];
+            red[(v * 32 + i) * 32 + li] = acc[r] + acl[r] * kLoInv;
         }
         __syncthreads();
         PSTAMP(3);   // partial tiles to LDS + barrier (wave skew)
@@ -242,24 +235,20 @@ __global__ __launch_bounds__(PNT) void rnn_persist_kernel(PersistArgs p) {
         }
         __syncthreads();
         PSTAMP(4);   // reduction + cell
-        // ---- publish: lanes 0..31 of wave 0 split this workgroup's 8 units of batch row j into three
-        // bf16 terms and store one 16-byte granule per plane (512 contiguous bytes per instruction)
+        // ---- publish: lanes 0..31 of wave 0 split this workgroup's 8 units of batch row j into the two
+        // fp16 terms and store one 16-byte granule per plane (512 contiguous bytes per instruction)
         if (v == 0 && lane < 32) {
-            bf16x8 ph, pm, pl;
+            f16x8 ph, pl;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float x = hstage[e * 32 + lane];
-                const __bf16 h1 = (__bf16)x;
-                const float r1 = x - (float)h1;
-                const __bf16 h2 = (__bf16)r1;
-                const __bf16 h3 = (__bf16)(r1 - (float)h2);
-                ph[e] = h1; pm[e] = h2; pl[e] = h3;
+                const _Float16 h1 = (_Float16)x;
+                ph[e] = h1; pl[e] = (_Float16)((x - (float)h1) * kLoScale);
             }
-            const unsigned off = (unsigned)((s & 1) * hp_par) + hchain + (unsigned)(w >> 1) * 3072u +
+            const unsigned off = (unsigned)((s & 1) * hp_par) + hchain + (unsigned)(w >> 1) * 2048u +
                                  (unsigned)(w & 1) * 512u + (unsigned)lane * 16u;
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ph), hrs, off, 0, 16);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pm), hrs, off + 1024u, 0, 16);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pl), hrs, off + 2048u, 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pl), hrs, off + 1024u, 0, 16);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave drains its own stores
         __syncthreads();
@@ -301,7 +290,7 @@ bool launch_kind(const PersistArgs& a, int ny, hipStream_t s, const EvPair& ev) 
 
 }  // namespace
 
-// H up to 1280 (10 pairs of 16 k per wave); every workgroup of a launch must own a CU, so a layer whose
+// H up to 1280 (10 pairs of 16 k per wave: 80 + 80 operand VGPRs); every workgroup of a launch must own a CU, so a layer whose
 // two directions do not fit together (H > 1024 on 256 CUs) runs them as two launches, one after the other.
 bool rnn_persist_eligible(const RnnGeom& g, int B, int n_cus) {
     if (g.U != PU || (g.H % 8) != 0) return false;
@@ -310,24 +299,17 @@ bool rnn_persist_eligible(const RnnGeom& g, int B, int n_cus) {
     return g.nwg <= n_cus;
 }
 
-static inline uint16_t bf16_rne(float x) {
-    uint32_t u;
-    std::memcpy(&u, &x, 4);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
-static inline float bf16_to_f32(uint16_t b) {
-    const uint32_t u = (uint32_t)b << 16;
-    float f;
-    std::memcpy(&f, &u, 4);
-    return f;
+static inline uint16_t f16_bits(_Float16 h) {
+    uint16_t u;
+    std::memcpy(&u, &h, 2);
+    return u;
 }
 
-// w_hh [G*H][H] (torch layout) of one direction -> [wg][pair][plane][lane][8] bf16 terms; lane (i = gate row,
-// hk) element e holds k = 16*pair + 8*hk + e, the same k the producer of units 8*(2*pair+hk).. publishes.
+// w_hh [G*H][H] (torch layout) of one direction -> [wg][pair][plane][lane][8] fp16 terms (hi, lo * 2^11); lane
+// (i = gate row, hk) element e holds k = 16*pair + 8*hk + e, the same k the producer of units 8*(2*pair+hk).. publishes.
 std::vector<uint16_t> pack_whh3(const RnnGeom& g, const float* w_hh) {
     const int npair = ceil_div(g.nq, 2);
-    std::vector<uint16_t> out((size_t)g.nwg * npair * 3 * 64 * 8, 0);
+    std::vector<uint16_t> out((size_t)g.nwg * npair * 2 * 64 * 8, 0);
     const int GU = g.G * g.U;
     for (int w = 0; w < g.nwg; ++w)
         for (int pq = 0; pq < npair; ++pq)
@@ -340,12 +322,10 @@ std::vector<uint16_t> pack_whh3(const RnnGeom& g, const float* w_hh) {
                     const int k = 16 * pq + 8 * hk + e;
                     if (k >= g.H) continue;
                     const float x = w_hh[(size_t)(gate * g.H + unit) * g.H + k];
-                    const uint16_t h1 = bf16_rne(x);
-                    const float r1 = x - bf16_to_f32(h1);
-                    const uint16_t h2 = bf16_rne(r1);
-                    const uint16_t h3 = bf16_rne(r1 - bf16_to_f32(h2));
-                    const size_t base = (((size_t)w * npair + pq) * 3) * 64 * 8 + (size_t)lane * 8 + e;
-                    out[base] = h1; out[base + 512] = h2; out[base + 1024] = h3;
+                    const _Float16 h1 = (_Float16)x;
+                    const _Float16 h2 = (_Float16)((x - (float)h1) * kLoScale);
+                    const size_t base = (((size_t)w * npair + pq) * 2) * 64 * 8 + (size_t)lane * 8 + e;
+                    out[base] = f16_bits(h1); out[base + 512] = f16_bits(h2);
                 }
             }
     return out;

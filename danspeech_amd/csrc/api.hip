@@ -217,6 +217,7 @@ extern "C" int dsmi_model_finalize(dsmi_model* m) {
             bih[col] = bi[dd]->data[src];
         }
         int rc;
+        for (float v : wih) if (!(std::fabs(v) < kF16Safe)) m->gemm_mode = 0;     // split-fp16 operand range
         if ((rc = upload(m, wih, &r.wih))) return rc;
         if ((rc = upload(m, pack_gemm_w3(wih.data(), g.Np, r.K, r.ldw), &r.wih3))) return rc;
         if ((rc = upload(m, bih, &r.bih))) return rc;
@@ -230,6 +231,8 @@ extern "C" int dsmi_model_finalize(dsmi_model* m) {
         if (l > 0) {  // model.py:403-404: BatchNorm1d(H) in front of layers >= 1
             std::vector<float> a, b;
             if (!bn_affine(m, "rnns." + std::to_string(l) + ".batch_norm.module", H, m->Hs, a, b)) return DSMI_ERR_NOT_READY;
+            // the GEMM's A operand is (h_fwd + h_bwd) * a + b with |h| <= 1: bounded by 2|a| + |b|
+            for (size_t k = 0; k < a.size(); ++k) if (!(2.f * std::fabs(a[k]) + std::fabs(b[k]) < kF16Safe)) m->gemm_mode = 0;
             if ((rc = upload(m, a, &r.bn_a))) return rc;
             if ((rc = upload(m, b, &r.bn_b))) return rc;
         }

@@ -182,24 +182,27 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// fp32-grade GEMM on the bf16 MFMA: both operands are split into three bf16 terms
-// (x = hi + mid + lo) and the six significant cross products are accumulated in fp32
-// (v_mfma_f32_32x32x16_bf16 runs at 16x the fp32 MFMA rate, so 6 of them cost 6/16 of the
-// fp32 product; measured error vs fp64 8.0e-7 at K = 800 against 1.0e-6 for the fp32 MFMA
-// chain, tools/exp/bf16x6_test.hip).  W is split and tiled once on the host
-// (pack_gemm_w3: [n-tile][k-tile][plane][128][32] bf16, so the operand loads are fully
-// coalesced 16-byte copies); the activations are split ONCE per GEMM by split_a_kernel, fused
-// with the same producer transforms as the fp32 kernel (direction sum + BatchNorm1d, conv
-// transpose), into the same tiled form.  Tile 128x128x32, 4 waves in 2x2, one LDS stage
-// (60 KiB -> two workgroups per CU cover each other's barriers), next tile's global loads in
-// flight in registers during the MFMAs.
-using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
-using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+// fp32-grade GEMM on the fp16 MFMA: both operands are split into two fp16 terms,
+// x = hi + lo * 2^-11 (hi = fp16(x), lo = fp16((x - hi) * 2^11), 22 mantissa bits; lo is stored
+// scaled so that it stays a normal number), and three products are formed per fragment pair:
+// hi.hi into one fp32 accumulator, hi.lo + lo.hi into a second one that is folded in with 2^-11
+// in the epilogue (lo.lo < 2^-22 is dropped).  v_mfma_f32_32x32x16_f16 runs at 16x the fp32 MFMA
+// rate, so the product costs 3/16 of the fp32 one; measured error vs fp64 at K = 800: 2.6e-7
+// against 1.0e-6 for the fp32 MFMA chain (tools/exp/bf16x6_test.hip).  Operand ranges must stay
+// below fp16's 65504: the caller checks weights and BatchNorm bounds at load time (api.hip).
+// W is split and tiled once on the host (pack_gemm_w3: [n-tile][k-tile][plane][128][32] fp16, so
+// the operand loads are fully coalesced 16-byte copies); the activations are split ONCE per GEMM
+// by split_a_kernel, fused with the same producer transforms as the fp32 kernel (direction sum +
+// BatchNorm1d, conv transpose), into the same tiled form.  Tile 128x128x32, 4 waves in 2x2, one
+// LDS stage (40 KiB), next tile's global loads in flight in registers during the MFMAs.
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 
-constexpr int XS = 40;                 // LDS row stride in bf16 (80 B: 16 consecutive rows hit 64 distinct banks)
-constexpr int XPLANE = 128 * XS;       // bf16 elements per plane of one operand tile
+constexpr int XS = 40;                 // LDS row stride in halfs (80 B: 16 consecutive rows hit 64 distinct banks)
+constexpr int XPLANE = 128 * XS;       // elements per plane of one operand tile
 constexpr int XT_STRIDE = 129;         // f32 transpose tile [32 k][129] (GEMM_A_CONV)
+constexpr float kLoScale = 2048.f, kLoInv = 1.f / 2048.f;
 
 struct Gemm3Args {
     const float* a; const float* a2; const float* alpha; const float* beta;
@@ -207,14 +210,7 @@ struct Gemm3Args {
     int M, N, K, lda, ldc, B, T, ys, tiles_per_b, ktiles;
 };
 
-__device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
-    h = (__bf16)x;
-    const float r1 = x - (float)h;
-    m = (__bf16)r1;
-    l = (__bf16)(r1 - (float)m);
-}
-
-// Pass 1: form the A operand ONCE (producer transforms + three-term split) as tiled bf16 planes
+// Pass 1: form the A operand ONCE (producer transforms + two-term split) as tiled fp16 planes
 // [m-tile][k-tile][plane][128][32]; every one of the N/128 column tiles then reads it as is.
 template <int MODE>
 __global__ __launch_bounds__(256) void split_a_kernel(Gemm3Args p, uint16_t* a3) {
@@ -222,7 +218,7 @@ __global__ __launch_bounds__(256) void split_a_kernel(Gemm3Args p, uint16_t* a3)
     const int tid = threadIdx.x;
     const int kt = blockIdx.x, mt = blockIdx.y;
     const int k0 = kt * BK;
-    __bf16* tile = reinterpret_cast<__bf16*>(a3) + ((size_t)mt * p.ktiles + kt) * (3 * 4096);
+    _Float16* tile = reinterpret_cast<_Float16*>(a3) + ((size_t)mt * p.ktiles + kt) * (2 * 4096);
     f32x4 v[4];
     if (MODE == GEMM_A_CONV) {
         const int bb = mt / p.tiles_per_b, t0 = (mt % p.tiles_per_b) * BM;
@@ -261,21 +257,23 @@ __global__ __launch_bounds__(256) void split_a_kernel(Gemm3Args p, uint16_t* a3)
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
         const int row = (tid >> 3) + 32 * ps, kc = (tid & 7) * 4;
-        bf16x4 h, m, l;
+        f16x4 h, l;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { __bf16 x, y, z; split3(v[ps][c], x, y, z); h[c] = x; m[c] = y; l[c] = z; }
-        *reinterpret_cast<bf16x4*>(tile + 0 * 4096 + row * 32 + kc) = h;
-        *reinterpret_cast<bf16x4*>(tile + 1 * 4096 + row * 32 + kc) = m;
-        *reinterpret_cast<bf16x4*>(tile + 2 * 4096 + row * 32 + kc) = l;
+        for (int c = 0; c < 4; ++c) {
+            const _Float16 hi = (_Float16)v[ps][c];
+            h[c] = hi; l[c] = (_Float16)((v[ps][c] - (float)hi) * kLoScale);
+        }
+        *reinterpret_cast<f16x4*>(tile + 0 * 4096 + row * 32 + kc) = h;
+        *reinterpret_cast<f16x4*>(tile + 1 * 4096 + row * 32 + kc) = l;
     }
 }
 
-// Pass 2: C = A3 . W3^T + bias on v_mfma_f32_32x32x16_bf16, six products per (A, W) fragment pair.
+// Pass 2: C = A2 . W2^T + bias on v_mfma_f32_32x32x16_f16, three products per (A, W) fragment pair.
 template <bool CONV_ROWS>
-__global__ __launch_bounds__(256, 2) void gemm_bf16x6_kernel(Gemm3Args p, const uint16_t* a3) {
+__global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(Gemm3Args p, const uint16_t* a3) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
-    __bf16* As = reinterpret_cast<__bf16*>(smem3);            // [3][128][XS]
-    __bf16* Ws = As + 3 * XPLANE;                              // [3][128][XS]
+    _Float16* As = reinterpret_cast<_Float16*>(smem3);        // [2][128][XS]
+    _Float16* Ws = As + 2 * XPLANE;                            // [2][128][XS]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1;
     const int li = lane & 31, hk = lane >> 5;
@@ -284,18 +282,18 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x6_kernel(Gemm3Args p, const 
     int m0 = mt * BM, bb = 0, t0 = 0;
     if (CONV_ROWS) { bb = mt / p.tiles_per_b; t0 = (mt % p.tiles_per_b) * BM; }
 
-    u32x4 ra[6], rw[6];
-    const u32x4* atile = reinterpret_cast<const u32x4*>(a3) + (size_t)mt * p.ktiles * (3 * 128 * 4);
-    const u32x4* wtile = reinterpret_cast<const u32x4*>(p.w3) + (size_t)nt * p.ktiles * (3 * 128 * 4);
+    u32x4 ra[4], rw[4];
+    const u32x4* atile = reinterpret_cast<const u32x4*>(a3) + (size_t)mt * p.ktiles * (2 * 128 * 4);
+    const u32x4* wtile = reinterpret_cast<const u32x4*>(p.w3) + (size_t)nt * p.ktiles * (2 * 128 * 4);
     auto load_global = [&](int kt) {
-        const u32x4* at = atile + (size_t)kt * (3 * 128 * 4);
-        const u32x4* wt = wtile + (size_t)kt * (3 * 128 * 4);
+        const u32x4* at = atile + (size_t)kt * (2 * 128 * 4);
+        const u32x4* wt = wtile + (size_t)kt * (2 * 128 * 4);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) { ra[i] = at[tid + 256 * i]; rw[i] = wt[tid + 256 * i]; }
+        for (int i = 0; i < 4; ++i) { ra[i] = at[tid + 256 * i]; rw[i] = wt[tid + 256 * i]; }
     };
     auto store_lds = [&]() {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
+        for (int i = 0; i < 4; ++i) {
             const int c = tid + 256 * i;
             const int off = (c >> 9) * XPLANE + ((c >> 2) & 127) * XS + (c & 3) * 8;
             *reinterpret_cast<u32x4*>(As + off) = ra[i];
@@ -303,13 +301,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x6_kernel(Gemm3Args p, const 
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][2], acl[2][2];       // hi.hi ; (hi.lo + lo.hi) * 2^11
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; acl[i][j][r] = 0.f; }
 
     load_global(0);
     for (int kt = 0; kt < p.ktiles; ++kt) {
@@ -318,29 +316,24 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x6_kernel(Gemm3Args p, const 
         if (kt + 1 < p.ktiles) load_global(kt + 1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[2][3], wf[2][3];
+            f16x8 af[2][2], wf[2][2];
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    af[mi][pl] = *reinterpret_cast<const bf16x8*>(As + pl * XPLANE + (wr * 64 + mi * 32 + li) * XS + ks * 16 + hk * 8);
+                for (int pl = 0; pl < 2; ++pl)
+                    af[mi][pl] = *reinterpret_cast<const f16x8*>(As + pl * XPLANE + (wr * 64 + mi * 32 + li) * XS + ks * 16 + hk * 8);
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    wf[ni][pl] = *reinterpret_cast<const bf16x8*>(Ws + pl * XPLANE + (wc * 64 + ni * 32 + li) * XS + ks * 16 + hk * 8);
+                for (int pl = 0; pl < 2; ++pl)
+                    wf[ni][pl] = *reinterpret_cast<const f16x8*>(Ws + pl * XPLANE + (wc * 64 + ni * 32 + li) * XS + ks * 16 + hk * 8);
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) {
-                    f32x16 c = acc[mi][ni];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][1], wf[ni][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][2], wf[ni][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][0], wf[ni][2], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][1], wf[ni][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][0], wf[ni][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][0], wf[ni][0], c, 0, 0, 0);
-                    acc[mi][ni] = c;
+                    acl[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi][1], wf[ni][0], acl[mi][ni], 0, 0, 0);
+                    acl[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi][0], wf[ni][1], acl[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi][0], wf[ni][0], acc[mi][ni], 0, 0, 0);
                 }
         }
         __syncthreads();
@@ -365,38 +358,29 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x6_kernel(Gemm3Args p, const 
                     if (m0 + i >= p.M) continue;
                     crow = (size_t)(m0 + i);
                 }
-                p.c[crow * p.ldc + n] = acc[mi][ni][r] + bv;
+                p.c[crow * p.ldc + n] = acc[mi][ni][r] + acl[mi][ni][r] * kLoInv + bv;
             }
         }
     }
 }
 
-static inline uint16_t g_bf16_rne(float x) {
-    uint32_t u;
-    __builtin_memcpy(&u, &x, 4);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
-static inline float g_bf16_f32(uint16_t b) {
-    const uint32_t u = (uint32_t)b << 16;
-    float f;
-    __builtin_memcpy(&f, &u, 4);
-    return f;
+static inline uint16_t g_f16_bits(_Float16 h) {
+    uint16_t u;
+    __builtin_memcpy(&u, &h, 2);
+    return u;
 }
 
-// W [N][ldw] fp32 (first K columns valid) -> [n-tile][k-tile][plane][128][32] bf16 terms.
+// W [N][ldw] fp32 (first K columns valid) -> [n-tile][k-tile][plane][128][32] fp16 terms (hi, lo * 2^11).
 std::vector<uint16_t> pack_gemm_w3(const float* w, int N, int K, int ldw) {
     const int ntl = ceil_div(N, BN), ktl = ceil_div(K, BK);
-    std::vector<uint16_t> out((size_t)ntl * ktl * 3 * 128 * 32, 0);
+    std::vector<uint16_t> out((size_t)ntl * ktl * 2 * 128 * 32, 0);
     for (int n = 0; n < N; ++n)
         for (int k = 0; k < K; ++k) {
             const float x = w[(size_t)n * ldw + k];
-            const uint16_t h1 = g_bf16_rne(x);
-            const float r1 = x - g_bf16_f32(h1);
-            const uint16_t h2 = g_bf16_rne(r1);
-            const uint16_t h3 = g_bf16_rne(r1 - g_bf16_f32(h2));
-            const size_t base = (((size_t)(n / BN) * ktl + k / BK) * 3) * 4096 + (size_t)(n % BN) * 32 + (k % BK);
-            out[base] = h1; out[base + 4096] = h2; out[base + 8192] = h3;
+            const _Float16 h1 = (_Float16)x;
+            const _Float16 h2 = (_Float16)((x - (float)h1) * kLoScale);
+            const size_t base = (((size_t)(n / BN) * ktl + k / BK) * 2) * 4096 + (size_t)(n % BN) * 32 + (k % BK);
+            out[base] = g_f16_bits(h1); out[base + 4096] = g_f16_bits(h2);
         }
     return out;
 }
@@ -417,9 +401,9 @@ void launch_gemm(const GemmLaunch& g, hipStream_t s) {
             default: hipLaunchKernelGGL(split_a_kernel<GEMM_A_CONV>, sgrid, dim3(256), 0, s, a, g.a3); break;
         }
         const dim3 grid3(ceil_div(g.N, BN), mtiles3);
-        const size_t lds3 = (size_t)6 * XPLANE * 2;
-        if (g.mode == GEMM_A_CONV) DSMI_LAUNCH(gemm_bf16x6_kernel<true>, grid3, dim3(256), lds3, s, g.ev, a, (const uint16_t*)g.a3);
-        else DSMI_LAUNCH(gemm_bf16x6_kernel<false>, grid3, dim3(256), lds3, s, g.ev, a, (const uint16_t*)g.a3);
+        const size_t lds3 = (size_t)4 * XPLANE * 2;
+        if (g.mode == GEMM_A_CONV) DSMI_LAUNCH(gemm_f16x3_kernel<true>, grid3, dim3(256), lds3, s, g.ev, a, (const uint16_t*)g.a3);
+        else DSMI_LAUNCH(gemm_f16x3_kernel<false>, grid3, dim3(256), lds3, s, g.ev, a, (const uint16_t*)g.a3);
         return;
     }
     GemmArgs a;

@@ -33,10 +33,11 @@ sys.path.insert(0, ROOT)
 # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_BF16_MFMA_TFLOPS = 2500.0
-# The contraction kernels compute fp32-grade products as six bf16 MFMA products of three-term split
-# operands: the ceiling for ALGORITHMIC fp32 FLOPs on that path is the bf16 peak / 6.
-PEAK_SPLIT_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
-BF16X6_KERNELS = {"rnn_layer_persistent", "gemm", "gemm_l0", "conv2", "conv3"}
+# The contraction kernels compute fp32-grade products as three fp16 MFMA products of two-term split
+# operands: the ceiling for ALGORITHMIC fp32 FLOPs on that path is the fp16 peak / 3
+# (the fp16 and bf16 dense MFMA peaks are the same figure).
+PEAK_SPLIT_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3.0
+SPLIT_KERNELS = {"rnn_layer_persistent", "gemm", "gemm_l0", "conv2", "conv3"}
 PEAK_HBM_GBS = 8000.0
 
 # HBM/fabric bytes per launch from rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE,
@@ -183,11 +184,11 @@ def main():
             dom = max(tot, key=tot.get)
             s = stats[dom]
             ach = s["flops_per_launch"] / (s["avg_us"] * 1e-6) / 1e12
-            split = dom in BF16X6_KERNELS and os.environ.get("DSMI_RNN_MODE") != "steps"
+            split = dom in SPLIT_KERNELS and os.environ.get("DSMI_RNN_MODE") != "steps"
             peak = PEAK_SPLIT_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
             roof = dict(bound="mfma", kernel=dom, achieved=round(ach, 3), peak=round(peak, 1), unit="TFLOP/s",
                         frac=round(ach / peak, 4), traffic=PMC_TRAFFIC.get(dom),
-                        peak_note=("bf16 dense MFMA peak 2500 TFLOP/s / 6 products per fp32-grade multiply (executed bf16 rate = 6 x achieved)"
+                        peak_note=("fp16 dense MFMA peak 2500 TFLOP/s / 3 products per fp32-grade multiply (executed fp16 rate = 3 x achieved)"
                                    if split else "fp32 MFMA peak"),
                         avg_launch_us=round(s["avg_us"], 3), launches_per_step=s["launches"] // args.steps,
                         flops_per_launch=s["flops_per_launch"],
@@ -196,7 +197,7 @@ def main():
             "metric": "audio-seconds/sec (RTFx) recognize() on 10 s clips, batch=32",
             "value": round(value, 2), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32 (bf16x6 split-operand MFMA, fp32 accumulate)", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32 (two-term fp16 split operands, 3 MFMA products, fp32 accumulate)", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: 2conv + 5xBiGRU800 (DanSpeechPrimary per BASELINE), greedy CTC, "
                                    "batch=%d x %.0f s 16 kHz clips per GPU, STFT+forward+decode" % (B, c["seconds"]),
                        "clips_per_gpu": B, "clip_seconds": c["seconds"], "parallelism": "utterance-dp%d" % world,

@@ -187,7 +187,10 @@ extern "C" int dsmi_model_finalize(dsmi_model* m) {
         if (!w || !b || !bn_affine(m, "conv.seq_module." + std::to_string(3 * l + 1), s.co, s.co, a, bb)) return DSMI_ERR_NOT_READY;
         int rc;
         if ((rc = upload(m, pack_conv_weights(w->data.data(), l), &m->conv[l].wp))) return rc;
-        if (l > 0 && (rc = upload(m, pack_conv_w3(w->data.data(), s.co), &m->conv[l].wp3))) return rc;
+        if (l > 0) {
+            for (float v : w->data) if (!(std::fabs(v) < kF16Safe)) m->conv_mode = 0;    // split-fp16 operand range
+            if ((rc = upload(m, pack_conv_w_split(w->data.data(), s.co), &m->conv[l].wp_sp))) return rc;
+        }
         if ((rc = upload(m, b->data, &m->conv[l].bias))) return rc;
         if ((rc = upload(m, a, &m->conv[l].bn_a))) return rc;
         if ((rc = upload(m, bb, &m->conv[l].bn_b))) return rc;
@@ -219,13 +222,13 @@ extern "C" int dsmi_model_finalize(dsmi_model* m) {
         int rc;
         for (float v : wih) if (!(std::fabs(v) < kF16Safe)) m->gemm_mode = 0;     // split-fp16 operand range
         if ((rc = upload(m, wih, &r.wih))) return rc;
-        if ((rc = upload(m, pack_gemm_w3(wih.data(), g.Np, r.K, r.ldw), &r.wih3))) return rc;
+        if ((rc = upload(m, pack_gemm_w_split(wih.data(), g.Np, r.K, r.ldw), &r.wih_sp))) return rc;
         if ((rc = upload(m, bih, &r.bih))) return rc;
         for (int dd = 0; dd < g.D; ++dd) {
             // the split-fp16 operands hold |x| < 65504 only: a model beyond that stays on the fp32 kernels
             for (float v : wh[dd]->data) if (!(std::fabs(v) < kF16Safe)) m->rnn_mode = 0;
             if ((rc = upload(m, pack_whh(g, wh[dd]->data.data()), &r.whh[dd]))) return rc;
-            if ((rc = upload(m, pack_whh3(g, wh[dd]->data.data()), &r.whh3[dd]))) return rc;
+            if ((rc = upload(m, pack_whh_split(g, wh[dd]->data.data()), &r.whh_sp[dd]))) return rc;
             if ((rc = upload(m, bh[dd]->data, &r.bhh[dd]))) return rc;
         }
         if (l > 0) {  // model.py:403-404: BatchNorm1d(H) in front of layers >= 1
@@ -303,8 +306,8 @@ extern "C" int dsmi_reserve(dsmi_model* m, int max_B, int max_T) {
     if ((rc = ws_alloc(m, &m->conv_buf[0], conv_max))) return rc;
     if ((rc = ws_alloc(m, &m->conv_buf[1], d.conv_layers > 1 ? conv_max : 1))) return rc;
     for (int i = 0; i < 2; ++i) {   // split intermediates: layer 0 -> buf3[0], layer 1 -> buf3[1] (3-conv models)
-        const size_t n = i < d.conv_layers - 1 ? (size_t)max_B * m->conv_fo[i] * 3 * std::max(To, 1) * 32 : 1;
-        if ((rc = ws_alloc(m, &m->conv_buf3[i], n))) return rc;
+        const size_t n = i < d.conv_layers - 1 ? (size_t)max_B * m->conv_fo[i] * 2 * std::max(To, 1) * 32 : 1;
+        if ((rc = ws_alloc(m, &m->conv_buf_sp[i], n))) return rc;
     }
     const size_t rows = (size_t)To * max_B;
     if ((rc = ws_alloc(m, &m->xp, rows * m->geom.Np))) return rc;
@@ -324,14 +327,14 @@ extern "C" int dsmi_reserve(dsmi_model* m, int max_B, int max_T) {
         HIP_OK(m, hipMemset(m->hpack, 0, n * sizeof(float)));
     }
     {
-        const size_t n = (size_t)2 * m->geom.D * ceil_div(max_B, 32) * ceil_div(m->geom.nq, 2) * 3 * 64 * 8;
-        if ((rc = ws_alloc(m, &m->hpack3, n))) return rc;
-        HIP_OK(m, hipMemset(m->hpack3, 0, n * sizeof(uint16_t)));
+        const size_t n = (size_t)2 * m->geom.D * ceil_div(max_B, 32) * ceil_div(m->geom.nq, 2) * 2 * 64 * 8;
+        if ((rc = ws_alloc(m, &m->hpack_sp, n))) return rc;
+        HIP_OK(m, hipMemset(m->hpack_sp, 0, n * sizeof(uint16_t)));
     }
     {
         const size_t mt = (size_t)max_B * ceil_div(std::max(To, 1), 128) + ceil_div((int)rows, 128) + 1;
         const size_t kt = (size_t)ceil_div(std::max(m->I0, m->Hs), 32);
-        if ((rc = ws_alloc(m, &m->a3, mt * kt * 3 * 4096))) return rc;
+        if ((rc = ws_alloc(m, &m->a_sp, mt * kt * 2 * 4096))) return rc;
     }
     if ((rc = ws_alloc(m, &m->pcnt, (size_t)m->geom.D * ceil_div(max_B, 32) * std::max(To, 1)))) return rc;
     if ((rc = ws_alloc(m, &m->perr, (size_t)4))) return rc;
@@ -378,7 +381,7 @@ static int check_batch(dsmi_model* m, const int32_t* lens, int B, int T) {
 
 static int run_conv(dsmi_model* m, const float* feat, int B, int T, int To, int ys, hipStream_t s, const float** out) {
     const float* x = feat;
-    const uint16_t* x3 = nullptr;
+    const uint16_t* x_sp = nullptr;
     int ti = T, xs = T;
     const int L = m->desc.conv_layers;
     for (int l = 0; l < L; ++l) {
@@ -386,25 +389,25 @@ static int run_conv(dsmi_model* m, const float* feat, int B, int T, int To, int 
         double fl = 0;
         for (int i = 0; i < B; ++i) fl += 2.0 * sp.co * m->conv_fo[l] * (double)m->host_out_lens[i] * sp.ci * sp.kf * sp.kt;
         const double by = 4.0 * B * ((double)sp.ci * m->conv_fi[l] * ti + (double)sp.co * m->conv_fo[l] * To);
-        const bool next_bf16 = m->conv_mode == 1 && l + 1 < L;       // the consumer is a bf16x6 conv layer
-        if (x3) {
-            ConvBf16Launch c;
-            c.x3 = x3; c.wp3 = m->conv[l].wp3; c.bias = m->conv[l].bias; c.bn_a = m->conv[l].bn_a; c.bn_b = m->conv[l].bn_b;
-            c.out_lens_dev = m->lens_dev; c.y = next_bf16 ? nullptr : m->conv_buf[l & 1]; c.y3 = next_bf16 ? m->conv_buf3[l] : nullptr;
+        const bool next_split = m->conv_mode == 1 && l + 1 < L;       // the consumer is a split-fp16 conv layer
+        if (x_sp) {
+            ConvSplitLaunch c;
+            c.x_sp = x_sp; c.wp_sp = m->conv[l].wp_sp; c.bias = m->conv[l].bias; c.bn_a = m->conv[l].bn_a; c.bn_b = m->conv[l].bn_b;
+            c.out_lens_dev = m->lens_dev; c.y = next_split ? nullptr : m->conv_buf[l & 1]; c.y_sp = next_split ? m->conv_buf_sp[l] : nullptr;
             c.B = B; c.co = sp.co; c.fi = m->conv_fi[l]; c.fo = m->conv_fo[l]; c.ti = ti; c.to = To; c.ys = ys;
             c.ev = timer_arm(m, KK_CONV1 + l, true, fl, by);
-            launch_conv_bf16(c, s);
-            x = c.y; x3 = c.y3;
+            launch_conv_split(c, s);
+            x = c.y; x_sp = c.y_sp;
         } else {
             ConvLaunch c;
             c.x = x; c.y = m->conv_buf[l & 1]; c.wp = m->conv[l].wp; c.bias = m->conv[l].bias;
             c.bn_a = m->conv[l].bn_a; c.bn_b = m->conv[l].bn_b; c.out_lens_dev = m->lens_dev;
             c.B = B; c.ci = sp.ci; c.co = sp.co; c.fi = m->conv_fi[l]; c.fo = m->conv_fo[l];
             c.ti = ti; c.to = To; c.xs = xs; c.ys = ys; c.layer = l;
-            c.y3 = next_bf16 ? m->conv_buf3[l] : nullptr;
+            c.y_sp = next_split ? m->conv_buf_sp[l] : nullptr;
             c.ev = timer_arm(m, KK_CONV1 + l, true, fl, by);
             launch_conv(c, s);
-            x = c.y; x3 = c.y3;
+            x = c.y; x_sp = c.y_sp;
         }
         ti = To; xs = ys;
     }
@@ -424,8 +427,8 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
         // whole layer in one launch; counters are single-use per step, zeroed right before
         RnnPersistLaunch pl;
         pl.g = m->geom;
-        for (int dd = 0; dd < 2; ++dd) { pl.whh3[dd] = m->rnn[l].whh3[dd]; pl.bhh[dd] = m->rnn[l].bhh[dd]; pl.out[dd] = m->hbuf[dst][dd]; }
-        pl.xp = m->xp; pl.lens_dev = m->lens_dev; pl.hpack3 = m->hpack3; pl.counters = m->pcnt; pl.err = m->perr; pl.B = B; pl.T = To;
+        for (int dd = 0; dd < 2; ++dd) { pl.whh_sp[dd] = m->rnn[l].whh_sp[dd]; pl.bhh[dd] = m->rnn[l].bhh[dd]; pl.out[dd] = m->hbuf[dst][dd]; }
+        pl.xp = m->xp; pl.lens_dev = m->lens_dev; pl.hpack_sp = m->hpack_sp; pl.counters = m->pcnt; pl.err = m->perr; pl.B = B; pl.T = To;
         (void)hipMemsetAsync(m->pcnt, 0, sizeof(unsigned) * (size_t)m->geom.D * ceil_div(B, 32) * To, s);
         // Persistent kernels need every workgroup co-resident, so two of them must never share
         // the device (e.g. two handles on two streams): chain them through a per-device event.
@@ -466,8 +469,8 @@ static GemmLaunch xproj_gemm(dsmi_model* m, int l, int B, int To) {
     GemmLaunch gl{};
     const RnnW& r = m->rnn[l];
     gl.w = r.wih; gl.bias = r.bih; gl.c = m->xp;
-    gl.w3 = m->gemm_mode == 1 ? r.wih3 : nullptr;
-    gl.a3 = m->a3;
+    gl.w_sp = m->gemm_mode == 1 ? r.wih_sp : nullptr;
+    gl.a_sp = m->a_sp;
     gl.M = To * B; gl.N = m->geom.Np; gl.K = r.K; gl.ldw = r.ldw; gl.ldc = m->geom.Np;
     gl.B = B; gl.T = To;
     return gl;
@@ -731,8 +734,8 @@ extern "C" int dsmi_debug_persist_stamps(dsmi_model* m, int layer, int B, int To
     HIP_OK(m, hipMemset(m->xp, 0, sizeof(float) * (size_t)To * B * m->geom.Np));
     RnnPersistLaunch pl;
     pl.g = m->geom;
-    for (int dd = 0; dd < 2; ++dd) { pl.whh3[dd] = m->rnn[layer].whh3[dd]; pl.bhh[dd] = m->rnn[layer].bhh[dd]; pl.out[dd] = m->hbuf[0][dd]; }
-    pl.xp = m->xp; pl.lens_dev = m->lens_dev; pl.hpack3 = m->hpack3; pl.counters = m->pcnt; pl.err = m->perr; pl.B = B; pl.T = To;
+    for (int dd = 0; dd < 2; ++dd) { pl.whh_sp[dd] = m->rnn[layer].whh_sp[dd]; pl.bhh[dd] = m->rnn[layer].bhh[dd]; pl.out[dd] = m->hbuf[0][dd]; }
+    pl.xp = m->xp; pl.lens_dev = m->lens_dev; pl.hpack_sp = m->hpack_sp; pl.counters = m->pcnt; pl.err = m->perr; pl.B = B; pl.T = To;
     pl.d0 = 0; pl.ny = m->geom.D;
     for (int rep = 0; rep < 2; ++rep) {     // first pass warms up, second is stamped
         HIP_OK(m, hipMemset(m->pcnt, 0, sizeof(unsigned) * (size_t)m->geom.D * To));

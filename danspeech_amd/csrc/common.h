@@ -50,23 +50,23 @@ struct ConvLaunch {
     const float* x; float* y; const float* wp; const float* bias; const float* bn_a; const float* bn_b;
     const int32_t* out_lens_dev;
     int B, ci, co, fi, fo, ti, to, xs, ys, layer;  // layer index selects the compile-time geometry
-    uint16_t* y3 = nullptr;   // optional: split channels-last output [B][fo][3][to][32] bf16 (32-channel layers)
+    uint16_t* y_sp = nullptr;   // optional: split channels-last output [B][fo][2][to][32] fp16 terms (hi, lo * 2^11) (32-channel layers)
     EvPair ev;
 };
 void launch_conv(const ConvLaunch& p, hipStream_t s);
 
-// conv_bf16.hip: the 32-input-channel conv layers on the bf16 MFMA with three-term split operands.
-struct ConvBf16Launch {
-    const uint16_t* x3;       // [B][fi][3][ti][32] bf16 (previous layer's split output)
-    const uint16_t* wp3;      // pack_conv_w3
+// conv_split.hip: the 32-input-channel conv layers on the fp16 MFMA with two-term split operands.
+struct ConvSplitLaunch {
+    const uint16_t* x_sp;       // [B][fi][2][ti][32] fp16 terms (previous layer's split output)
+    const uint16_t* wp_sp;      // pack_conv_w_split
     const float* bias; const float* bn_a; const float* bn_b; const int32_t* out_lens_dev;
     float* y;                 // [B][co][fo][ys] fp32 (last conv layer) ...
-    uint16_t* y3;             // ... or split channels-last for another bf16 conv layer (co == 32)
+    uint16_t* y_sp;             // ... or split channels-last for another split-fp16 conv layer (co == 32)
     int B, co, fi, fo, ti, to, ys;
     EvPair ev;
 };
-void launch_conv_bf16(const ConvBf16Launch& p, hipStream_t s);
-std::vector<uint16_t> pack_conv_w3(const float* w, int co_total);
+void launch_conv_split(const ConvSplitLaunch& p, hipStream_t s);
+std::vector<uint16_t> pack_conv_w_split(const float* w, int co_total);
 // Host-side weight packer: w [co][ci][kf][kt] -> kernel layout. Returns packed floats.
 std::vector<float> pack_conv_weights(const float* w, int layer);
 
@@ -80,15 +80,15 @@ struct GemmLaunch {
     int mode;
     const float* a; const float* a2; const float* alpha; const float* beta;
     const float* w; const float* bias; float* c;
-    const uint16_t* w3 = nullptr;   // pack_gemm_w3 image of w: when set (with a3), the bf16x6 split-operand path runs
-    uint16_t* a3 = nullptr;         // workspace for the split A operand: [m-tiles][k-tiles][3][128][32] bf16
+    const uint16_t* w_sp = nullptr;   // pack_gemm_w_split image of w: when set (with a_sp), the split-fp16 path runs
+    uint16_t* a_sp = nullptr;         // workspace for the split A operand: [m-tiles][k-tiles][2][128][32] fp16
     int M, N, K;       // N, K as stored (W is [N][K] row-major, K % 4 == 0 guaranteed by packing)
     int lda, ldw, ldc;
     int B, T, ys;      // GEMM_A_CONV: batch, frames per clip, time stride
     EvPair ev;
 };
 void launch_gemm(const GemmLaunch& p, hipStream_t s);
-std::vector<uint16_t> pack_gemm_w3(const float* w, int N, int K, int ldw);
+std::vector<uint16_t> pack_gemm_w_split(const float* w, int N, int K, int ldw);
 
 // rnn_step.hip: one time step of both directions of one recurrent layer.
 struct RnnGeom {
@@ -129,9 +129,9 @@ void launch_rnn_step(const RnnStepLaunch& p, hipStream_t s);
 // counter-based hand-off of h between workgroups).  Needs every workgroup co-resident.
 struct RnnPersistLaunch {
     RnnGeom g;
-    const uint16_t* whh3[2];     // pack_whh3 output per direction
+    const uint16_t* whh_sp[2];     // pack_whh_split output per direction
     const float* bhh[2]; const float* xp; float* out[2];
-    const int32_t* lens_dev; uint16_t* hpack3;   // [2][D*ceil(B/32)][npair][3][64][8] bf16
+    const int32_t* lens_dev; uint16_t* hpack_sp;   // [2][D*ceil(B/32)][npair][2][64][8] fp16
     unsigned* counters;          // [D * ceil(B/32)][T], zeroed before the launch
     unsigned* err;               // one word, set on a wait timeout
     int B, T;
@@ -140,7 +140,7 @@ struct RnnPersistLaunch {
     unsigned long long* dbg = nullptr;   // diagnostics: accumulated per-wave phase times
 };
 bool rnn_persist_eligible(const RnnGeom& g, int B, int n_cus);
-std::vector<uint16_t> pack_whh3(const RnnGeom& g, const float* w_hh);
+std::vector<uint16_t> pack_whh_split(const RnnGeom& g, const float* w_hh);
 bool launch_rnn_persist(const RnnPersistLaunch& p, hipStream_t s);
 
 // head.hip

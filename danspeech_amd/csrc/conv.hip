@@ -62,10 +62,10 @@ struct ConvArgs {
     const float* x; float* y; const float* wp; const float* bias; const float* bn_a; const float* bn_b;
     const int32_t* out_lens;
     int B, fi, fo, ti, to, xs, ys;
-    uint16_t* y3;    // when set: write [b][f][plane][t][32] three-term bf16 instead of y (feeds conv_bf16.hip)
+    uint16_t* y_sp;    // when set: write [b][f][plane 2][t][32] fp16 terms (hi, lo * 2^11) instead of y (feeds conv_split.hip)
 };
 
-using bf16x4c = __attribute__((ext_vector_type(4))) __bf16;
+using f16x4c = __attribute__((ext_vector_type(4))) _Float16;
 using u32x4c = __attribute__((ext_vector_type(4))) unsigned int;
 
 template <int L>
@@ -79,11 +79,11 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs p) {
     const int f = f0 + wv;
     const int olen = p.out_lens[b];
 
-    if (t0 >= olen && p.y3) {   // fully masked tile, split channels-last output
-        for (int idx = tid; idx < NF * 3 * TT * 4; idx += 256) {
-            const int part = idx & 3, tl = (idx >> 2) % TT, pl = (idx / (4 * TT)) % 3, ff = idx / (4 * TT * 3);
+    if (t0 >= olen && p.y_sp) {   // fully masked tile, split channels-last output
+        for (int idx = tid; idx < NF * 2 * TT * 4; idx += 256) {
+            const int part = idx & 3, tl = (idx >> 2) % TT, pl = (idx / (4 * TT)) % 2, ff = idx / (4 * TT * 2);
             if (f0 + ff < p.fo && t0 + tl < p.to)
-                *reinterpret_cast<u32x4c*>(reinterpret_cast<__bf16*>(p.y3) + ((((size_t)b * p.fo + f0 + ff) * 3 + pl) * p.to + t0 + tl) * 32 + part * 8) = u32x4c{0, 0, 0, 0};
+                *reinterpret_cast<u32x4c*>(reinterpret_cast<_Float16*>(p.y_sp) + ((((size_t)b * p.fo + f0 + ff) * 2 + pl) * p.to + t0 + tl) * 32 + part * 8) = u32x4c{0, 0, 0, 0};
         }
         return;
     }
@@ -155,30 +155,27 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs p) {
     }
 
     if (f >= p.fo) return;
-    if (p.y3) {
-        // ---- epilogue for a bf16x6 consumer: 4 consecutive channels per store, x = hi + mid + lo
+    if (p.y_sp) {
+        // ---- epilogue for a split-fp16 consumer: 4 consecutive channels per store, x = hi + lo * 2^-11
 #pragma unroll
         for (int tt = 0; tt < NTT; ++tt) {
             const int t = t0 + tt * 32 + li;
             if (t >= p.to) continue;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                bf16x4c h, m, l;
+                f16x4c h, l;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int co = q + 8 * g + 4 * hk;
                     float v = (acc[0][tt][4 * g + q] + p.bias[co]) * p.bn_a[co] + p.bn_b[co];
                     v = fminf(fmaxf(v, 0.f), 20.f);
                     v = t < olen ? v : 0.f;
-                    const __bf16 a = (__bf16)v;
-                    const float r1 = v - (float)a;
-                    const __bf16 bm = (__bf16)r1;
-                    h[q] = a; m[q] = bm; l[q] = (__bf16)(r1 - (float)bm);
+                    const _Float16 a = (_Float16)v;
+                    h[q] = a; l[q] = (_Float16)((v - (float)a) * 2048.f);
                 }
-                __bf16* base = reinterpret_cast<__bf16*>(p.y3) + ((((size_t)b * p.fo + f) * 3) * (size_t)p.to + t) * 32 + 8 * g + 4 * hk;
-                *reinterpret_cast<bf16x4c*>(base) = h;
-                *reinterpret_cast<bf16x4c*>(base + (size_t)p.to * 32) = m;
-                *reinterpret_cast<bf16x4c*>(base + (size_t)2 * p.to * 32) = l;
+                _Float16* base = reinterpret_cast<_Float16*>(p.y_sp) + ((((size_t)b * p.fo + f) * 2) * (size_t)p.to + t) * 32 + 8 * g + 4 * hk;
+                *reinterpret_cast<f16x4c*>(base) = h;
+                *reinterpret_cast<f16x4c*>(base + (size_t)p.to * 32) = l;
             }
         }
         return;
@@ -205,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs p) {
 template <int L>
 static void launch_layer(const ConvLaunch& c, hipStream_t s) {
     using D = CD<L>;
-    ConvArgs a{c.x, c.y, c.wp, c.bias, c.bn_a, c.bn_b, c.out_lens_dev, c.B, c.fi, c.fo, c.ti, c.to, c.xs, c.ys, c.y3};
+    ConvArgs a{c.x, c.y, c.wp, c.bias, c.bn_a, c.bn_b, c.out_lens_dev, c.B, c.fi, c.fo, c.ti, c.to, c.xs, c.ys, c.y_sp};
     dim3 grid(ceil_div(c.to, TT), ceil_div(c.fo, NF), c.B);
     const size_t lds = (size_t)D::NBUF * D::CHUNK * sizeof(float);
     DSMI_LAUNCH(conv_kernel<L>, grid, dim3(256), lds, s, c.ev, a);

@@ -1,0 +1,246 @@
+// Conv2d (32 input channels) + bias + BatchNorm2d(eval) + Hardtanh(0,20) + time mask on the fp16
+// MFMA with two-term split operands (x = hi + lo * 2^-11, three products, two fp32 accumulators:
+// better than fp32-MFMA accuracy, see gemm.hip / tools/exp/bf16x6_test.hip).  Inputs are Hardtanh
+// outputs in [0, 20] and the weights are range-checked at load time, so fp16's 65504 is never near.
+//
+// Replaces the 2nd and 3rd (Conv2d, BatchNorm2d, Hardtanh) triples of the reference's conv stack
+// and their MaskConv zeroing (danspeech/deepspeech/model.py:65-81, 372-374, 389-391), i.e. the
+// layers that hold 89 % / 97 % of the conv FLOPs.  conv.hip (fp32 MFMA) keeps the
+// first layer (1 input channel) and remains the plain fp32 statement of all three.
+//
+// Implicit GEMM with the INPUT CHANNELS as the MFMA's K: one v_mfma_f32_32x32x16_f16 contracts
+// 16 input channels of one kernel tap (kf, kt); A = weights (row = output channel, pre-split and
+// packed on the host in lane order), B = input (col = output time step).  The input arrives
+// already split and channels-last, [b][f][plane 2][t][32 ci] fp16, written by the previous layer's
+// epilogue, so that a lane's 8-channel B fragment is ONE aligned 16-byte LDS read and staging is a
+// plain copy.  Workgroup = 4 waves = 4 consecutive output rows f x 64 output steps x all output
+// channels; per kernel row kf the four input rows it needs (one per wave) are staged in LDS with
+// an 80-byte pitch per time step (16 consecutive steps hit 64 distinct banks), the next kf's
+// rows are in flight in registers during the MFMAs, and the weight fragments of the next
+// (kt, channel half) are requested before the current one's MFMAs (they come from L2: ~600 cycles).
+#include "common.h"
+
+namespace dsmi {
+
+namespace {
+
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
+constexpr float kLoScale = 2048.f, kLoInv = 1.f / 2048.f;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+
+constexpr int BNF = 4;                 // output rows per workgroup (one per wave)
+constexpr int BTT = 64;                // output steps per workgroup (2 MFMA column tiles per wave)
+constexpr int KT = 11, KF = 21, SF = 2, PF = 10, PT = 5, CI = 32;
+constexpr int WIN = BTT + KT - 1;      // staged time steps per row: 74
+constexpr int NPL = 2;                 // operand planes: hi, lo * 2^11
+constexpr int PITCH = 40;              // halfs per staged time step (32 ci + 8 pad = 80 B)
+constexpr int ROWPLANE = WIN * PITCH;  // halfs per (row, plane)
+constexpr int NCHUNK = BNF * NPL * WIN * 4;         // 16-byte chunks staged per kf: 2368
+constexpr int CPT = (NCHUNK + 255) / 256;           // chunks per thread: 10
+
+struct ConvSplitArgs {
+    const uint16_t* x_sp; const uint16_t* wp_sp; const float* bias; const float* bn_a; const float* bn_b;
+    const int32_t* out_lens; float* y; uint16_t* y_sp;
+    int B, fi, fo, ti, to, ys;
+    int nco;        // 32-channel output tiles (1: 32 channels, 3: 96); blockIdx.z = b * nco + tile
+};
+
+// Shared epilogue piece: 4 consecutive channels of one (b, f, t) -> two 8-byte stores, channels-last split.
+__device__ __forceinline__ void store_split4(uint16_t* y_sp, size_t bf_index, int t_stride, int t, int c0, const float (&v)[4]) {
+    f16x4 h, l;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const _Float16 hi = (_Float16)v[c];
+        h[c] = hi; l[c] = (_Float16)((v[c] - (float)hi) * kLoScale);
+    }
+    _Float16* base = reinterpret_cast<_Float16*>(y_sp) + ((bf_index * NPL) * (size_t)t_stride + t) * 32 + c0;
+    *reinterpret_cast<f16x4*>(base) = h;
+    *reinterpret_cast<f16x4*>(base + (size_t)t_stride * 32) = l;
+}
+
+// One workgroup = one 32-channel output tile (two accumulators per MFMA tile leave no room for three
+// tiles' worth in 256 VGPRs; the 96-channel third layer runs its tiles as separate workgroups).
+template <bool SPLIT_OUT>
+__global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvSplitArgs p) {
+    constexpr int NCO = 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char csm[];
+    _Float16* Xs = reinterpret_cast<_Float16*>(csm);  // [4 rows][2 planes][WIN][PITCH]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, hk = lane >> 5;
+    const int t0 = blockIdx.x * BTT, f0 = blockIdx.y * BNF;
+    const int b = blockIdx.z / p.nco, ct = blockIdx.z - b * p.nco;
+    const int f = f0 + wv;
+    const int olen = p.out_lens[b];
+    const int CO = 32 * p.nco;
+
+    if (t0 >= olen) {     // fully masked tile: zeros in the consumer's format
+        if (SPLIT_OUT) {
+            for (int idx = tid; idx < BNF * NPL * BTT * 4; idx += 256) {
+                const int part = idx & 3, tl = (idx >> 2) % BTT, pl = (idx / (4 * BTT)) % NPL, ff = idx / (4 * BTT * NPL);
+                if (f0 + ff < p.fo && t0 + tl < p.to)
+                    *reinterpret_cast<u32x4*>(reinterpret_cast<_Float16*>(p.y_sp) + ((((size_t)b * p.fo + f0 + ff) * NPL + pl) * p.to + t0 + tl) * 32 + part * 8) = u32x4{0, 0, 0, 0};
+            }
+        } else {
+            for (int idx = tid; idx < 32 * BNF * BTT; idx += 256) {
+                const int tl = idx % BTT, ff = (idx / BTT) % BNF, co = ct * 32 + idx / (BTT * BNF);
+                if (f0 + ff < p.fo && t0 + tl < p.to) p.y[(((size_t)b * CO + co) * p.fo + f0 + ff) * p.ys + t0 + tl] = 0.f;
+            }
+        }
+        return;
+    }
+
+    f32x16 acc[NCO][2], acl[NCO][2];      // hi.hi ; (hi.lo + lo.hi) * 2^11
+#pragma unroll
+    for (int c = 0; c < NCO; ++c)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[c][tt][r] = 0.f; acl[c][tt][r] = 0.f; }
+
+    // ---- staging: chunk id -> (row, plane, step, 16-byte part); global source is a plain copy
+    u32x4 stg[CPT];
+    auto load_rows = [&](int kf) {
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int c = tid + 256 * i;
+            u32x4 v = {0, 0, 0, 0};
+            if (c < NCHUNK) {
+                const int part = c & 3, st = (c >> 2) % WIN, rp = (c >> 2) / WIN;     // rp = row * NPL + plane
+                const int row = rp / NPL, pl = rp - row * NPL;
+                const int fin = SF * (f0 + row) + kf - PF, tin = t0 - PT + st;
+                if (fin >= 0 && fin < p.fi && tin >= 0 && tin < p.ti)
+                    v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const _Float16*>(p.x_sp) +
+                                                        ((((size_t)b * p.fi + fin) * NPL + pl) * p.ti + tin) * 32 + part * 8);
+            }
+            stg[i] = v;
+        }
+    };
+    auto store_rows = [&]() {
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int c = tid + 256 * i;
+            if (c < NCHUNK) {
+                const int part = c & 3, st = (c >> 2) % WIN, rp = (c >> 2) / WIN;
+                *reinterpret_cast<u32x4*>(Xs + rp * ROWPLANE + st * PITCH + part * 8) = stg[i];
+            }
+        }
+    };
+
+    const u32x4* wbase = reinterpret_cast<const u32x4*>(p.wp_sp) + lane;
+    const _Float16* xrow = Xs + (wv * NPL) * ROWPLANE + li * PITCH + hk * 8;
+    // weight fragments of step q = (kf * KT + kt) * 2 + half, one step ahead of the MFMAs
+    f16x8 wf[NCO][NPL], wn[NCO][NPL];
+    auto load_w = [&](int q, f16x8 (&dst)[NCO][NPL]) {
+#pragma unroll
+        for (int c = 0; c < NCO; ++c)
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl)
+                dst[c][pl] = __builtin_bit_cast(f16x8, wbase[(((size_t)q * p.nco + ct + c) * NPL + pl) * 64]);
+    };
+    constexpr int NQ = KF * KT * 2;
+    load_w(0, wn);
+
+    load_rows(0);
+    for (int kf = 0; kf < KF; ++kf) {
+        store_rows();
+        __syncthreads();
+        if (kf + 1 < KF) load_rows(kf + 1);
+        if (f < p.fo) {
+#pragma unroll 1
+            for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int q = (kf * KT + kt) * 2 + half;
+#pragma unroll
+                    for (int c = 0; c < NCO; ++c)
+#pragma unroll
+                        for (int pl = 0; pl < NPL; ++pl) wf[c][pl] = wn[c][pl];
+                    load_w(min(q + 1, NQ - 1), wn);
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) {
+                        f16x8 xf[NPL];
+#pragma unroll
+                        for (int pl = 0; pl < NPL; ++pl)
+                            xf[pl] = *reinterpret_cast<const f16x8*>(xrow + pl * ROWPLANE + (tt * 32 + kt) * PITCH + half * 16);
+#pragma unroll
+                        for (int c = 0; c < NCO; ++c) {
+                            acl[c][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[c][1], xf[0], acl[c][tt], 0, 0, 0);
+                            acl[c][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[c][0], xf[1], acl[c][tt], 0, 0, 0);
+                            acc[c][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[c][0], xf[0], acc[c][tt], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    if (f >= p.fo) return;
+    // ---- epilogue: D[i][j]: i = co (regs), j = lane&31 = time
+#pragma unroll
+    for (int c = 0; c < NCO; ++c)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int t = t0 + tt * 32 + li;
+            if (t >= p.to) continue;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int co = (ct + c) * 32 + q + 8 * g + 4 * hk;
+                    float x = (acc[c][tt][4 * g + q] + acl[c][tt][4 * g + q] * kLoInv + p.bias[co]) * p.bn_a[co] + p.bn_b[co];
+                    x = fminf(fmaxf(x, 0.f), 20.f);
+                    v[q] = t < olen ? x : 0.f;
+                }
+                if (SPLIT_OUT) {
+                    store_split4(p.y_sp, (size_t)b * p.fo + f, p.to, t, 8 * g + 4 * hk, v);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        p.y[(((size_t)b * CO + (ct + c) * 32 + q + 8 * g + 4 * hk) * p.fo + f) * p.ys + t] = v[q];
+                }
+            }
+        }
+}
+
+inline uint16_t c_f16_bits(_Float16 h) {
+    uint16_t u;
+    __builtin_memcpy(&u, &h, 2);
+    return u;
+}
+
+}  // namespace
+
+// w [co][32][21][11] fp32 -> [kf][kt][half][co-tile][plane][lane][8] fp16 terms (hi, lo * 2^11); lane (i = co in
+// tile, h) element e holds input channel 16*half + 8*h + e.
+std::vector<uint16_t> pack_conv_w_split(const float* w, int co_total) {
+    const int nco = co_total / 32;
+    std::vector<uint16_t> out((size_t)KF * KT * 2 * nco * NPL * 64 * 8, 0);
+    for (int kf = 0; kf < KF; ++kf)
+        for (int kt = 0; kt < KT; ++kt)
+            for (int half = 0; half < 2; ++half)
+                for (int ct = 0; ct < nco; ++ct)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 8; ++e) {
+                            const int co = ct * 32 + (lane & 31), ci = 16 * half + 8 * (lane >> 5) + e;
+                            const float x = w[(((size_t)co * CI + ci) * KF + kf) * KT + kt];
+                            const _Float16 h1 = (_Float16)x;
+                            const _Float16 h2 = (_Float16)((x - (float)h1) * kLoScale);
+                            const size_t base = ((((((size_t)kf * KT + kt) * 2 + half) * nco + ct) * NPL) * 64 + lane) * 8 + e;
+                            out[base] = c_f16_bits(h1); out[base + 512] = c_f16_bits(h2);
+                        }
+    return out;
+}
+
+void launch_conv_split(const ConvSplitLaunch& c, hipStream_t s) {
+    ConvSplitArgs a{c.x_sp, c.wp_sp, c.bias, c.bn_a, c.bn_b, c.out_lens_dev, c.y, c.y_sp, c.B, c.fi, c.fo, c.ti, c.to, c.ys, c.co / 32};
+    const dim3 grid(ceil_div(c.to, BTT), ceil_div(c.fo, BNF), c.B * a.nco);
+    const size_t lds = (size_t)BNF * NPL * ROWPLANE * 2;   // 47,360 B
+    if (c.y_sp) DSMI_LAUNCH((conv_f16x3_kernel<true>), grid, dim3(256), lds, s, c.ev, a);
+    else DSMI_LAUNCH((conv_f16x3_kernel<false>), grid, dim3(256), lds, s, c.ev, a);
+}
+
+}  // namespace dsmi

@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
 // rate, so the product costs 3/16 of the fp32 one; measured error vs fp64 at K = 800: 2.6e-7
 // against 1.0e-6 for the fp32 MFMA chain (tools/exp/bf16x6_test.hip).  Operand ranges must stay
 // below fp16's 65504: the caller checks weights and BatchNorm bounds at load time (api.hip).
-// W is split and tiled once on the host (pack_gemm_w3: [n-tile][k-tile][plane][128][32] fp16, so
+// W is split and tiled once on the host (pack_gemm_w_split: [n-tile][k-tile][plane][128][32] fp16, so
 // the operand loads are fully coalesced 16-byte copies); the activations are split ONCE per GEMM
 // by split_a_kernel, fused with the same producer transforms as the fp32 kernel (direction sum +
 // BatchNorm1d, conv transpose), into the same tiled form.  Tile 128x128x32, 4 waves in 2x2, one
@@ -204,21 +204,21 @@ constexpr int XPLANE = 128 * XS;       // elements per plane of one operand tile
 constexpr int XT_STRIDE = 129;         // f32 transpose tile [32 k][129] (GEMM_A_CONV)
 constexpr float kLoScale = 2048.f, kLoInv = 1.f / 2048.f;
 
-struct Gemm3Args {
+struct GemmSplitArgs {
     const float* a; const float* a2; const float* alpha; const float* beta;
-    const uint16_t* w3; const float* bias; float* c;
+    const uint16_t* w_sp; const float* bias; float* c;
     int M, N, K, lda, ldc, B, T, ys, tiles_per_b, ktiles;
 };
 
 // Pass 1: form the A operand ONCE (producer transforms + two-term split) as tiled fp16 planes
 // [m-tile][k-tile][plane][128][32]; every one of the N/128 column tiles then reads it as is.
 template <int MODE>
-__global__ __launch_bounds__(256) void split_a_kernel(Gemm3Args p, uint16_t* a3) {
+__global__ __launch_bounds__(256) void split_a_kernel(GemmSplitArgs p, uint16_t* a_sp) {
     __shared__ float Tf[MODE == GEMM_A_CONV ? 32 * XT_STRIDE : 1];
     const int tid = threadIdx.x;
     const int kt = blockIdx.x, mt = blockIdx.y;
     const int k0 = kt * BK;
-    _Float16* tile = reinterpret_cast<_Float16*>(a3) + ((size_t)mt * p.ktiles + kt) * (2 * 4096);
+    _Float16* tile = reinterpret_cast<_Float16*>(a_sp) + ((size_t)mt * p.ktiles + kt) * (2 * 4096);
     f32x4 v[4];
     if (MODE == GEMM_A_CONV) {
         const int bb = mt / p.tiles_per_b, t0 = (mt % p.tiles_per_b) * BM;
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void split_a_kernel(Gemm3Args p, uint16_t* a3)
 
 // Pass 2: C = A2 . W2^T + bias on v_mfma_f32_32x32x16_f16, three products per (A, W) fragment pair.
 template <bool CONV_ROWS>
-__global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(Gemm3Args p, const uint16_t* a3) {
+__global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmSplitArgs p, const uint16_t* a_sp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
     _Float16* As = reinterpret_cast<_Float16*>(smem3);        // [2][128][XS]
     _Float16* Ws = As + 2 * XPLANE;                            // [2][128][XS]
@@ -283,8 +283,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(Gemm3Args p, const u
     if (CONV_ROWS) { bb = mt / p.tiles_per_b; t0 = (mt % p.tiles_per_b) * BM; }
 
     u32x4 ra[4], rw[4];
-    const u32x4* atile = reinterpret_cast<const u32x4*>(a3) + (size_t)mt * p.ktiles * (2 * 128 * 4);
-    const u32x4* wtile = reinterpret_cast<const u32x4*>(p.w3) + (size_t)nt * p.ktiles * (2 * 128 * 4);
+    const u32x4* atile = reinterpret_cast<const u32x4*>(a_sp) + (size_t)mt * p.ktiles * (2 * 128 * 4);
+    const u32x4* wtile = reinterpret_cast<const u32x4*>(p.w_sp) + (size_t)nt * p.ktiles * (2 * 128 * 4);
     auto load_global = [&](int kt) {
         const u32x4* at = atile + (size_t)kt * (2 * 128 * 4);
         const u32x4* wt = wtile + (size_t)kt * (2 * 128 * 4);
@@ -371,7 +371,7 @@ static inline uint16_t g_f16_bits(_Float16 h) {
 }
 
 // W [N][ldw] fp32 (first K columns valid) -> [n-tile][k-tile][plane][128][32] fp16 terms (hi, lo * 2^11).
-std::vector<uint16_t> pack_gemm_w3(const float* w, int N, int K, int ldw) {
+std::vector<uint16_t> pack_gemm_w_split(const float* w, int N, int K, int ldw) {
     const int ntl = ceil_div(N, BN), ktl = ceil_div(K, BK);
     std::vector<uint16_t> out((size_t)ntl * ktl * 2 * 128 * 32, 0);
     for (int n = 0; n < N; ++n)
@@ -386,9 +386,9 @@ std::vector<uint16_t> pack_gemm_w3(const float* w, int N, int K, int ldw) {
 }
 
 void launch_gemm(const GemmLaunch& g, hipStream_t s) {
-    if (g.w3 && g.a3) {
-        Gemm3Args a;
-        a.a = g.a; a.a2 = g.a2; a.alpha = g.alpha; a.beta = g.beta; a.w3 = g.w3; a.bias = g.bias; a.c = g.c;
+    if (g.w_sp && g.a_sp) {
+        GemmSplitArgs a;
+        a.a = g.a; a.a2 = g.a2; a.alpha = g.alpha; a.beta = g.beta; a.w_sp = g.w_sp; a.bias = g.bias; a.c = g.c;
         a.M = g.M; a.N = g.N; a.K = g.K; a.lda = g.lda; a.ldc = g.ldc; a.B = g.B; a.T = g.T; a.ys = g.ys;
         a.tiles_per_b = 0; a.ktiles = ceil_div(g.K, BK);
         int mtiles3;
@@ -396,14 +396,14 @@ void launch_gemm(const GemmLaunch& g, hipStream_t s) {
         else mtiles3 = ceil_div(g.M, BM);
         const dim3 sgrid(a.ktiles, mtiles3);
         switch (g.mode) {
-            case GEMM_A_ROWMAJOR: hipLaunchKernelGGL(split_a_kernel<GEMM_A_ROWMAJOR>, sgrid, dim3(256), 0, s, a, g.a3); break;
-            case GEMM_A_SUM_BN: hipLaunchKernelGGL(split_a_kernel<GEMM_A_SUM_BN>, sgrid, dim3(256), 0, s, a, g.a3); break;
-            default: hipLaunchKernelGGL(split_a_kernel<GEMM_A_CONV>, sgrid, dim3(256), 0, s, a, g.a3); break;
+            case GEMM_A_ROWMAJOR: hipLaunchKernelGGL(split_a_kernel<GEMM_A_ROWMAJOR>, sgrid, dim3(256), 0, s, a, g.a_sp); break;
+            case GEMM_A_SUM_BN: hipLaunchKernelGGL(split_a_kernel<GEMM_A_SUM_BN>, sgrid, dim3(256), 0, s, a, g.a_sp); break;
+            default: hipLaunchKernelGGL(split_a_kernel<GEMM_A_CONV>, sgrid, dim3(256), 0, s, a, g.a_sp); break;
         }
         const dim3 grid3(ceil_div(g.N, BN), mtiles3);
         const size_t lds3 = (size_t)4 * XPLANE * 2;
-        if (g.mode == GEMM_A_CONV) DSMI_LAUNCH(gemm_f16x3_kernel<true>, grid3, dim3(256), lds3, s, g.ev, a, (const uint16_t*)g.a3);
-        else DSMI_LAUNCH(gemm_f16x3_kernel<false>, grid3, dim3(256), lds3, s, g.ev, a, (const uint16_t*)g.a3);
+        if (g.mode == GEMM_A_CONV) DSMI_LAUNCH(gemm_f16x3_kernel<true>, grid3, dim3(256), lds3, s, g.ev, a, (const uint16_t*)g.a_sp);
+        else DSMI_LAUNCH(gemm_f16x3_kernel<false>, grid3, dim3(256), lds3, s, g.ev, a, (const uint16_t*)g.a_sp);
         return;
     }
     GemmArgs a;

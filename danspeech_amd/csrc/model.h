@@ -7,14 +7,14 @@ struct HostTensor {
     std::vector<float> data;
 };
 
-struct ConvW { float *wp = nullptr, *bias = nullptr, *bn_a = nullptr, *bn_b = nullptr; uint16_t* wp3 = nullptr; };
+struct ConvW { float *wp = nullptr, *bias = nullptr, *bn_a = nullptr, *bn_b = nullptr; uint16_t* wp_sp = nullptr; };
 
 struct RnnW {
     float* wih = nullptr;   // [Np][ldw] gate-permuted (see rnn_src_row), zero padded
-    uint16_t* wih3 = nullptr;  // the same as tiled three-term bf16 split (pack_gemm_w3)
+    uint16_t* wih_sp = nullptr;  // the same as tiled two-term fp16 split (pack_gemm_w_split)
     float* bih = nullptr;   // [Np]
     float* whh[2] = {nullptr, nullptr};  // packed MFMA operand stream per direction
-    uint16_t* whh3[2] = {nullptr, nullptr};  // three-term bf16 split of the same, persistent kernel
+    uint16_t* whh_sp[2] = {nullptr, nullptr};  // two-term fp16 split of the same, persistent kernel
     float* bhh[2] = {nullptr, nullptr};  // torch layout [G*H]
     float* bn_a = nullptr;  // [Hs] BatchNorm1d in front of layers >= 1
     float* bn_b = nullptr;
@@ -58,20 +58,20 @@ struct dsmi_model {
     int cap_B = 0, cap_T = 0;
     std::vector<void*> ws;
     float* conv_buf[2] = {nullptr, nullptr};
-    uint16_t* conv_buf3[2] = {nullptr, nullptr};   // split channels-last intermediates between conv layers
+    uint16_t* conv_buf_sp[2] = {nullptr, nullptr};   // split channels-last intermediates between conv layers
     float* xp = nullptr;
     float* hbuf[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     float* cst[2] = {nullptr, nullptr};
     float* look_buf = nullptr;
     float* hpack = nullptr;
-    uint16_t* hpack3 = nullptr;
-    uint16_t* a3 = nullptr;       // split A operand of the x-projection GEMM
+    uint16_t* hpack_sp = nullptr;
+    uint16_t* a_sp = nullptr;       // split A operand of the x-projection GEMM
     unsigned* pcnt = nullptr;     // persistent-kernel step counters [layers][D*ceil(B/32)][T]
     unsigned* perr = nullptr;     // persistent-kernel timeout word (device)
     unsigned* perr_host = nullptr; // pinned mirror, refreshed at the end of every forward
     int n_cus = 0;
-    int conv_mode = 1;            // 1: bf16x6 conv for the 32-input-channel layers, 0: fp32 MFMA conv
-    int gemm_mode = 1;            // 1: bf16x6 split-operand GEMM, 0: fp32 MFMA GEMM
+    int conv_mode = 1;            // 1: split-fp16 conv for the 32-input-channel layers, 0: fp32 MFMA conv
+    int gemm_mode = 1;            // 1: split-fp16 GEMM, 0: fp32 MFMA GEMM
     int rnn_mode = 1;             // 1: persistent layer kernel when eligible, 0: one launch per step
     float* xin = nullptr;
     std::vector<int32_t> host_out_lens;   // output lengths of the batch being processed

@@ -48,9 +48,9 @@ using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 constexpr float kLoScale = 2048.f, kLoInv = 1.f / 2048.f;   // 2^11: the lo term is stored scaled
 
 struct PersistArgs {
-    const uint16_t* whh3[2];   // [wg][pair][plane 2][lane 64][8 fp16]: split W_hh (hi, lo * 2^11) in A-operand lane order
+    const uint16_t* whh_sp[2];   // [wg][pair][plane 2][lane 64][8 fp16]: split W_hh (hi, lo * 2^11) in A-operand lane order
     const float* bhh[2]; const float* xp; float* out[2];
-    const int32_t* lens; uint16_t* hpack3; unsigned* cnt; unsigned* err;
+    const int32_t* lens; uint16_t* hpack_sp; unsigned* cnt; unsigned* err;
     int B, T, G, H, Hs, npair, Np, nwg;
     int nz;                    // batch tiles of 32 clips, all walked by every workgroup each step
     int d0, nd;                // first direction of this launch, directions in the layer (chains are numbered over the layer)
@@ -99,17 +99,17 @@ __global__ __launch_bounds__(PNT) void rnn_persist_kernel(PersistArgs p) {
     const int p0 = (v * p.npair) / PNW, p1 = ((v + 1) * p.npair) / PNW;
     f16x8 wv[NPW][2];
     {
-        const u32x4* wp = reinterpret_cast<const u32x4*>(p.whh3[d]) + ((size_t)w * p.npair) * 128 + lane;
+        const u32x4* wp = reinterpret_cast<const u32x4*>(p.whh_sp[d]) + ((size_t)w * p.npair) * 128 + lane;
 #pragma unroll
         for (int i = 0; i < NPW; ++i) {
-            const int pq = min(p0 + i, p1 - 1);
+            const int pq = min(p0 + i, max(p1 - 1, p0));     // a wave with no pair of its own (small H) reads pair p0 and skips the MFMAs
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) wv[i][pl] = __builtin_bit_cast(f16x8, wp[((size_t)pq * 2 + pl) * 64]);
         }
     }
     // packed split state, [parity][chain][pair][plane][hk][batch j][8 fp16]; accessed ONLY through sc1 buffer ops
     const size_t hp_par = (size_t)p.nd * p.nz * p.npair * 2048;    // bytes per parity
-    const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.hpack3, 0, (int)(2 * hp_par), 0x00020000);
+    const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.hpack_sp, 0, (int)(2 * hp_par), 0x00020000);
 
     // epilogue role: threads 0..255 own (unit u = tid>>5, batch bl = tid&31) of every tile
     const int eu = tid >> 5, ebl = tid & 31;
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(PNT) void rnn_persist_kernel(PersistArgs p) {
             f16x8 hv[NPW][2];
 #pragma unroll
             for (int i = 0; i < NPW; ++i) {
-                const int pq = min(p0 + i, p1 - 1);
+                const int pq = min(p0 + i, max(p1 - 1, p0));     // a wave with no pair of its own (small H) reads pair p0 and skips the MFMAs
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl)
                     hv[i][pl] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(
@@ -307,7 +307,7 @@ static inline uint16_t f16_bits(_Float16 h) {
 
 // w_hh [G*H][H] (torch layout) of one direction -> [wg][pair][plane][lane][8] fp16 terms (hi, lo * 2^11); lane
 // (i = gate row, hk) element e holds k = 16*pair + 8*hk + e, the same k the producer of units 8*(2*pair+hk).. publishes.
-std::vector<uint16_t> pack_whh3(const RnnGeom& g, const float* w_hh) {
+std::vector<uint16_t> pack_whh_split(const RnnGeom& g, const float* w_hh) {
     const int npair = ceil_div(g.nq, 2);
     std::vector<uint16_t> out((size_t)g.nwg * npair * 2 * 64 * 8, 0);
     const int GU = g.G * g.U;
@@ -333,8 +333,8 @@ std::vector<uint16_t> pack_whh3(const RnnGeom& g, const float* w_hh) {
 
 bool launch_rnn_persist(const RnnPersistLaunch& p, hipStream_t s) {
     PersistArgs a;
-    for (int d = 0; d < 2; ++d) { a.whh3[d] = p.whh3[d]; a.bhh[d] = p.bhh[d]; a.out[d] = p.out[d]; }
-    a.xp = p.xp; a.lens = p.lens_dev; a.hpack3 = p.hpack3; a.cnt = p.counters; a.err = p.err; a.dbg = p.dbg;
+    for (int d = 0; d < 2; ++d) { a.whh_sp[d] = p.whh_sp[d]; a.bhh[d] = p.bhh[d]; a.out[d] = p.out[d]; }
+    a.xp = p.xp; a.lens = p.lens_dev; a.hpack_sp = p.hpack_sp; a.cnt = p.counters; a.err = p.err; a.dbg = p.dbg;
     a.B = p.B; a.T = p.T; a.G = p.g.G; a.H = p.g.H; a.Hs = p.g.Kp; a.npair = ceil_div(p.g.nq, 2); a.Np = p.g.Np; a.nwg = p.g.nwg;
     a.nz = ceil_div(p.B, 32); a.d0 = p.d0; a.nd = p.g.D;
     switch (p.g.kind) {

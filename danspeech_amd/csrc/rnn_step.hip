@@ -125,7 +125,7 @@ __global__ __launch_bounds__(NW * 64) void rnn_step_kernel(StepArgs p) {
                           ((((size_t)(par ^ 1) * gridDim.y + d) * gridDim.z + blockIdx.z) * p.nq) * 64 + lane;
 #pragma unroll
         for (int i = 0; i < NQW; ++i) {
-            const int q = min(q0 + i, q1 - 1);      // clamp: the duplicate is skipped below
+            const int q = min(q0 + i, max(q1 - 1, q0));      // clamp: duplicates (and a wave without k-blocks) are skipped below
             wv[i] = wp[(size_t)q * 64];
             hv[i] = hq[(size_t)q * 64];
         }

@@ -175,7 +175,7 @@ extern "C" int dsmi_stream_forward(dsmi_stream* st, const float* feat, int T, in
         c.x = xin[l]; c.y = yv[l]; c.wp = m->conv[l].wp; c.bias = m->conv[l].bias; c.bn_a = m->conv[l].bn_a; c.bn_b = m->conv[l].bn_b;
         c.out_lens_dev = st->lens_dev + l;
         c.B = 1; c.ci = sp.ci; c.co = sp.co; c.fi = m->conv_fi[l]; c.fo = m->conv_fo[l];
-        c.ti = tin[l]; c.to = tout[l]; c.xs = tin[l]; c.ys = ysv[l]; c.layer = l; c.y3 = nullptr;
+        c.ti = tin[l]; c.to = tout[l]; c.xs = tin[l]; c.ys = ysv[l]; c.layer = l; c.y_sp = nullptr;
         launch_conv(c, s);
     }
     st->has_left = !is_last;
@@ -185,7 +185,7 @@ extern "C" int dsmi_stream_forward(dsmi_stream* st, const float* feat, int T, in
     for (int l = 0; l < d.rnn_layers; ++l) {
         const RnnW& r = m->rnn[l];
         GemmLaunch gl{};
-        gl.w = r.wih; gl.bias = r.bih; gl.c = st->xp; gl.w3 = nullptr; gl.a3 = nullptr;
+        gl.w = r.wih; gl.bias = r.bih; gl.c = st->xp; gl.w_sp = nullptr; gl.a_sp = nullptr;
         gl.M = Tc; gl.N = m->geom.Np; gl.K = r.K; gl.ldw = r.ldw; gl.ldc = m->geom.Np; gl.B = 1; gl.T = Tc;
         if (l == 0) { gl.mode = GEMM_A_CONV; gl.a = st->y2; gl.ys = ys2; }
         else { gl.mode = GEMM_A_SUM_BN; gl.a = st->hb[(l - 1) & 1]; gl.a2 = nullptr; gl.alpha = r.bn_a; gl.beta = r.bn_b; gl.lda = m->Hs; }

@@ -327,14 +327,22 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmSplitArgs p, con
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl)
                     wf[ni][pl] = *reinterpret_cast<const f16x8*>(Ws + pl * XPLANE + (wc * 64 + ni * 32 + li) * XS + ks * 16 + hk * 8);
+            // product by product across the four tiles: no MFMA waits on the one issued just before it
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
+                for (int ni = 0; ni < 2; ++ni)
                     acl[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi][1], wf[ni][0], acl[mi][ni], 0, 0, 0);
-                    acl[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi][0], wf[ni][1], acl[mi][ni], 0, 0, 0);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi][0], wf[ni][0], acc[mi][ni], 0, 0, 0);
-                }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acl[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi][0], wf[ni][1], acl[mi][ni], 0, 0, 0);
         }
         __syncthreads();
     }

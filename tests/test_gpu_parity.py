@@ -239,7 +239,7 @@ def test_wide_and_odd_layers_vs_oracle(native, H, why):
 
 
 def test_step_path_and_persistent_path_agree(native, monkeypatch):
-    """DSMI_RNN_MODE=steps (fp32 MFMA, one launch per step) vs the default persistent bf16x6 kernel."""
+    """DSMI_RNN_MODE=steps (fp32 MFMA, one launch per step) vs the default split-fp16 kernels."""
     sd = syn.make_state_dict(2, "lstm", 64, 2, seed=35, fc_gain=4.0)
     cfg = _cfg(2, "lstm", 64, 2)
     lens = np.array([90, 77, 30], dtype=np.int32)

@@ -208,6 +208,7 @@ struct GemmSplitArgs {
     const float* a; const float* a2; const float* alpha; const float* beta;
     const uint16_t* w_sp; const float* bias; float* c;
     int M, N, K, lda, ldc, B, T, ys, tiles_per_b, ktiles;
+    int ntiles, mtiles;       // output tiles (gemm kernel's XCD-aware tile order)
 };
 
 // Pass 1: form the A operand ONCE (producer transforms + two-term split) as tiled fp16 planes
@@ -272,16 +273,33 @@ __global__ __launch_bounds__(256) void split_a_kernel(GemmSplitArgs p, uint16_t*
 template <bool CONV_ROWS>
 __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmSplitArgs p, const uint16_t* a_sp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
-    _Float16* As = reinterpret_cast<_Float16*>(smem3);        // [2][128][XS]
-    _Float16* Ws = As + 2 * XPLANE;                            // [2][128][XS]
+    _Float16* As = reinterpret_cast<_Float16*>(smem3);        // [2 k-tiles][2 planes][128][XS]
+    _Float16* Ws = As + 4 * XPLANE;                            // [2 k-tiles][2 planes][128][XS]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1;
     const int li = lane & 31, hk = lane >> 5;
-    const int nt = blockIdx.x, mt = blockIdx.y;
+    // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (each with its own 4 MB L2), so
+    // workgroup id -> (xcd = id % 8, slot = id / 8) and every XCD walks its own contiguous share of the tiles in
+    // panels of 8 column tiles: the ~64 workgroups resident on an XCD then cover 8 row tiles x 8 column tiles and
+    // fetch 16 operand tiles from Infinity Cache / HBM instead of 128 (every operand tile is shared 8 ways in L2).
+    int nt, mt;
+    {
+        const int ntiles = p.ntiles, mtiles = p.mtiles, total = ntiles * mtiles;
+        const int share = (total + 7) / 8;
+        const int idx = (blockIdx.x & 7) * share + (blockIdx.x >> 3);
+        if ((int)(blockIdx.x >> 3) >= share || idx >= total) return;
+        constexpr int PN = 8;
+        const int panel = idx / (PN * mtiles), rem = idx - panel * (PN * mtiles);
+        const int pw = min(PN, ntiles - panel * PN);          // width of this (possibly last, narrower) panel
+        mt = rem / pw; nt = panel * PN + (rem - mt * pw);
+    }
     const int n0 = nt * BN;
     int m0 = mt * BM, bb = 0, t0 = 0;
     if (CONV_ROWS) { bb = mt / p.tiles_per_b; t0 = (mt % p.tiles_per_b) * BM; }
 
+    // Pipeline: LDS holds two stages (k-tiles), so there is ONE barrier per k-tile: tile kt+1 is written to the
+    // other stage at the end of iteration kt (its global loads were issued a whole iteration earlier), and the
+    // fragments of the next k-step are read from LDS while the current k-step's 12 MFMAs run.
     u32x4 ra[4], rw[4];
     const u32x4* atile = reinterpret_cast<const u32x4*>(a_sp) + (size_t)mt * p.ktiles * (2 * 128 * 4);
     const u32x4* wtile = reinterpret_cast<const u32x4*>(p.w_sp) + (size_t)nt * p.ktiles * (2 * 128 * 4);
@@ -291,14 +309,25 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmSplitArgs p, con
 #pragma unroll
         for (int i = 0; i < 4; ++i) { ra[i] = at[tid + 256 * i]; rw[i] = wt[tid + 256 * i]; }
     };
-    auto store_lds = [&]() {
+    auto store_lds = [&](int stage) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int c = tid + 256 * i;
-            const int off = (c >> 9) * XPLANE + ((c >> 2) & 127) * XS + (c & 3) * 8;
+            const int off = stage * (2 * XPLANE) + (c >> 9) * XPLANE + ((c >> 2) & 127) * XS + (c & 3) * 8;
             *reinterpret_cast<u32x4*>(As + off) = ra[i];
             *reinterpret_cast<u32x4*>(Ws + off) = rw[i];
         }
+    };
+    f16x8 af[2][2][2], wf[2][2][2];      // [buffer][tile][plane]
+    auto read_frags = [&](int buf, int stage, int ks) {
+        const int sub = stage * (2 * XPLANE) + ks * 16 + hk * 8;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                af[buf][mi][pl] = *reinterpret_cast<const f16x8*>(As + sub + pl * XPLANE + (wr * 64 + mi * 32 + li) * XS);
+                wf[buf][mi][pl] = *reinterpret_cast<const f16x8*>(Ws + sub + pl * XPLANE + (wc * 64 + mi * 32 + li) * XS);
+            }
     };
 
     f32x16 acc[2][2], acl[2][2];       // hi.hi ; (hi.lo + lo.hi) * 2^11
@@ -310,41 +339,39 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmSplitArgs p, con
             for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; acl[i][j][r] = 0.f; }
 
     load_global(0);
+    store_lds(0);
+    __syncthreads();
+    if (p.ktiles > 1) load_global(1);
+    read_frags(0, 0, 0);
     for (int kt = 0; kt < p.ktiles; ++kt) {
-        store_lds();
-        __syncthreads();
-        if (kt + 1 < p.ktiles) load_global(kt + 1);
+        const int stage = kt & 1;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            f16x8 af[2][2], wf[2][2];
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl)
-                    af[mi][pl] = *reinterpret_cast<const f16x8*>(As + pl * XPLANE + (wr * 64 + mi * 32 + li) * XS + ks * 16 + hk * 8);
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl)
-                    wf[ni][pl] = *reinterpret_cast<const f16x8*>(Ws + pl * XPLANE + (wc * 64 + ni * 32 + li) * XS + ks * 16 + hk * 8);
+            if (ks == 0) read_frags(1, stage, 1);          // next k-step of this tile, while this one computes
+            const int cb = ks;
             // product by product across the four tiles: no MFMA waits on the one issued just before it
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
-                    acl[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi][1], wf[ni][0], acl[mi][ni], 0, 0, 0);
+                    acl[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cb][mi][1], wf[cb][ni][0], acl[mi][ni], 0, 0, 0);
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi][0], wf[ni][0], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cb][mi][0], wf[cb][ni][0], acc[mi][ni], 0, 0, 0);
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
-                    acl[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi][0], wf[ni][1], acl[mi][ni], 0, 0, 0);
+                    acl[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cb][mi][0], wf[cb][ni][1], acl[mi][ni], 0, 0, 0);
+            if (ks == 0 && kt + 1 < p.ktiles) store_lds(stage ^ 1);      // tile kt+1 -> the other stage (last read in iteration kt-1)
         }
         __syncthreads();
+        if (kt + 1 < p.ktiles) {
+            if (kt + 2 < p.ktiles) load_global(kt + 2);
+            read_frags(0, stage ^ 1, 0);
+        }
     }
 
 #pragma unroll
@@ -408,8 +435,11 @@ void launch_gemm(const GemmLaunch& g, hipStream_t s) {
             case GEMM_A_SUM_BN: hipLaunchKernelGGL(split_a_kernel<GEMM_A_SUM_BN>, sgrid, dim3(256), 0, s, a, g.a_sp); break;
             default: hipLaunchKernelGGL(split_a_kernel<GEMM_A_CONV>, sgrid, dim3(256), 0, s, a, g.a_sp); break;
         }
-        const dim3 grid3(ceil_div(g.N, BN), mtiles3);
-        const size_t lds3 = (size_t)4 * XPLANE * 2;
+        a.ntiles = ceil_div(g.N, BN); a.mtiles = mtiles3;
+        const dim3 grid3(8 * ceil_div(a.ntiles * a.mtiles, 8));
+        const size_t lds3 = (size_t)8 * XPLANE * 2;     // 80 KiB: two workgroups fill the CU's 160 KiB exactly
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
         if (g.mode == GEMM_A_CONV) DSMI_LAUNCH(gemm_f16x3_kernel<true>, grid3, dim3(256), lds3, s, g.ev, a, (const uint16_t*)g.a_sp);
         else DSMI_LAUNCH(gemm_f16x3_kernel<false>, grid3, dim3(256), lds3, s, g.ev, a, (const uint16_t*)g.a_sp);
         return;

@@ -632,13 +632,19 @@ extern "C" int dsmi_beam(dsmi_decoder* d, const float* probs, const int32_t* siz
     hipLaunchKernelGGL(beam_kernel, dim3(B), dim3(BT), lds, s, a);
     std::vector<int32_t> h_len((size_t)B * beam), h_n(B);
     std::vector<double> h_score((size_t)B * beam);
-    DEC_HIP(d, hipMemcpyAsync(tokens, w + o_tok, (size_t)B * beam * To * 4, hipMemcpyDeviceToHost, s));
-    DEC_HIP(d, hipMemcpyAsync(tsteps, w + o_step, (size_t)B * beam * To * 4, hipMemcpyDeviceToHost, s));
     DEC_HIP(d, hipMemcpyAsync(h_len.data(), w + o_len, (size_t)B * beam * 4, hipMemcpyDeviceToHost, s));
     DEC_HIP(d, hipMemcpyAsync(h_n.data(), w + o_n, (size_t)B * 4, hipMemcpyDeviceToHost, s));
     DEC_HIP(d, hipMemcpyAsync(h_score.data(), w + o_score, (size_t)B * beam * 8, hipMemcpyDeviceToHost, s));
     DEC_HIP(d, hipStreamSynchronize(s));
     DEC_HIP(d, hipGetLastError());
+    // transcripts are a fraction of T_out long: bring back only the columns that hold tokens
+    int maxlen = 0;
+    for (int32_t v : h_len) maxlen = std::max(maxlen, (int)v);
+    if (maxlen > 0) {
+        DEC_HIP(d, hipMemcpy2DAsync(tokens, (size_t)To * 4, w + o_tok, (size_t)To * 4, (size_t)maxlen * 4, (size_t)B * beam, hipMemcpyDeviceToHost, s));
+        DEC_HIP(d, hipMemcpy2DAsync(tsteps, (size_t)To * 4, w + o_step, (size_t)To * 4, (size_t)maxlen * 4, (size_t)B * beam, hipMemcpyDeviceToHost, s));
+        DEC_HIP(d, hipStreamSynchronize(s));
+    }
     // ---- ctcdecode "approx_ctc": strip the word bonus and the LM weight; score = -approx
     for (int b = 0; b < B; ++b)
         for (int p = 0; p < beam; ++p) {

@@ -23,7 +23,7 @@ struct dsmi_frontend {
     std::string err;
     double* tw = nullptr;    // [n_fft][2] cos, sin
     double* win = nullptr;   // [n_fft]
-    int64_t* offs = nullptr; // device: per-clip sample offset, n_samples  [2][cap]
+    int64_t* offs = nullptr; // device: per-clip sample offset, n_samples [2][cap], then float64 partial statistics [cap][NSL][2]
     int cap = 0;
 };
 
@@ -124,25 +124,44 @@ __device__ double block_sum(double v, double* sh) {
     return tot;
 }
 
-// one workgroup per clip: mean, unbiased std, normalise in place, zero the tail frames
-__global__ __launch_bounds__(1024) void normalize_kernel(float* feat, const int64_t* nsamp, int hop, int n_freq, int t_stride, int normalize) {
+// Per-clip mean and unbiased std over the clip's own n_freq x frames values (parsers.py:66-70), then
+// normalise in place and zero the tail frames.  NSL workgroups per clip: (1) every slice writes its float64 sum and
+// sum of squares, (2) every slice adds the NSL partials in a fixed order (deterministic, unlike atomics) and normalises.
+constexpr int NSL = 16;
+
+__global__ __launch_bounds__(1024) void clip_stats_kernel(const float* feat, const int64_t* nsamp, int hop, int n_freq, int t_stride, double* stats) {
     __shared__ double sh[16];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int nfr = 1 + (int)(nsamp[b] / hop);
+    const float* fb = feat + (size_t)b * n_freq * t_stride;
+    const int total = n_freq * t_stride;
+    double s = 0.0, q = 0.0;
+    for (int i = blockIdx.x * 1024 + tid; i < total; i += NSL * 1024)
+        if (i % t_stride < nfr) { const double v = (double)fb[i]; s += v; q += v * v; }
+    s = block_sum(s, sh);
+    q = block_sum(q, sh);
+    if (tid == 0) { stats[((size_t)b * NSL + blockIdx.x) * 2] = s; stats[((size_t)b * NSL + blockIdx.x) * 2 + 1] = q; }
+}
+
+__global__ __launch_bounds__(1024) void normalize_kernel(float* feat, const int64_t* nsamp, int hop, int n_freq, int t_stride, int normalize,
+                                                         const double* stats) {
+    const int b = blockIdx.y, tid = threadIdx.x;
     const int nfr = 1 + (int)(nsamp[b] / hop);
     float* fb = feat + (size_t)b * n_freq * t_stride;
     const int total = n_freq * t_stride;
+    float meanf = 0.f, stdf = 1.f;
     if (normalize) {
-        double s = 0.0;
-        for (int i = tid; i < total; i += 1024) if (i % t_stride < nfr) s += (double)fb[i];
         const double cnt = (double)n_freq * nfr;
-        const double mean = block_sum(s, sh) / cnt;
-        double q = 0.0;
-        for (int i = tid; i < total; i += 1024) if (i % t_stride < nfr) { const double dlt = (double)fb[i] - mean; q += dlt * dlt; }
-        const double var = block_sum(q, sh) / (cnt - 1.0);
-        const float meanf = (float)mean, stdf = (float)sqrt(var);
-        for (int i = tid; i < total; i += 1024) fb[i] = (i % t_stride < nfr) ? (fb[i] - meanf) / stdf : 0.f;
-    } else {
-        for (int i = tid; i < total; i += 1024) if (i % t_stride >= nfr) fb[i] = 0.f;
+        double sum = 0.0, sq = 0.0;
+        for (int k = 0; k < NSL; ++k) { sum += stats[((size_t)b * NSL + k) * 2]; sq += stats[((size_t)b * NSL + k) * 2 + 1]; }
+        const double mean = sum / cnt;
+        const double var = (sq - cnt * mean * mean) / (cnt - 1.0);
+        meanf = (float)mean; stdf = (float)sqrt(var);
+    }
+    for (int i = blockIdx.x * 1024 + tid; i < total; i += NSL * 1024) {
+        const bool in = i % t_stride < nfr;
+        if (normalize) fb[i] = in ? (fb[i] - meanf) / stdf : 0.f;
+        else if (!in) fb[i] = 0.f;
     }
 }
 
@@ -218,7 +237,7 @@ extern "C" int dsmi_features_stream(dsmi_frontend* f, const void* pcm, int dtype
     hipStream_t s = (hipStream_t)stream;
     if (f->cap < 2) {       // offs doubles as scratch for the statistics: [0] offset, [cap] n_samples, then two doubles
         if (f->offs) { (void)hipStreamSynchronize(s); (void)hipFree(f->offs); f->offs = nullptr; }
-        if (hipMalloc((void**)&f->offs, sizeof(int64_t) * 4) != hipSuccess) return bad(DSMI_ERR_NOMEM, "hipMalloc failed");
+        if (hipMalloc((void**)&f->offs, sizeof(int64_t) * (2 + 2 * NSL) * 2) != hipSuccess) return bad(DSMI_ERR_NOMEM, "hipMalloc failed");
         f->cap = 2;
     }
     const int64_t host[2] = {0, n_samples};
@@ -386,7 +405,7 @@ extern "C" int dsmi_features(dsmi_frontend* m, const void* pcm, int dtype, const
     }
     if (B > f->cap) {
         if (f->offs) { (void)hipStreamSynchronize(s); (void)hipFree(f->offs); }
-        if (hipMalloc((void**)&f->offs, sizeof(int64_t) * 2 * B) != hipSuccess) return bad(DSMI_ERR_NOMEM, "hipMalloc failed");
+        if (hipMalloc((void**)&f->offs, sizeof(int64_t) * (2 + 2 * NSL) * B) != hipSuccess) return bad(DSMI_ERR_NOMEM, "hipMalloc failed");
         f->cap = B;
     }
     if (hipMemcpyAsync(f->offs, host.data(), sizeof(int64_t) * B, hipMemcpyHostToDevice, s) != hipSuccess ||
@@ -396,7 +415,11 @@ extern "C" int dsmi_features(dsmi_frontend* m, const void* pcm, int dtype, const
     EvPair ev;
     DSMI_LAUNCH(stft_logmag_kernel, dim3(ceil_div(maxfr, FT), B), dim3(256), lds, s, ev, pcm, dtype, f->offs, f->offs + f->cap,
                 f->tw, f->win, m->n_fft, m->hop, m->n_freq, m->desc.pad_mode, feat, t_stride);
-    hipLaunchKernelGGL(normalize_kernel, dim3(B), dim3(1024), 0, s, feat, f->offs + f->cap, m->hop, m->n_freq, t_stride, m->desc.normalize);
+    double* stats = reinterpret_cast<double*>(f->offs + 2 * (size_t)f->cap);       // [B][NSL][2] behind the offsets / lengths
+    if (m->desc.normalize) {
+        hipLaunchKernelGGL(clip_stats_kernel, dim3(NSL, B), dim3(1024), 0, s, feat, f->offs + f->cap, m->hop, m->n_freq, t_stride, stats);
+    }
+    hipLaunchKernelGGL(normalize_kernel, dim3(NSL, B), dim3(1024), 0, s, feat, f->offs + f->cap, m->hop, m->n_freq, t_stride, m->desc.normalize, stats);
     if (hipGetLastError() != hipSuccess) return bad(DSMI_ERR_HIP, "feature kernels failed to launch");
     return DSMI_OK;
 }

@@ -40,6 +40,7 @@ constexpr int PNW = 8;                 // waves per workgroup
 constexpr int PNT = PNW * 64;
 constexpr int PU = 8;                  // hidden units per workgroup (rnn geometry U)
 constexpr unsigned SPIN_LIMIT = 1u << 22;
+constexpr int RP = 40;                 // row pitch of the reduce buffer in words
 constexpr size_t PERSIST_LDS = 82 * 1024;   // > half of the CU's 160 KiB: at most one workgroup per CU
 
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
@@ -84,8 +85,9 @@ __global__ __launch_bounds__(PNT) void rnn_persist_kernel(PersistArgs p) {
     // reduce buffer + new-state staging; padded past 80 KiB so that two workgroups never share a CU
     // (dynamic LDS, requested as PERSIST_LDS bytes at launch: a static pad would be optimised away)
     extern __shared__ __attribute__((aligned(16))) float plds[];
-    float* red = plds;                               // [PNW][32][32]
-    float* hstage = red + PNW * 32 * 32;             // [PU][32]
+    float* red = plds;                               // [PNW][32 gate rows][RP]: row pitch 40 words keeps both the MFMA-layout
+                                                     // writes (lanes along the batch) and the cell's reads (lanes along units) conflict-free
+    float* hstage = red + PNW * 32 * RP;             // (spare)
     int& s_dead = *reinterpret_cast<int*>(hstage + PU * 32);
     // MULTI: per-tile recurrent state of the epilogue threads (a single tile keeps it in registers)
     float* st_h = hstage + PU * 32 + 32;             // [PMAXZ][PU*32]
@@ -116,8 +118,9 @@ __global__ __launch_bounds__(PNT) void rnn_persist_kernel(PersistArgs p) {
     const size_t hp_par = (size_t)p.nd * p.nz * p.npair * 2048;    // bytes per parity
     const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.hpack_sp, 0, (int)(2 * hp_par), 0x00020000);
 
-    // epilogue role: threads 0..255 own (unit u = tid>>5, batch bl = tid&31) of every tile
-    const int eu = tid >> 5, ebl = tid & 31;
+    // epilogue role: threads 0..255 own (batch bl = tid>>3, unit u = tid&7) of every tile: the 8 units of a batch row sit
+    // in 8 adjacent lanes, so a wave's 2-byte stores of the new state are 128 contiguous bytes of packed granules
+    const int eu = tid & 7, ebl = tid >> 3;
     const int eunit = w * PU + eu;
     const bool eunit_ok = tid < PU * 32 && eunit < p.H;
     float bh[NG];
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(PNT) void rnn_persist_kernel(PersistArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i = (r & 3) + 8 * (r >> 2) + 4 * hk;
-            red[(v * 32 + i) * 32 + li] = acc[r] + acl[r] * kLoInv;
+            red[(v * 32 + i) * RP + li] = acc[r] + acl[r] * kLoInv;
         }
         __syncthreads();
         PSTAMP(3);   // partial tiles to LDS + barrier (wave skew)
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(PNT) void rnn_persist_kernel(PersistArgs p) {
                     const int row = g * PU + eu;
                     float sum = 0.f;
 #pragma unroll
-                    for (int k = 0; k < PNW; ++k) sum += red[(k * 32 + row) * 32 + ebl];
+                    for (int k = 0; k < PNW; ++k) sum += red[(k * 32 + row) * RP + ebl];
                     hg[g] = sum + bh[g];
                 }
                 if (KIND == DSMI_RNN_GRU) {
@@ -236,25 +239,16 @@ __global__ __launch_bounds__(PNT) void rnn_persist_kernel(PersistArgs p) {
             } else if (ebl < nb && eunit < p.Hs) {
                 p.out[d][((size_t)t * p.B + eb) * p.Hs + eunit] = 0.f;     // padding units of the last workgroup
             }
-            hstage[eu * 32 + ebl] = hn;
-        }
-        __syncthreads();
-        PSTAMP(4);   // reduction + cell
-        // ---- publish: lanes 0..31 of wave 0 split this workgroup's 8 units of batch row j into the two
-        // fp16 terms and store one 16-byte granule per plane (512 contiguous bytes per instruction)
-        if (v == 0 && lane < 32) {
-            f16x8 ph, pl;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float x = hstage[e * 32 + lane];
-                const _Float16 h1 = (_Float16)x;
-                ph[e] = h1; pl[e] = (_Float16)((x - (float)h1) * kLoScale);
-            }
+            // ---- publish straight from the cell threads: hi / lo fp16 terms of (batch row ebl, unit eu) at byte
+            // 16 * ebl + 2 * eu of this workgroup's granule block = 2 * tid: contiguous per wave, write-through (sc1)
+            const _Float16 h1 = (_Float16)hn;
+            const _Float16 h2 = (_Float16)((hn - (float)h1) * kLoScale);
             const unsigned off = (unsigned)((s & 1) * hp_par) + hchain + (unsigned)(w >> 1) * 2048u +
-                                 (unsigned)(w & 1) * 512u + (unsigned)lane * 16u;
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ph), hrs, off, 0, 16);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pl), hrs, off + 1024u, 0, 16);
+                                 (unsigned)(w & 1) * 512u + (unsigned)tid * 2u;
+            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, h1), hrs, off, 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, h2), hrs, off + 1024u, 0, 16);
         }
+        PSTAMP(4);   // reduction + cell + publish
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave drains its own stores
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(&cnt[s], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -11,9 +11,9 @@ from danspeech_amd.deepspeech.model import DeepSpeech
 from danspeech_amd import Recognizer
 
 
-def build(H, L, lm_order=None, beam=None, n_words=5000):
-    sd = syn.make_state_dict(2, "gru", H, L, seed=0, fc_gain=8.0)
-    m = DeepSpeech("cfg", rnn_hidden_size=H, rnn_layers=L).load_state_dict(sd)
+def build(H, L, lm_order=None, beam=None, n_words=5000, conv=2):
+    sd = syn.make_state_dict(conv, "gru", H, L, seed=0, fc_gain=8.0)
+    m = DeepSpeech("cfg", rnn_hidden_size=H, rnn_layers=L, conv_layers=conv).load_state_dict(sd)
     rec = Recognizer(model=m)
     if lm_order:
         path = os.path.join(tempfile.gettempdir(), "syn%d.arpa" % lm_order)
@@ -36,7 +36,7 @@ def run(name, rec, B, seconds, reps=3):
     return out
 
 
-which = [int(a) for a in sys.argv[1:]] or [2, 3, 4, 5]
+which = [int(a) for a in sys.argv[1:]] or [2, 3, 4, 5, 6]
 if 2 in which:
     run("config 2: cfgA greedy B=32 x 10 s", build(800, 5), 32, 10.0)
 if 3 in which:
@@ -45,3 +45,5 @@ if 4 in which:
     run("config 4: 7 x BiGRU1200 + 5-gram beam=128 B=64 x 10 s", build(1200, 7, 5, 128), 64, 10.0, reps=2)
 if 5 in which:
     run("config 5 (one GPU's share): cfgA + 3-gram beam=64 B=128 x 30 s", build(800, 5, 3, 64), 128, 30.0, reps=1)
+if 6 in which:     # SURVEY 8(d) side row: the docstring shape of DanSpeechPrimary (3 conv, 9 x BiGRU 1200), config 2's workload
+    run("side row: 3 conv + 9 x BiGRU1200 greedy B=32 x 10 s", build(1200, 9, conv=3), 32, 10.0, reps=2)

@@ -1,6 +1,6 @@
 // Conv2d (32 input channels) + bias + BatchNorm2d(eval) + Hardtanh(0,20) + time mask on the fp16
 // MFMA with two-term split operands (x = hi + lo * 2^-11, three products, two fp32 accumulators:
-// better than fp32-MFMA accuracy, see gemm.hip / tools/exp/bf16x6_test.hip).  Inputs are Hardtanh
+// better than fp32-MFMA accuracy, see gemm.hip / tools/exp/split_mfma_accuracy.hip).  Inputs are Hardtanh
 // outputs in [0, 20] and the weights are range-checked at load time, so fp16's 65504 is never near.
 //
 // Replaces the 2nd and 3rd (Conv2d, BatchNorm2d, Hardtanh) triples of the reference's conv stack

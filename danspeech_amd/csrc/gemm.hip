@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
 // hi.hi into one fp32 accumulator, hi.lo + lo.hi into a second one that is folded in with 2^-11
 // in the epilogue (lo.lo < 2^-22 is dropped).  v_mfma_f32_32x32x16_f16 runs at 16x the fp32 MFMA
 // rate, so the product costs 3/16 of the fp32 one; measured error vs fp64 at K = 800: 2.6e-7
-// against 1.0e-6 for the fp32 MFMA chain (tools/exp/bf16x6_test.hip).  Operand ranges must stay
+// against 1.0e-6 for the fp32 MFMA chain (tools/exp/split_mfma_accuracy.hip).  Operand ranges must stay
 // below fp16's 65504: the caller checks weights and BatchNorm bounds at load time (api.hip).
 // W is split and tiled once on the host (pack_gemm_w_split: [n-tile][k-tile][plane][128][32] fp16, so
 // the operand loads are fully coalesced 16-byte copies); the activations are split ONCE per GEMM

@@ -12,7 +12,7 @@
 //     number), three products: hi.hi in one fp32 accumulator, hi.lo + lo.hi in a second one that
 //     is folded in with 2^-11 at the end (lo.lo < 2^-22 is dropped).  Measured error vs an fp64
 //     reference at K = 800: 2.6e-7, against 1.0e-6 for the fp32 MFMA chain and 8.0e-7 for the
-//     earlier three-term bf16 split with six products (tools/exp/bf16x6_test.hip): better than
+//     earlier three-term bf16 split with six products (tools/exp/split_mfma_accuracy.hip): better than
 //     fp32-MFMA accuracy at 3/16 of its time.  Ranges are safe by construction: |h| <= 1 for
 //     every cell type, |W_hh| is checked at load time (fp16 max 65504).
 //     W_hh is split once on the host; each workgroup splits the 256 state values it produces

@@ -1,4 +1,5 @@
-// Experiment: fp32-equivalent product through 6 bf16 MFMAs (hi/mid/lo split) vs the f32 MFMA.
+// Experiment: accuracy of fp32-grade products on the low-precision MFMA: two-term fp16 split (3 products), three-term
+// bf16 split (6 and 3 products) and the plain fp32 MFMA, all against an fp64 reference.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cmath>

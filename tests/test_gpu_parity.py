@@ -278,3 +278,25 @@ def test_multi_tile_batches_in_the_persistent_kernel_vs_oracle(native, kind, B):
     assert np.array_equal(ol, ol_ref)
     np.testing.assert_allclose(p.cpu().numpy(), ref, rtol=0, atol=1e-4)
     m.close()
+
+
+def test_extreme_lengths_vs_oracle(native):
+    """One-frame and very short clips next to a 30 s clip (T = 3001, T' = 1501: BASELINE config 5's length) in one
+    ragged batch: counters, masks and packed-sequence zeros at both ends of the length range."""
+    from oracle import model as om
+    H = 40
+    sd = syn.make_state_dict(2, "gru", H, 2, seed=51, fc_gain=4.0)
+    cfg = _cfg(2, "gru", H, 2)
+    lens = np.array([3001, 700, 12, 2, 1], dtype=np.int32)
+    x = syn.make_features(len(lens), 3001, seed=52)
+    for b, L in enumerate(lens):
+        x[b, :, :, L:] = 0
+    m = native.NativeModel(cfg, sd)
+    p, ol = m.forward(_dev(x), lens)
+    ref, ol_ref = om.forward(sd, cfg, x, lens)
+    assert np.array_equal(ol, ol_ref) and ol[0] == 1501 and ol[-1] == 1
+    np.testing.assert_allclose(p.cpu().numpy(), ref, rtol=0, atol=1e-4)
+    # a batch of one single-frame clip
+    p1, ol1 = m.forward(_dev(x[4:5, :, :, :1].copy()), lens[4:5])
+    np.testing.assert_allclose(p1.cpu().numpy()[0, :1], ref[4, :1], rtol=0, atol=1e-5)
+    m.close()

@@ -15,15 +15,18 @@
 //     earlier three-term bf16 split with six products (tools/exp/split_mfma_accuracy.hip): better than
 //     fp32-MFMA accuracy at 3/16 of its time.  Ranges are safe by construction: |h| <= 1 for
 //     every cell type, |W_hh| is checked at load time (fp16 max 65504).
-//     W_hh is split once on the host; each workgroup splits the 256 state values it produces
-//     and publishes them already in B-operand lane order;
+//     W_hh is split once on the host; the 256 cell threads of a workgroup split the state values
+//     they produce and store them straight into the packed buffer, already in B-operand lane order
+//     (2-byte stores, 128 contiguous bytes per wave instruction);
 //   * the per-step all-to-all of h goes through the packed state buffer with the counter form
 //     of the hand-off protocol of cdna_hip_programming.md Guideline 16 / MI355X_MICROARCH.md
-//     "Valid forms" row 3: producers store their h granules write-through (sc1, whole 128-B
-//     lines per wave instruction), every storing wave drains vmcnt, workgroup barrier, ONE
-//     lane adds to an agent-scope counter; consumers poll that counter with an sc1 load, pass a
+//     "Valid forms" row 3: producers store their h granules write-through (sc1), every storing
+//     wave drains vmcnt, workgroup barrier, ONE lane adds to an agent-scope counter; consumers poll that counter with an sc1 load, pass a
 //     workgroup barrier, and read h with sc1 loads only.  One counter per (direction, batch
 //     tile, step), zeroed by a memset node before the launch; no flag is ever reused.
+//   * batches above 32 clips: every workgroup walks the 32-clip batch tiles one after the other each
+//     step with the same resident weights (MULTI); layers too wide for both directions to be
+//     co-resident run one launch per direction;
 //   * every spin is bounded: on timeout the workgroup raises an error word and stops waiting,
 //     so a lost workgroup can never hang the GPU (the host then reports DSMI_ERR_HIP).
 // Requires all workgroups co-resident: the launcher checks grid <= number of CUs (the kernel
@@ -87,10 +90,9 @@ __global__ __launch_bounds__(PNT) void rnn_persist_kernel(PersistArgs p) {
     extern __shared__ __attribute__((aligned(16))) float plds[];
     float* red = plds;                               // [PNW][32 gate rows][RP]: row pitch 40 words keeps both the MFMA-layout
                                                      // writes (lanes along the batch) and the cell's reads (lanes along units) conflict-free
-    float* hstage = red + PNW * 32 * RP;             // (spare)
-    int& s_dead = *reinterpret_cast<int*>(hstage + PU * 32);
+    int& s_dead = *reinterpret_cast<int*>(red + PNW * 32 * RP);
     // MULTI: per-tile recurrent state of the epilogue threads (a single tile keeps it in registers)
-    float* st_h = hstage + PU * 32 + 32;             // [PMAXZ][PU*32]
+    float* st_h = red + PNW * 32 * RP + 32;          // [PMAXZ][PU*32]
     float* st_c = st_h + PMAXZ * PU * 32;            // [PMAXZ][PU*32]
     int* st_len = reinterpret_cast<int*>(st_c + PMAXZ * PU * 32);   // [PMAXZ][PU*32]
     const int tid = threadIdx.x, lane = tid & 63;

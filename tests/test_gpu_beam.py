@@ -93,6 +93,18 @@ def test_beam_cutoff_top_n(native):
     _compare(native, probs, None, labels, beam=20, cutoff_top_n=10)
 
 
+def test_beam_cutoff_prob_with_lm_and_long_utterance(native, tmp_path):
+    """cutoff_prob < 1 (cumulative-probability vocabulary pruning, decoder_utils get_pruned_log_probs) together
+    with the scorer, on 300 frames: many radix-select passes, node reuse and dictionary pruning in one run."""
+    labels = syn.DANSPEECH_LABELS
+    path = str(tmp_path / "lm3.arpa")
+    syn.make_arpa(path, order=3, n_words=400, seed=21, ngrams_per_order=1500)
+    rng = np.random.default_rng(7)
+    probs = _peaky_probs(rng, 2, 300, len(labels))
+    _compare(native, probs, np.array([300, 171], dtype=np.int32), labels, beam=48, lm_path=path, alpha=1.1, beta=0.3,
+             cutoff_top_n=15, cutoff_prob=0.98, n_check=24)
+
+
 def test_lm_file_errors(native, tmp_path):
     dec = native.NativeDecoder(syn.DANSPEECH_LABELS, blank_index=0)
     with pytest.raises(native.DsmiError):

@@ -300,3 +300,25 @@ def test_extreme_lengths_vs_oracle(native):
     p1, ol1 = m.forward(_dev(x[4:5, :, :, :1].copy()), lens[4:5])
     np.testing.assert_allclose(p1.cpu().numpy()[0, :1], ref[4, :1], rtol=0, atol=1e-5)
     m.close()
+
+
+@pytest.mark.parametrize("kind,H,L,cl,bidir", [("lstm", 800, 2, 2, True),        # full-width LSTM: 4 gates x 8 units fill the MFMA row tile
+                                               ("rnn", 800, 2, 2, True),         # tanh RNN at full width
+                                               ("gru", 1200, 3, 3, True),        # docstring-Primary shape: 3 conv (96-channel third layer), wide layers
+                                               ("gru", 800, 2, 2, False)])       # unidirectional + Lookahead(context 20) at full width
+def test_full_width_variants_vs_oracle(native, kind, H, L, cl, bidir):
+    from oracle import model as om
+    sd = syn.make_state_dict(cl, kind, H, L, bidirectional=bidir, context=20, seed=61, fc_gain=6.0)
+    cfg = _cfg(cl, kind, H, L, bidir, 20)
+    lens = np.array([201, 150, 64], dtype=np.int32)
+    x = syn.make_features(3, 201, seed=62)
+    for b, Lb in enumerate(lens):
+        x[b, :, :, Lb:] = 0
+    m = native.NativeModel(cfg, sd)
+    p, ol = m.forward(_dev(x), lens)
+    ref, ol_ref = om.forward(sd, cfg, x, lens)
+    assert np.array_equal(ol, ol_ref)
+    err = np.abs(p.cpu().numpy() - ref).max()
+    print("%s H=%d L=%d conv=%d bidir=%d: max |probs - oracle| = %.3g" % (kind, H, L, cl, bidir, err))
+    assert err < 1e-4
+    m.close()

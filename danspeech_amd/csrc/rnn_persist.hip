@@ -139,6 +139,7 @@ __global__ __launch_bounds__(PNT) void rnn_persist_kernel(PersistArgs p) {
     }
     __syncthreads();
 
+    unsigned* pend = nullptr;      // MULTI: counter of the tile just published, not yet signalled
     for (int s = 0; s < p.T; ++s) {
         const int t = d == 0 ? s : p.T - 1 - s;
       for (int z = 0; z < nz; ++z) {
@@ -203,7 +204,11 @@ __global__ __launch_bounds__(PNT) void rnn_persist_kernel(PersistArgs p) {
             const int i = (r & 3) + 8 * (r >> 2) + 4 * hk;
             red[(v * 32 + i) * RP + li] = acc[r] + acl[r] * kLoInv;
         }
+        if (MULTI) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the previous tile's state stores are acknowledged
         __syncthreads();
+        // MULTI: the previous tile is signalled only now -- its write-through stores drained while this tile waited,
+        // loaded and multiplied, so no wave ever sits in a drain; consumers need that tile a whole round of tiles later
+        if (MULTI && tid == 0 && pend) __hip_atomic_fetch_add(pend, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         PSTAMP(3);   // partial tiles to LDS + barrier (wave skew)
         // ---- K-split reduction (fixed order) + cell, one (unit, batch) pair per thread
         if (tid < PU * 32) {
@@ -251,9 +256,13 @@ __global__ __launch_bounds__(PNT) void rnn_persist_kernel(PersistArgs p) {
             __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, h2), hrs, off + 1024u, 0, 16);
         }
         PSTAMP(4);   // reduction + cell + publish
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave drains its own stores
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(&cnt[s], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (MULTI) {
+            pend = &cnt[s];                                        // signalled after the next tile's MFMAs (see above)
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave drains its own stores
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(&cnt[s], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         PSTAMP(5);   // publish + drain + signal
       }
     }

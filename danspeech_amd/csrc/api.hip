@@ -109,12 +109,15 @@ extern "C" int dsmi_model_create(const dsmi_model_desc* d, int device, dsmi_mode
     m->I0 = kConvSpecs[d->conv_layers - 1].co * f;           // model.py:365,379,396
     m->geom = make_rnn_geom(d->rnn_type, d->rnn_hidden_size, d->bidirectional ? 2 : 1);
     m->Hs = m->geom.Kp;
+    m->geom16 = make_rnn_geom_u(d->rnn_type, d->rnn_hidden_size, d->bidirectional ? 2 : 1, 16);
+    m->have16 = d->rnn_hidden_size % 16 == 0;
     m->rnn.resize(d->rnn_layers);
     {
         hipDeviceProp_t prop;
         m->n_cus = hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount : 0;
-        const char* mode = std::getenv("DSMI_RNN_MODE");      // "steps" forces one launch per time step
+        const char* mode = std::getenv("DSMI_RNN_MODE");      // "steps": one launch per time step; "persist8": first-generation persistent kernel
         m->rnn_mode = (mode && std::string(mode) == "steps") ? 0 : 1;
+        m->persist_gen = (mode && std::string(mode) == "persist8") ? 1 : 2;
         const char* gm = std::getenv("DSMI_GEMM_MODE");       // "f32" forces the fp32-MFMA GEMM
         m->gemm_mode = (gm && std::string(gm) == "f32") ? 0 : 1;
         const char* cm = std::getenv("DSMI_CONV_MODE");       // "f32" forces the fp32-MFMA conv for all layers
@@ -231,6 +234,21 @@ extern "C" int dsmi_model_finalize(dsmi_model* m) {
             if ((rc = upload(m, pack_whh_split(g, wh[dd]->data.data()), &r.whh_sp[dd]))) return rc;
             if ((rc = upload(m, bh[dd]->data, &r.bhh[dd]))) return rc;
         }
+        if (m->have16) {
+            const RnnGeom& g16 = m->geom16;
+            std::vector<float> w16((size_t)g16.Np * r.ldw, 0.f), b16(g16.Np, 0.f);
+            for (int col = 0; col < g16.Np; ++col) {
+                int dd;
+                const int src = rnn_src_row(g16, col, &dd);
+                if (src < 0) continue;
+                std::memcpy(&w16[(size_t)col * r.ldw], &wi[dd]->data[(size_t)src * I], sizeof(float) * I);
+                b16[col] = bi[dd]->data[src];
+            }
+            if ((rc = upload(m, pack_gemm_w_split(w16.data(), g16.Np, r.K, r.ldw), &r.wih16_sp))) return rc;
+            if ((rc = upload(m, b16, &r.bih16))) return rc;
+            for (int dd = 0; dd < g.D; ++dd)
+                if ((rc = upload(m, pack_whh16(g16, wh[dd]->data.data()), &r.whh16_sp[dd]))) return rc;
+        }
         if (l > 0) {  // model.py:403-404: BatchNorm1d(H) in front of layers >= 1
             std::vector<float> a, b;
             if (!bn_affine(m, "rnns." + std::to_string(l) + ".batch_norm.module", H, m->Hs, a, b)) return DSMI_ERR_NOT_READY;
@@ -310,7 +328,7 @@ extern "C" int dsmi_reserve(dsmi_model* m, int max_B, int max_T) {
         if ((rc = ws_alloc(m, &m->conv_buf_sp[i], n))) return rc;
     }
     const size_t rows = (size_t)To * max_B;
-    if ((rc = ws_alloc(m, &m->xp, rows * m->geom.Np))) return rc;
+    if ((rc = ws_alloc(m, &m->xp, rows * std::max(m->geom.Np, m->have16 ? m->geom16.Np : 0)))) return rc;
     for (int i = 0; i < 2; ++i)
         for (int dd = 0; dd < 2; ++dd) {
             m->hbuf[i][dd] = nullptr;
@@ -336,7 +354,12 @@ extern "C" int dsmi_reserve(dsmi_model* m, int max_B, int max_T) {
         const size_t kt = (size_t)ceil_div(std::max(m->I0, m->Hs), 32);
         if ((rc = ws_alloc(m, &m->a_sp, mt * kt * 2 * 4096))) return rc;
     }
-    if ((rc = ws_alloc(m, &m->pcnt, (size_t)m->geom.D * ceil_div(max_B, 32) * std::max(To, 1)))) return rc;
+    if (m->have16) {
+        const size_t n = rnn_persist16_state_halfs(m->geom16, max_B);
+        if ((rc = ws_alloc(m, &m->hpack16, n))) return rc;
+        HIP_OK(m, hipMemset(m->hpack16, 0, n * sizeof(uint16_t)));
+    }
+    if ((rc = ws_alloc(m, &m->pcnt, (size_t)m->geom.D * ceil_div(max_B, 16) * std::max(To, 1)))) return rc;
     if ((rc = ws_alloc(m, &m->perr, (size_t)4))) return rc;
     HIP_OK(m, hipMemset(m->perr, 0, 4 * sizeof(unsigned)));
     m->look_buf = nullptr;
@@ -420,9 +443,33 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
     double sumlen = 0;
     for (int i = 0; i < B; ++i) sumlen += m->host_out_lens[i];
     const double GH = (double)m->geom.G * m->desc.rnn_hidden_size, Dd = m->geom.D;
+    int pgroups = 0;
+    const bool use16 = m->rnn_mode == 1 && m->persist_gen == 2 && m->gemm_mode == 1 && m->have16 && gl.w_sp &&
+                       rnn_persist16_eligible(m->geom16, B, m->n_cus, &pgroups);
+    if (use16) {      // the second-generation kernel reads the x-projection in its own column order
+        gl.w_sp = m->rnn[l].wih16_sp; gl.bias = m->rnn[l].bih16; gl.N = m->geom16.Np; gl.ldc = m->geom16.Np;
+    }
     gl.ev = timer_arm(m, gl.mode == GEMM_A_CONV ? KK_GEMM0 : KK_GEMM, true, 2.0 * Dd * GH * gl.K * sumlen,
                       4.0 * ((double)gl.M * gl.K * (gl.a2 ? 2 : 1) + (double)gl.N * gl.K + (double)gl.M * gl.N));
     launch_gemm(gl, s);
+    if (use16) {
+        RnnPersist16Launch pl;
+        pl.g = m->geom16;
+        for (int dd = 0; dd < 2; ++dd) { pl.whh16[dd] = m->rnn[l].whh16_sp[dd]; pl.bhh[dd] = m->rnn[l].bhh[dd]; pl.out[dd] = m->hbuf[dst][dd]; }
+        pl.xp = m->xp; pl.lens_dev = m->lens_dev; pl.hpack16 = m->hpack16; pl.counters = m->pcnt; pl.err = m->perr;
+        pl.B = B; pl.T = To; pl.pgroups = pgroups;
+        (void)hipMemsetAsync(m->pcnt, 0, sizeof(unsigned) * (size_t)m->geom.D * ceil_div(B, 16) * To, s);
+        hipEvent_t gate = persist_gate(m->device);
+        if (gate) (void)hipStreamWaitEvent(s, gate, 0);
+        pl.ev = timer_arm(m, KK_PERSIST, true, 2.0 * Dd * GH * m->desc.rnn_hidden_size * sumlen,
+                          4.0 * Dd * (GH * m->desc.rnn_hidden_size + (double)To * B * (GH + 2.0 * m->desc.rnn_hidden_size)));
+        const bool ok = launch_rnn_persist16(pl, s);
+        if (gate) (void)hipEventRecord(gate, s);
+        if (ok) return;
+        // (not reachable for eligible shapes; the x-projection is in the other column order, so redo it)
+        gl.w_sp = m->rnn[l].wih_sp; gl.bias = m->rnn[l].bih; gl.N = m->geom.Np; gl.ldc = m->geom.Np; gl.ev = EvPair{};
+        launch_gemm(gl, s);
+    }
     if (m->rnn_mode == 1 && rnn_persist_eligible(m->geom, B, m->n_cus)) {
         // whole layer in one launch; counters are single-use per step, zeroed right before
         RnnPersistLaunch pl;

@@ -143,6 +143,24 @@ bool rnn_persist_eligible(const RnnGeom& g, int B, int n_cus);
 std::vector<uint16_t> pack_whh_split(const RnnGeom& g, const float* w_hh);
 bool launch_rnn_persist(const RnnPersistLaunch& p, hipStream_t s);
 
+// rnn_persist16.hip: second-generation persistent layer (16 units per workgroup, 16-clip batch tiles as separate
+// chains side by side); needs the x-projection in the U = 16 geometry.
+RnnGeom make_rnn_geom_u(int kind, int H, int D, int U);
+struct RnnPersist16Launch {
+    RnnGeom g;                   // make_rnn_geom_u(kind, H, D, 16)
+    const uint16_t* whh16[2];    // pack_whh16 output per direction
+    const float* bhh[2]; const float* xp; float* out[2];
+    const int32_t* lens_dev; uint16_t* hpack16;     // rnn_persist16_state_halfs(g, B) fp16 values
+    unsigned* counters;          // [D * ceil(B/16)][T], zeroed before the launch
+    unsigned* err;
+    int B, T, pgroups;           // pgroups from rnn_persist16_eligible
+    EvPair ev;
+};
+bool rnn_persist16_eligible(const RnnGeom& g16, int B, int n_cus, int* pgroups_out);
+std::vector<uint16_t> pack_whh16(const RnnGeom& g16, const float* w_hh);
+size_t rnn_persist16_state_halfs(const RnnGeom& g16, int B);
+bool launch_rnn_persist16(const RnnPersist16Launch& p, hipStream_t s);
+
 // head.hip
 //   lookahead: y[t][b][h] = clip(sum_k w[h][k] * x[t+k][b][h], 0, 20)
 void launch_lookahead(const float* x, const float* w, float* y, int T, int B, int H, int context, hipStream_t s);

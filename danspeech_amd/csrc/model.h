@@ -16,6 +16,8 @@ struct RnnW {
     float* whh[2] = {nullptr, nullptr};  // packed MFMA operand stream per direction
     uint16_t* whh_sp[2] = {nullptr, nullptr};  // two-term fp16 split of the same, persistent kernel
     float* bhh[2] = {nullptr, nullptr};  // torch layout [G*H]
+    // the same x-projection weights permuted for the 16-unit geometry of rnn_persist16.hip (H % 16 == 0 only)
+    uint16_t* wih16_sp = nullptr; float* bih16 = nullptr; uint16_t* whh16_sp[2] = {nullptr, nullptr};
     float* bn_a = nullptr;  // [Hs] BatchNorm1d in front of layers >= 1
     float* bn_b = nullptr;
     int K = 0, ldw = 0;
@@ -46,6 +48,8 @@ struct dsmi_model {
     int conv_fi[3] = {0, 0, 0}, conv_fo[3] = {0, 0, 0};
     int I0 = 0, Hs = 0;
     dsmi::RnnGeom geom{};
+    dsmi::RnnGeom geom16{};       // U = 16 geometry of the second-generation persistent kernel
+    bool have16 = false;          // geom16 weights were packed (H % 16 == 0)
 
     // weights (device)
     ConvW conv[3];
@@ -65,6 +69,7 @@ struct dsmi_model {
     float* look_buf = nullptr;
     float* hpack = nullptr;
     uint16_t* hpack_sp = nullptr;
+    uint16_t* hpack16 = nullptr;   // packed split state of rnn_persist16.hip
     uint16_t* a_sp = nullptr;       // split A operand of the x-projection GEMM
     unsigned* pcnt = nullptr;     // persistent-kernel step counters [layers][D*ceil(B/32)][T]
     unsigned* perr = nullptr;     // persistent-kernel timeout word (device)
@@ -73,6 +78,7 @@ struct dsmi_model {
     int conv_mode = 1;            // 1: split-fp16 conv for the 32-input-channel layers, 0: fp32 MFMA conv
     int gemm_mode = 1;            // 1: split-fp16 GEMM, 0: fp32 MFMA GEMM
     int rnn_mode = 1;             // 1: persistent layer kernel when eligible, 0: one launch per step
+    int persist_gen = 2;          // 2: rnn_persist16.hip where eligible (DSMI_RNN_MODE=persist8 selects the first generation)
     float* xin = nullptr;
     std::vector<int32_t> host_out_lens;   // output lengths of the batch being processed
     int32_t *lens_dev = nullptr, *sizes_dev = nullptr, *raw_ids = nullptr, *ids = nullptr, *offs = nullptr, *nout = nullptr;

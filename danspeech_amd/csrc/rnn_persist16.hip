@@ -1,0 +1,328 @@
+// Persistent recurrent layer, second generation: 16 hidden units per workgroup, 16-clip batch tiles.
+//
+// Same contract and hand-off protocol as rnn_persist.hip (all T steps of a BatchRNN in one launch, W_hh
+// resident in registers, split-fp16 products, counter form of the agent-scope hand-off, bounded spins), with
+// the work cut the other way.  The step time of the first-generation kernel grows with the width of a chain:
+// measured 2.4 us/step at 13 workgroups per direction, 3.0 at 50, 4.2 at 100, 5.1 at 125
+// (tools/exp/persist_vs_width.py) -- every workgroup ingests the whole state of its chain from L2 each step
+// and waits for every producer of the chain.  So a chain is made half as wide and half as deep:
+//   * a workgroup owns 16 hidden units (G x 16 gate rows = G MFMA row tiles of 16) -> H/16 workgroups per chain;
+//   * a chain carries a tile of 16 clips, the MFMA is v_mfma_f32_16x16x32_f16 (16 gate rows x 16 clips x 32 k);
+//   * the batch tiles of a 32-clip batch run as separate chains on separate CUs, side by side with the two
+//     directions: cfgA, B = 32 -> 2 directions x 2 tiles x 50 workgroups = 200 CUs, each ingesting 50 KB per step
+//     from 50 producers instead of 100 KB from 100.
+// Batches with more tiles than fit side by side are walked tile after tile by every workgroup (signal of a tile
+// deferred behind the next tile's MFMAs, as in rnn_persist.hip).
+//
+// Layouts (k = hidden unit index, kb = k / 32, kg = (k / 8) % 4, e = k % 8):
+//   W_hh split, per direction:  [workgroup][kb][gate][plane 2][lane 64][8 fp16], lane = (unit u = lane & 15, kg = lane >> 4)
+//   state, per parity and chain: [kb][plane 2][kg 4][clip j 16][8 fp16]   (one 1-KiB MFMA B operand per (kb, plane))
+//   x-projection: geometry U = 16 (make_rnn_geom_u), one workgroup's G x 16 gate columns contiguous.
+#include "common.h"
+#include <cstring>
+
+namespace dsmi {
+
+namespace {
+
+constexpr int QNW = 8;                 // waves per workgroup (K-split)
+constexpr int QNT = QNW * 64;
+constexpr int QU = 16;                 // hidden units per workgroup
+constexpr int QB = 16;                 // clips per batch tile
+constexpr int QRP = 20;                // row pitch (words) of the reduce buffer: conflict-free for the MFMA-layout writes
+constexpr int QMAXZ = 8;               // batch tiles one workgroup can walk
+constexpr unsigned Q_SPIN_LIMIT = 1u << 22;
+constexpr size_t Q_LDS = 82 * 1024;    // > half of the CU's LDS: one workgroup per CU
+
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+constexpr float kLoScale = 2048.f, kLoInv = 1.f / 2048.f;
+
+struct P16Args {
+    const uint16_t* whh[2];    // pack_whh16 per direction
+    const float* bhh[2]; const float* xp; float* out[2];
+    const int32_t* lens; uint16_t* hpack; unsigned* cnt; unsigned* err;
+    int B, T, H, Hs, Np, nwg, nkb;
+    int ntiles;                // 16-clip batch tiles
+    int pgroups;               // tile groups running side by side (gridDim.y = D * pgroups); a workgroup walks tiles pg, pg + pgroups, ...
+    int D;
+};
+
+__device__ __forceinline__ float qsigmoid(float v) { return __frcp_rn(1.f + __expf(-v)); }
+__device__ __forceinline__ float qtanh(float v) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * v)); }
+
+// KIND: cell type; NKW: compile-time bound of the 32-wide k-blocks one wave owns.
+template <int KIND, int NKW>
+__global__ __launch_bounds__(QNT) void rnn_persist16_kernel(P16Args p) {
+    constexpr int NG = KIND == DSMI_RNN_GRU ? 3 : (KIND == DSMI_RNN_LSTM ? 4 : 1);
+    extern __shared__ __attribute__((aligned(16))) float qlds[];
+    float* red = qlds;                                               // [QNW][NG][16 units][QRP]
+    int& s_dead = *reinterpret_cast<int*>(red + QNW * 4 * 16 * QRP);
+    float* st_h = red + QNW * 4 * 16 * QRP + 32;                    // [QMAXZ][256] carried state when a workgroup walks several tiles
+    float* st_c = st_h + QMAXZ * 256;
+    int* st_len = reinterpret_cast<int*>(st_c + QMAXZ * 256);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int v = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ln = lane & 15, lg = lane >> 4;                        // MFMA lane roles: column / row index, k-group / row-group
+    const int w = blockIdx.x;
+    const int d = blockIdx.y / p.pgroups, pg = blockIdx.y - d * p.pgroups;
+    const int nz = (p.ntiles - pg + p.pgroups - 1) / p.pgroups;      // tiles this workgroup walks
+    const bool multi = nz > 1;
+    const int GU = NG * QU;
+    const size_t xcol = (size_t)d * p.nwg * GU + (size_t)w * GU;
+    if (tid == 0) s_dead = 0;
+
+    // ---- resident operand: this wave's k-blocks of the split W_hh, all gates
+    const int kb0 = (v * p.nkb) / QNW, kb1 = ((v + 1) * p.nkb) / QNW;
+    f16x8 wv[NKW][NG][2];
+    {
+        const u32x4* wp = reinterpret_cast<const u32x4*>(p.whh[d]) + ((size_t)w * p.nkb) * (NG * 2 * 64) + lane;
+#pragma unroll
+        for (int i = 0; i < NKW; ++i) {
+            const int kb = min(kb0 + i, max(kb1 - 1, kb0));
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) wv[i][g][pl] = __builtin_bit_cast(f16x8, wp[(((size_t)kb * NG + g) * 2 + pl) * 64]);
+        }
+    }
+    const size_t hp_par = (size_t)p.D * p.ntiles * p.nkb * 2048;     // bytes per parity
+    const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.hpack, 0, (int)(2 * hp_par), 0x00020000);
+
+    // cell role: threads 0..255 own (unit u = 8 * (tid >> 7) + (tid & 7), clip j = (tid >> 3) & 15): a wave's 2-byte
+    // stores of the new state are 128 contiguous bytes of one k-group block
+    const int cuh = tid >> 7, ce = tid & 7, cj = (tid >> 3) & 15;
+    const int cu = 8 * cuh + ce;
+    const int cunit = w * QU + cu;
+    const bool cunit_ok = tid < 256 && cunit < p.H;
+    float bh[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) bh[g] = cunit_ok ? p.bhh[d][g * p.H + cunit] : 0.f;
+    int mylen = 0;
+    float hprev_own = 0.f, cprev_own = 0.f;
+    if (tid < 256) {
+        if (multi) {
+            for (int z = 0; z < nz; ++z) {
+                const int eb = (pg + z * p.pgroups) * QB + cj;
+                st_h[z * 256 + tid] = 0.f; st_c[z * 256 + tid] = 0.f;
+                st_len[z * 256 + tid] = (cunit_ok && eb < p.B) ? p.lens[eb] : 0;
+            }
+        } else {
+            const int eb = pg * QB + cj;
+            mylen = (cunit_ok && eb < p.B) ? p.lens[eb] : 0;
+        }
+    }
+    __syncthreads();
+
+    unsigned* pend = nullptr;          // several tiles: counter of the tile just published, signalled behind the next tile's MFMAs
+    for (int s = 0; s < p.T; ++s) {
+        const int t = d == 0 ? s : p.T - 1 - s;
+        for (int z = 0; z < nz; ++z) {
+            const int tile = pg + z * p.pgroups;
+            const int b0 = tile * QB;
+            const int nb = min(QB, p.B - b0);
+            const int eb = b0 + cj;
+            const bool eact = cunit_ok && cj < nb;
+            const int chain = d * p.ntiles + tile;
+            unsigned* cnt = p.cnt + (size_t)chain * p.T;
+            const unsigned hchain = (unsigned)((size_t)chain * p.nkb * 2048);
+            if (multi && tid < 256) { mylen = st_len[z * 256 + tid]; hprev_own = st_h[z * 256 + tid]; cprev_own = st_c[z * 256 + tid]; }
+            // x-projection operands of this step do not depend on other workgroups: request them first
+            float xg[NG];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) xg[g] = 0.f;
+            if (eact) {
+                const float* xr = p.xp + ((size_t)t * p.B + eb) * p.Np + xcol + cu;
+#pragma unroll
+                for (int g = 0; g < NG; ++g) xg[g] = xr[g * QU];
+            }
+            f32x4 acc[NG], acl[NG];        // hi.hi ; (hi.lo + lo.hi) * 2^11
+#pragma unroll
+            for (int g = 0; g < NG; ++g) { acc[g] = f32x4{0.f, 0.f, 0.f, 0.f}; acl[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            if (s > 0) {
+                // ---- wait until every workgroup of this chain has published h_{s-1} (bounded)
+                if (v == 0 && !s_dead) {
+                    unsigned spins = 0;
+                    while (__hip_atomic_load(&cnt[s - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)p.nwg) {
+                        __builtin_amdgcn_s_sleep(1);
+                        ++spins;
+                        if ((spins & 1023u) == 0 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { s_dead = 1; break; }
+                        if (spins > Q_SPIN_LIMIT) { atomicExch(p.err, 1u); s_dead = 1; break; }
+                    }
+                }
+                __syncthreads();
+                // ---- B operand: split h_{s-1} of this wave's k-blocks, sc1 loads only (lane = kg * 16 + clip)
+                const unsigned hbase = (unsigned)(((s - 1) & 1) * hp_par) + hchain + (unsigned)lane * 16u;
+                f16x8 hv[NKW][2];
+#pragma unroll
+                for (int i = 0; i < NKW; ++i) {
+                    const int kb = min(kb0 + i, max(kb1 - 1, kb0));
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl)
+                        hv[i][pl] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                            hrs, hbase + (unsigned)(kb * 2 + pl) * 1024u, 0, 16));
+                }
+#pragma unroll
+                for (int i = 0; i < NKW; ++i) {
+                    if (kb0 + i < kb1) {
+#pragma unroll
+                        for (int g = 0; g < NG; ++g) acl[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[i][g][1], hv[i][0], acl[g], 0, 0, 0);
+#pragma unroll
+                        for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[i][g][0], hv[i][0], acc[g], 0, 0, 0);
+#pragma unroll
+                        for (int g = 0; g < NG; ++g) acl[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[i][g][0], hv[i][1], acl[g], 0, 0, 0);
+                    }
+                }
+            }
+            // partial tiles -> LDS: D[row = unit 4 * lg + r][col = clip ln]
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    red[((v * 4 + g) * 16 + 4 * lg + r) * QRP + ln] = acc[g][r] + acl[g][r] * kLoInv;
+            if (multi) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the previous tile's state stores are acknowledged
+            __syncthreads();
+            if (multi && tid == 0 && pend) __hip_atomic_fetch_add(pend, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // ---- K-split reduction (fixed order) + cell + publish, one (unit, clip) pair per thread
+            if (tid < 256) {
+                float hn = 0.f;
+                if (eact) {
+                    float hg[NG];
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        float sum = 0.f;
+#pragma unroll
+                        for (int k = 0; k < QNW; ++k) sum += red[((k * 4 + g) * 16 + cu) * QRP + cj];
+                        hg[g] = sum + bh[g];
+                    }
+                    if (KIND == DSMI_RNN_GRU) {
+                        const float r = qsigmoid(xg[0] + hg[0]);
+                        const float zz = qsigmoid(xg[1] + hg[1]);
+                        const float n = qtanh(xg[2] + r * hg[2]);
+                        hn = (1.f - zz) * n + zz * hprev_own;
+                    } else if (KIND == DSMI_RNN_LSTM) {
+                        const float ig = qsigmoid(xg[0] + hg[0]);
+                        const float fg = qsigmoid(xg[1] + hg[1]);
+                        const float gg = qtanh(xg[2] + hg[2]);
+                        const float og = qsigmoid(xg[3] + hg[3]);
+                        const float cn = fg * cprev_own + ig * gg;
+                        hn = og * qtanh(cn);
+                        if (t < mylen) cprev_own = cn;
+                    } else {
+                        hn = qtanh(xg[0] + hg[0]);
+                    }
+                    if (t >= mylen) hn = 0.f;         // pad_packed_sequence zero; the reverse chain stays at 0 until len-1
+                    hprev_own = hn;
+                    if (multi) { st_h[z * 256 + tid] = hn; if (KIND == DSMI_RNN_LSTM) st_c[z * 256 + tid] = cprev_own; }
+                    p.out[d][((size_t)t * p.B + eb) * p.Hs + cunit] = hn;
+                } else if (cj < nb && cunit < p.Hs) {
+                    p.out[d][((size_t)t * p.B + eb) * p.Hs + cunit] = 0.f;     // padding units of the last workgroup
+                }
+                const _Float16 h1 = (_Float16)hn;
+                const _Float16 h2 = (_Float16)((hn - (float)h1) * kLoScale);
+                const unsigned off = (unsigned)((s & 1) * hp_par) + hchain + (unsigned)(w >> 1) * 2048u +
+                                     (unsigned)(2 * (w & 1) + cuh) * 256u + (unsigned)cj * 16u + (unsigned)ce * 2u;
+                __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, h1), hrs, off, 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, h2), hrs, off + 1024u, 0, 16);
+            }
+            if (multi) {
+                pend = &cnt[s];
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave drains its own stores
+                __syncthreads();
+                if (tid == 0) __hip_atomic_fetch_add(&cnt[s], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
+inline uint16_t q_f16_bits(_Float16 h) {
+    uint16_t u;
+    std::memcpy(&u, &h, 2);
+    return u;
+}
+
+template <int KIND>
+bool launch16(const P16Args& a, hipStream_t s, const EvPair& ev) {
+    const int nkw = ceil_div(a.nkb, QNW);
+    const dim3 grid(a.nwg, a.D * a.pgroups, 1), block(QNT);
+#define LAUNCH_Q(N)                                                                                                  \
+    do {                                                                                                             \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rnn_persist16_kernel<KIND, N>),                       \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)Q_LDS);                            \
+        DSMI_LAUNCH((rnn_persist16_kernel<KIND, N>), grid, block, Q_LDS, s, ev, a);                                   \
+    } while (0)
+    if (nkw <= 2) LAUNCH_Q(2);
+    else if (nkw <= 4) LAUNCH_Q(4);
+    else if (nkw <= 5 && KIND != DSMI_RNN_LSTM) LAUNCH_Q(5);
+    else return false;
+#undef LAUNCH_Q
+    return true;
+}
+
+}  // namespace
+
+RnnGeom make_rnn_geom_u(int kind, int H, int D, int U) {
+    RnnGeom g = make_rnn_geom(kind, H, D);
+    g.U = U;
+    g.nwg = ceil_div(H, U);
+    g.Np = D * g.nwg * g.G * U;
+    return g;
+}
+
+// H a multiple of 16, at most 4 k-blocks per wave (H <= 1024; 5 for GRU / RNN: H <= 1280), both directions of a
+// tile group co-resident, no more tiles per workgroup than the carried-state arrays hold.
+bool rnn_persist16_eligible(const RnnGeom& g16, int B, int n_cus, int* pgroups_out) {
+    if (g16.U != QU || (g16.H % QU) != 0) return false;
+    const int nkb = ceil_div(g16.H, 32), nkw = ceil_div(nkb, QNW);
+    if (nkw > (g16.kind == DSMI_RNN_LSTM ? 4 : 5)) return false;
+    if (g16.nwg * g16.D > n_cus) return false;
+    const int ntiles = ceil_div(B, QB);
+    const int pg = std::min(ntiles, n_cus / (g16.nwg * g16.D));
+    if (ceil_div(ntiles, pg) > QMAXZ) return false;
+    if (pgroups_out) *pgroups_out = pg;
+    return true;
+}
+
+// w_hh [G*H][H] (torch layout) of one direction -> [workgroup][kb][gate][plane][lane][8] fp16 terms (hi, lo * 2^11);
+// lane (u = lane & 15, kg = lane >> 4) element e holds W[gate * H + 16 * wg + u][32 * kb + 8 * kg + e].
+std::vector<uint16_t> pack_whh16(const RnnGeom& g16, const float* w_hh) {
+    const int nkb = ceil_div(g16.H, 32), G = g16.G, H = g16.H;
+    std::vector<uint16_t> out((size_t)g16.nwg * nkb * G * 2 * 64 * 8, 0);
+    for (int w = 0; w < g16.nwg; ++w)
+        for (int kb = 0; kb < nkb; ++kb)
+            for (int gate = 0; gate < G; ++gate)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int unit = w * QU + (lane & 15);
+                    if (unit >= H) continue;
+                    for (int e = 0; e < 8; ++e) {
+                        const int k = 32 * kb + 8 * (lane >> 4) + e;
+                        if (k >= H) continue;
+                        const float x = w_hh[(size_t)(gate * H + unit) * H + k];
+                        const _Float16 h1 = (_Float16)x;
+                        const _Float16 h2 = (_Float16)((x - (float)h1) * kLoScale);
+                        const size_t base = ((((size_t)w * nkb + kb) * G + gate) * 2) * 512 + (size_t)lane * 8 + e;
+                        out[base] = q_f16_bits(h1); out[base + 512] = q_f16_bits(h2);
+                    }
+                }
+    return out;
+}
+
+size_t rnn_persist16_state_halfs(const RnnGeom& g16, int B) {
+    return (size_t)2 * g16.D * ceil_div(B, QB) * ceil_div(g16.H, 32) * 1024;
+}
+
+bool launch_rnn_persist16(const RnnPersist16Launch& p, hipStream_t s) {
+    P16Args a;
+    for (int d = 0; d < 2; ++d) { a.whh[d] = p.whh16[d]; a.bhh[d] = p.bhh[d]; a.out[d] = p.out[d]; }
+    a.xp = p.xp; a.lens = p.lens_dev; a.hpack = p.hpack16; a.cnt = p.counters; a.err = p.err;
+    a.B = p.B; a.T = p.T; a.H = p.g.H; a.Hs = p.g.Kp; a.Np = p.g.Np; a.nwg = p.g.nwg; a.nkb = ceil_div(p.g.H, 32);
+    a.ntiles = ceil_div(p.B, QB); a.pgroups = p.pgroups; a.D = p.g.D;
+    switch (p.g.kind) {
+        case DSMI_RNN_GRU: return launch16<DSMI_RNN_GRU>(a, s, p.ev);
+        case DSMI_RNN_LSTM: return launch16<DSMI_RNN_LSTM>(a, s, p.ev);
+        default: return launch16<DSMI_RNN_TANH>(a, s, p.ev);
+    }
+}
+
+}  // namespace dsmi

@@ -213,12 +213,16 @@ def test_features_window_and_pad_variants(native):
     fe.close()
 
 
-@pytest.mark.parametrize("H,why", [(904, "10 k-pairs per wave, h taken in two halves"),
-                                   (1200, "config 4 width: 2 x 150 workgroups > 256 CUs, one launch per direction"),
-                                   (100, "H % 8 != 0: per-step fp32-MFMA fallback"),
-                                   (1288, "H > 1280: per-step fp32-MFMA fallback")])
-def test_wide_and_odd_layers_vs_oracle(native, H, why):
+@pytest.mark.parametrize("H,why,gen1_launches", [
+    (904, "not a multiple of 16: first-generation persistent kernel, 10 k-pairs per wave", 1),
+    (1200, "config 4 width: second generation, 75 workgroups x 2 directions, batch tiles walked in turn", None),
+    (1200, "persist8: first generation, 2 x 150 workgroups > 256 CUs, one launch per direction", 2),
+    (100, "H % 8 != 0: per-step fp32-MFMA fallback", None),
+    (1288, "H > 1280: per-step fp32-MFMA fallback", None)])
+def test_wide_and_odd_layers_vs_oracle(native, monkeypatch, H, why, gen1_launches):
     from oracle import model as om
+    if why.startswith("persist8"):
+        monkeypatch.setenv("DSMI_RNN_MODE", "persist8")
     sd = syn.make_state_dict(2, "gru", H, 1, seed=33, fc_gain=4.0)
     cfg = _cfg(2, "gru", H, 1)
     m = native.NativeModel(cfg, sd)
@@ -234,8 +238,28 @@ def test_wide_and_odd_layers_vs_oracle(native, H, why):
     if "fallback" in why:
         assert ks["rnn_step"]["launches"] == int(ol[0]) and "rnn_layer_persistent" not in ks
     else:
-        assert ks["rnn_layer_persistent"]["launches"] == (2 if H == 1200 else 1) and "rnn_step" not in ks
+        assert ks["rnn_layer_persistent"]["launches"] == (gen1_launches or 1) and "rnn_step" not in ks
     m.close()
+
+
+def test_first_and_second_generation_persistent_kernels_agree(native, monkeypatch):
+    """DSMI_RNN_MODE=persist8 (8 units per workgroup, 32-clip tiles) vs the default second generation (16 units,
+    16-clip tiles side by side) on a 40-clip ragged batch: same split-fp16 products, different summation splits."""
+    sd = syn.make_state_dict(2, "gru", 96, 2, seed=37, fc_gain=4.0)
+    cfg = _cfg(2, "gru", 96, 2)
+    rng = np.random.default_rng(38)
+    lens = np.sort(rng.integers(5, 80, size=40))[::-1].astype(np.int32).copy()
+    lens[0] = 80
+    x = syn.make_features(40, 80, seed=39)
+    for b, L in enumerate(lens):
+        x[b, :, :, L:] = 0
+    m2 = native.NativeModel(cfg, sd)
+    p2, _ = m2.forward(_dev(x), lens)
+    monkeypatch.setenv("DSMI_RNN_MODE", "persist8")
+    m1 = native.NativeModel(cfg, sd)
+    p1, _ = m1.forward(_dev(x), lens)
+    np.testing.assert_allclose(p1.cpu().numpy(), p2.cpu().numpy(), rtol=0, atol=2e-5)
+    m1.close(); m2.close()
 
 
 def test_step_path_and_persistent_path_agree(native, monkeypatch):

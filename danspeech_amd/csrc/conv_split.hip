@@ -130,8 +130,9 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvSplitArgs p) {
 
     const u32x4* wbase = reinterpret_cast<const u32x4*>(p.wp_sp) + lane;
     const _Float16* xrow = Xs + (wv * NPL) * ROWPLANE + li * PITCH + hk * 8;
-    // weight fragments of step q = (kf * KT + kt) * 2 + half, one step ahead of the MFMAs
-    f16x8 wf[NCO][NPL], wn[NCO][NPL];
+    // weight fragments of step q = (kf * KT + kt) * 2 + half, two steps ahead of the MFMAs (they come from L2:
+    // a step is 6 MFMAs = 192 cycles, the other wave of the SIMD covers as much again)
+    f16x8 wq[2][NCO][NPL];
     auto load_w = [&](int q, f16x8 (&dst)[NCO][NPL]) {
 #pragma unroll
         for (int c = 0; c < NCO; ++c)
@@ -140,7 +141,8 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvSplitArgs p) {
                 dst[c][pl] = __builtin_bit_cast(f16x8, wbase[(((size_t)q * p.nco + ct + c) * NPL + pl) * 64]);
     };
     constexpr int NQ = KF * KT * 2;
-    load_w(0, wn);
+    load_w(0, wq[0]);
+    load_w(1, wq[1]);
 
     load_rows(0);
     for (int kf = 0; kf < KF; ++kf) {
@@ -153,11 +155,12 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvSplitArgs p) {
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
                     const int q = (kf * KT + kt) * 2 + half;
+                    f16x8 wf[NCO][NPL];
 #pragma unroll
                     for (int c = 0; c < NCO; ++c)
 #pragma unroll
-                        for (int pl = 0; pl < NPL; ++pl) wf[c][pl] = wn[c][pl];
-                    load_w(min(q + 1, NQ - 1), wn);
+                        for (int pl = 0; pl < NPL; ++pl) wf[c][pl] = wq[half][c][pl];
+                    load_w(min(q + 2, NQ - 1), wq[half]);
 #pragma unroll
                     for (int tt = 0; tt < 2; ++tt) {
                         f16x8 xf[NPL];

@@ -359,7 +359,7 @@ extern "C" int dsmi_reserve(dsmi_model* m, int max_B, int max_T) {
         if ((rc = ws_alloc(m, &m->hpack16, n))) return rc;
         HIP_OK(m, hipMemset(m->hpack16, 0, n * sizeof(uint16_t)));
     }
-    if ((rc = ws_alloc(m, &m->pcnt, (size_t)m->geom.D * ceil_div(max_B, 16) * std::max(To, 1)))) return rc;
+    if ((rc = ws_alloc(m, &m->pcnt, (size_t)m->geom.D * ceil_div(max_B, 16) * std::max(To, 1) * kPersist16CntWords))) return rc;
     if ((rc = ws_alloc(m, &m->perr, (size_t)4))) return rc;
     HIP_OK(m, hipMemset(m->perr, 0, 4 * sizeof(unsigned)));
     m->look_buf = nullptr;
@@ -458,7 +458,7 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
         for (int dd = 0; dd < 2; ++dd) { pl.whh16[dd] = m->rnn[l].whh16_sp[dd]; pl.bhh[dd] = m->rnn[l].bhh[dd]; pl.out[dd] = m->hbuf[dst][dd]; }
         pl.xp = m->xp; pl.lens_dev = m->lens_dev; pl.hpack16 = m->hpack16; pl.counters = m->pcnt; pl.err = m->perr;
         pl.B = B; pl.T = To; pl.pgroups = pgroups;
-        (void)hipMemsetAsync(m->pcnt, 0, sizeof(unsigned) * (size_t)m->geom.D * ceil_div(B, 16) * To, s);
+        (void)hipMemsetAsync(m->pcnt, 0, sizeof(unsigned) * (size_t)m->geom.D * ceil_div(B, 16) * To * kPersist16CntWords, s);
         hipEvent_t gate = persist_gate(m->device);
         if (gate) (void)hipStreamWaitEvent(s, gate, 0);
         pl.ev = timer_arm(m, KK_PERSIST, true, 2.0 * Dd * GH * m->desc.rnn_hidden_size * sumlen,

@@ -151,11 +151,13 @@ struct RnnPersist16Launch {
     const uint16_t* whh16[2];    // pack_whh16 output per direction
     const float* bhh[2]; const float* xp; float* out[2];
     const int32_t* lens_dev; uint16_t* hpack16;     // rnn_persist16_state_halfs(g, B) fp16 values
-    unsigned* counters;          // [D * ceil(B/16)][T], zeroed before the launch
+    unsigned* counters;          // [D * ceil(B/16)][T][kPersist16CntWords], zeroed before the launch
     unsigned* err;
     int B, T, pgroups;           // pgroups from rnn_persist16_eligible
     EvPair ev;
 };
+constexpr int kPersist16Shards = 4;                        // shards of the hand-off counter of a (chain, step) ...
+constexpr int kPersist16CntWords = kPersist16Shards * 64;   // ... each on its own 256-byte line
 bool rnn_persist16_eligible(const RnnGeom& g16, int B, int n_cus, int* pgroups_out);
 std::vector<uint16_t> pack_whh16(const RnnGeom& g16, const float* w_hh);
 size_t rnn_persist16_state_halfs(const RnnGeom& g16, int B);

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(QNT) void rnn_persist16_kernel(P16Args p) {
             const int eb = b0 + cj;
             const bool eact = cunit_ok && cj < nb;
             const int chain = d * p.ntiles + tile;
-            unsigned* cnt = p.cnt + (size_t)chain * p.T;
+            unsigned* cnt = p.cnt + (size_t)chain * p.T * kPersist16CntWords;
             const unsigned hchain = (unsigned)((size_t)chain * p.nkb * 2048);
             if (multi && tid < 256) { mylen = st_len[z * 256 + tid]; hprev_own = st_h[z * 256 + tid]; cprev_own = st_c[z * 256 + tid]; }
             // x-projection operands of this step do not depend on other workgroups: request them first
@@ -141,9 +141,15 @@ __global__ __launch_bounds__(QNT) void rnn_persist16_kernel(P16Args p) {
             for (int g = 0; g < NG; ++g) { acc[g] = f32x4{0.f, 0.f, 0.f, 0.f}; acl[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
             if (s > 0) {
                 // ---- wait until every workgroup of this chain has published h_{s-1} (bounded)
+                // the counter of a (chain, step) is sharded (workgroup id % kPersist16Shards), each shard on its own 256-byte
+                // line: atomics and polls on one line are served one at a time, ~10 ns each
                 if (v == 0 && !s_dead) {
                     unsigned spins = 0;
-                    while (__hip_atomic_load(&cnt[s - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)p.nwg) {
+                    const unsigned* cp = &cnt[(size_t)(s - 1) * kPersist16CntWords + (lane & (kPersist16Shards - 1)) * 64];
+                    const unsigned need = (unsigned)((p.nwg + kPersist16Shards - 1 - (lane & (kPersist16Shards - 1))) / kPersist16Shards);   // workgroups w with w % shards == lane
+                    while (true) {
+                        const unsigned got = lane < kPersist16Shards ? __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need;
+                        if (__builtin_amdgcn_ballot_w64(got < need) == 0) break;
                         __builtin_amdgcn_s_sleep(1);
                         ++spins;
                         if ((spins & 1023u) == 0 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { s_dead = 1; break; }
@@ -226,11 +232,11 @@ __global__ __launch_bounds__(QNT) void rnn_persist16_kernel(P16Args p) {
                 __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, h2), hrs, off + 1024u, 0, 16);
             }
             if (multi) {
-                pend = &cnt[s];
+                pend = &cnt[(size_t)s * kPersist16CntWords + (w & (kPersist16Shards - 1)) * 64];
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave drains its own stores
                 __syncthreads();
-                if (tid == 0) __hip_atomic_fetch_add(&cnt[s], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (tid == 0) __hip_atomic_fetch_add(&cnt[(size_t)s * kPersist16CntWords + (w & (kPersist16Shards - 1)) * 64], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }

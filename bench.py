@@ -42,7 +42,7 @@ PEAK_HBM_GBS = 8000.0
 
 # HBM/fabric bytes per launch from rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE,
 # collected in separate passes (profiles/r01_pmc_*.md); None where no pass has been run.
-PMC_TRAFFIC = {"rnn_layer_persistent": 1.23e9 + 0.21e9}   # profiles/r01f_pmc_rnn_persist16.md
+PMC_TRAFFIC = {"rnn_layer_persistent": 1.24e9 + 0.21e9}   # profiles/r01f_pmc_rnn_persist16.md
 
 CONFIGS = {
     # BASELINE.json configs[1]: "DanSpeechPrimary (5-layer BiRNN, 800 hidden), greedy decode,

@@ -762,7 +762,8 @@ extern "C" int dsmi_debug_step_stamps(dsmi_model* m, int layer, int B, int To, i
 }
 
 // ---- diagnostics: accumulated per-wave phase times (100 MHz ticks) of one persistent layer launch;
-// stamps_host[D*nwg][8 waves][8]: 0 loop head, 1 wait, 2 h load + MFMA, 3 LDS + barrier, 4 cell, 5 publish.
+// stamps_host[workgroups][8 waves][8]: 0 loop head, 1 wait, 2 h load + MFMA, 3 LDS + barrier, 4 cell (+ publish stores),
+// 5 drain + signal.  Returns the number of workgroups stamped (> 0) or a DSMI_ERR_* code (< 0).
 extern "C" int dsmi_debug_persist_stamps(dsmi_model* m, int layer, int B, int To, uint64_t* stamps_host, int64_t n_words) {
     if (!m || !m->finalized || B > 32 || layer < 0 || layer >= m->desc.rnn_layers || !rnn_persist_eligible(m->geom, B, m->n_cus) ||
         m->geom.nwg * m->geom.D > m->n_cus) return DSMI_ERR_INVALID;
@@ -771,14 +772,33 @@ extern "C" int dsmi_debug_persist_stamps(dsmi_model* m, int layer, int B, int To
     int rc;
     if ((rc = dsmi_reserve(m, B, Tin))) return rc;
     HIP_OK(m, hipSetDevice(m->device));
-    const int64_t need = (int64_t)m->geom.D * m->geom.nwg * 8 * 8;
+    int pgroups = 0;
+    const bool use16 = m->persist_gen == 2 && m->have16 && rnn_persist16_eligible(m->geom16, B, m->n_cus, &pgroups) &&
+                       ceil_div(B, 16) <= pgroups;        // one tile per workgroup: the plain single-tile path is what is stamped
+    const int64_t need = use16 ? (int64_t)m->geom16.D * pgroups * m->geom16.nwg * 8 * 8 : (int64_t)m->geom.D * m->geom.nwg * 8 * 8;
     if (n_words < need) return fail(m, DSMI_ERR_INVALID, "stamp buffer too small");
     unsigned long long* dbg;
     HIP_OK(m, hipMalloc((void**)&dbg, sizeof(unsigned long long) * need));
     HIP_OK(m, hipMemset(dbg, 0, sizeof(unsigned long long) * need));
     std::vector<int32_t> lens(B, To);
     HIP_OK(m, hipMemcpy(m->lens_dev, lens.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice));
-    HIP_OK(m, hipMemset(m->xp, 0, sizeof(float) * (size_t)To * B * m->geom.Np));
+    HIP_OK(m, hipMemset(m->xp, 0, sizeof(float) * (size_t)To * B * std::max(m->geom.Np, m->have16 ? m->geom16.Np : 0)));
+    if (use16) {
+        RnnPersist16Launch pl;
+        pl.g = m->geom16;
+        for (int dd = 0; dd < 2; ++dd) { pl.whh16[dd] = m->rnn[layer].whh16_sp[dd]; pl.bhh[dd] = m->rnn[layer].bhh[dd]; pl.out[dd] = m->hbuf[0][dd]; }
+        pl.xp = m->xp; pl.lens_dev = m->lens_dev; pl.hpack16 = m->hpack16; pl.counters = m->pcnt; pl.err = m->perr;
+        pl.B = B; pl.T = To; pl.pgroups = pgroups;
+        for (int rep = 0; rep < 2; ++rep) {     // first pass warms up, second is stamped
+            HIP_OK(m, hipMemset(m->pcnt, 0, sizeof(unsigned) * (size_t)m->geom.D * ceil_div(B, 16) * To * kPersist16CntWords));
+            pl.dbg = rep ? dbg : nullptr;
+            launch_rnn_persist16(pl, nullptr);
+            HIP_OK(m, hipDeviceSynchronize());
+        }
+        HIP_OK(m, hipMemcpy(stamps_host, dbg, sizeof(unsigned long long) * need, hipMemcpyDeviceToHost));
+        (void)hipFree(dbg);
+        return (int)(need / 64);      // number of workgroups stamped
+    }
     RnnPersistLaunch pl;
     pl.g = m->geom;
     for (int dd = 0; dd < 2; ++dd) { pl.whh_sp[dd] = m->rnn[layer].whh_sp[dd]; pl.bhh[dd] = m->rnn[layer].bhh[dd]; pl.out[dd] = m->hbuf[0][dd]; }
@@ -792,5 +812,5 @@ extern "C" int dsmi_debug_persist_stamps(dsmi_model* m, int layer, int B, int To
     }
     HIP_OK(m, hipMemcpy(stamps_host, dbg, sizeof(unsigned long long) * need, hipMemcpyDeviceToHost));
     (void)hipFree(dbg);
-    return DSMI_OK;
+    return (int)(need / 64);          // number of workgroups stamped
 }

@@ -155,6 +155,7 @@ struct RnnPersist16Launch {
     unsigned* err;
     int B, T, pgroups;           // pgroups from rnn_persist16_eligible
     EvPair ev;
+    unsigned long long* dbg = nullptr;   // diagnostics: accumulated per-wave phase times
 };
 constexpr int kPersist16Shards = 4;                        // shards of the hand-off counter of a (chain, step) ...
 constexpr int kPersist16CntWords = kPersist16Shards * 64;   // ... each on its own 256-byte line

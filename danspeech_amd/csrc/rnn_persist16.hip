@@ -46,14 +46,27 @@ struct P16Args {
     int ntiles;                // 16-clip batch tiles
     int pgroups;               // tile groups running side by side (gridDim.y = D * pgroups); a workgroup walks tiles pg, pg + pgroups, ...
     int D;
+    unsigned long long* dbg;   // diagnostics build only: per-wave accumulated phase times [workgroup][wave][8]
 };
+
+#define QSTAMP(k)                                                                         \
+    do {                                                                                  \
+        if (STAMP) {                                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                            \
+            const unsigned long long now_ = __builtin_amdgcn_s_memrealtime();             \
+            tacc[k] += now_ - tlast; tlast = now_;                                        \
+            __builtin_amdgcn_sched_barrier(0);                                            \
+        }                                                                                 \
+    } while (0)
 
 __device__ __forceinline__ float qsigmoid(float v) { return __frcp_rn(1.f + __expf(-v)); }
 __device__ __forceinline__ float qtanh(float v) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * v)); }
 
 // KIND: cell type; NKW: compile-time bound of the 32-wide k-blocks one wave owns.
-template <int KIND, int NKW>
+template <int KIND, int NKW, bool STAMP = false>
 __global__ __launch_bounds__(QNT) void rnn_persist16_kernel(P16Args p) {
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = STAMP ? __builtin_amdgcn_s_memrealtime() : 0;
     constexpr int NG = KIND == DSMI_RNN_GRU ? 3 : (KIND == DSMI_RNN_LSTM ? 4 : 1);
     extern __shared__ __attribute__((aligned(16))) float qlds[];
     float* red = qlds;                                               // [QNW][NG][16 units][QRP]
@@ -139,6 +152,7 @@ __global__ __launch_bounds__(QNT) void rnn_persist16_kernel(P16Args p) {
             f32x4 acc[NG], acl[NG];        // hi.hi ; (hi.lo + lo.hi) * 2^11
 #pragma unroll
             for (int g = 0; g < NG; ++g) { acc[g] = f32x4{0.f, 0.f, 0.f, 0.f}; acl[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            QSTAMP(0);   // loop head + x-projection request
             if (s > 0) {
                 // ---- wait until every workgroup of this chain has published h_{s-1} (bounded)
                 // the counter of a (chain, step) is sharded (workgroup id % kPersist16Shards), each shard on its own 256-byte
@@ -157,6 +171,7 @@ __global__ __launch_bounds__(QNT) void rnn_persist16_kernel(P16Args p) {
                     }
                 }
                 __syncthreads();
+                QSTAMP(1);   // waiting for the other workgroups
                 // ---- B operand: split h_{s-1} of this wave's k-blocks, sc1 loads only (lane = kg * 16 + clip)
                 const unsigned hbase = (unsigned)(((s - 1) & 1) * hp_par) + hchain + (unsigned)lane * 16u;
                 f16x8 hv[NKW][2];
@@ -180,6 +195,7 @@ __global__ __launch_bounds__(QNT) void rnn_persist16_kernel(P16Args p) {
                     }
                 }
             }
+            QSTAMP(2);   // h load + MFMA chain
             // partial tiles -> LDS: D[row = unit 4 * lg + r][col = clip ln]
 #pragma unroll
             for (int g = 0; g < NG; ++g)
@@ -189,6 +205,7 @@ __global__ __launch_bounds__(QNT) void rnn_persist16_kernel(P16Args p) {
             if (multi) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the previous tile's state stores are acknowledged
             __syncthreads();
             if (multi && tid == 0 && pend) __hip_atomic_fetch_add(pend, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            QSTAMP(3);   // partial tiles to LDS + barrier (wave skew)
             // ---- K-split reduction (fixed order) + cell + publish, one (unit, clip) pair per thread
             if (tid < 256) {
                 float hn = 0.f;
@@ -231,6 +248,7 @@ __global__ __launch_bounds__(QNT) void rnn_persist16_kernel(P16Args p) {
                 __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, h1), hrs, off, 0, 16);
                 __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, h2), hrs, off + 1024u, 0, 16);
             }
+            QSTAMP(4);   // reduction + cell + publish stores issued
             if (multi) {
                 pend = &cnt[(size_t)s * kPersist16CntWords + (w & (kPersist16Shards - 1)) * 64];
             } else {
@@ -238,7 +256,12 @@ __global__ __launch_bounds__(QNT) void rnn_persist16_kernel(P16Args p) {
                 __syncthreads();
                 if (tid == 0) __hip_atomic_fetch_add(&cnt[(size_t)s * kPersist16CntWords + (w & (kPersist16Shards - 1)) * 64], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            QSTAMP(5);   // drain + barrier + signal
         }
+    }
+    if (STAMP && lane == 0) {
+        unsigned long long* o = p.dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * QNW + v) * 8;
+        for (int k = 0; k < 6; ++k) o[k] = tacc[k];
     }
 }
 
@@ -258,6 +281,12 @@ bool launch16(const P16Args& a, hipStream_t s, const EvPair& ev) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)Q_LDS);                            \
         DSMI_LAUNCH((rnn_persist16_kernel<KIND, N>), grid, block, Q_LDS, s, ev, a);                                   \
     } while (0)
+    if (a.dbg) {
+        if (nkw > 4) return false;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rnn_persist16_kernel<KIND, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Q_LDS);
+        hipLaunchKernelGGL((rnn_persist16_kernel<KIND, 4, true>), grid, block, Q_LDS, s, a);
+        return true;
+    }
     if (nkw <= 2) LAUNCH_Q(2);
     else if (nkw <= 4) LAUNCH_Q(4);
     else if (nkw <= 5 && KIND != DSMI_RNN_LSTM) LAUNCH_Q(5);
@@ -323,7 +352,7 @@ bool launch_rnn_persist16(const RnnPersist16Launch& p, hipStream_t s) {
     for (int d = 0; d < 2; ++d) { a.whh[d] = p.whh16[d]; a.bhh[d] = p.bhh[d]; a.out[d] = p.out[d]; }
     a.xp = p.xp; a.lens = p.lens_dev; a.hpack = p.hpack16; a.cnt = p.counters; a.err = p.err;
     a.B = p.B; a.T = p.T; a.H = p.g.H; a.Hs = p.g.Kp; a.Np = p.g.Np; a.nwg = p.g.nwg; a.nkb = ceil_div(p.g.H, 32);
-    a.ntiles = ceil_div(p.B, QB); a.pgroups = p.pgroups; a.D = p.g.D;
+    a.ntiles = ceil_div(p.B, QB); a.pgroups = p.pgroups; a.D = p.g.D; a.dbg = p.dbg;
     switch (p.g.kind) {
         case DSMI_RNN_GRU: return launch16<DSMI_RNN_GRU>(a, s, p.ev);
         case DSMI_RNN_LSTM: return launch16<DSMI_RNN_LSTM>(a, s, p.ev);

@@ -11,11 +11,12 @@ cfg = dict(conv_layers=2, rnn_type="gru", rnn_hidden_size=H, rnn_layers=2, bidir
 sd = syn.make_state_dict(2, "gru", H, 2, seed=0)
 m = _native.NativeModel(cfg, sd)
 L = _native.lib()
-nwg = H // 8
 T = 501
-buf = np.zeros((2 * nwg, 8, 8), dtype=np.uint64)
-rc = L.dsmi_debug_persist_stamps(m._h, 1, 32, T, buf.ctypes.data_as(C.c_void_p), buf.size)
-assert rc == 0, rc
+buf = np.zeros((256, 8, 8), dtype=np.uint64)
+n = L.dsmi_debug_persist_stamps(m._h, 1, 32, T, buf.ctypes.data_as(C.c_void_p), buf.size)
+assert n > 0, n
+buf = buf[:n]
+print("%d workgroups stamped" % n)
 us = buf.astype(np.float64) * 10.0 / 1000.0 / T      # per-step average, microseconds
 names = ["loop head", "wait", "h load + mfma", "lds + barrier", "cell", "publish"]
 tot = us[:, :, :6].sum(axis=2)

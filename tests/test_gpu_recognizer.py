@@ -241,3 +241,27 @@ def test_recognize_long_equals_per_phrase_recognize():
     assert [(a, b) for a, b, _ in got] == want_segs and len(got) >= 3
     for a, b, text in got:
         assert text == rec.recognize(audio[a:b])
+
+
+def test_recognize_files_groups_by_format_and_segment_takes_raw_wav_frames(tmp_path):
+    """Files of different sample formats in one recognize_files call (one batch per format), and dsmi_segment on
+    a stereo file's raw frames (same phrases as on load_audio's fold of it)."""
+    import wave
+    from danspeech_amd import Recognizer, _native
+    from danspeech_amd.audio import load_audio
+    from danspeech_amd.audio.resources import read_wav_frames
+    mono = (_long_recording(seconds=6, seed=92)).astype(np.int16)
+    p_mono = str(tmp_path / "mono16.wav")
+    with wave.open(p_mono, "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.writeframes(mono.astype("<i2").tobytes())
+    m, sd, cfg = _model("mixed-formats", 64, 2, seed=73)
+    rec = Recognizer(model=m)
+    got = rec.recognize_files([WAV, p_mono, WAV])
+    assert got == [rec.recognize(load_audio(p)) for p in (WAV, p_mono, WAV)]
+    # segmentation straight on the stereo example file's frames
+    raw, width, nch = read_wav_frames(WAV)
+    fe = _native.NativeFrontend()
+    a = fe.segment(torch.from_numpy(np.frombuffer(raw, dtype=np.uint8).copy()).cuda(), energy_threshold=300, wav_format=(width, nch))
+    b = fe.segment(torch.from_numpy(load_audio(WAV)).cuda(), energy_threshold=300)
+    assert np.array_equal(a, b)
+    fe.close()

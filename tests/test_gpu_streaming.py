@@ -205,3 +205,28 @@ def test_streaming_final_text_from_secondary_model_and_from_lm(tmp_path):
     rec2.enable_real_time_streaming(streaming_model=rec2.danspeech_recognizer.model)
     out2 = list(rec2.stream_recording(audio, chunk_samples=2048))
     assert out2[-1][0] is True and isinstance(out2[-1][1], str)
+
+
+def test_stream_forward_cpu_streaming_rnn_shape_vs_oracle(native):
+    """The shape of pretrained_models.CPUStreamingRNN (2 conv, 5 x GRU 800 unidirectional, context 20)
+    over the real-time chunk sizes: first pass 54 spectrogram frames, then 39 per pass, short last pass."""
+    from oracle import streaming as ost
+    H, L, ctx = 800, 5, 20
+    sd = syn.make_state_dict(2, "gru", H, L, bidirectional=False, context=ctx, seed=89, fc_gain=6.0)
+    cfg = _cfg("gru", H, L, ctx)
+    m = native.NativeModel(cfg, sd)
+    st = native.NativeStream(m)
+    om = ost.StreamingModel(sd, cfg)
+    chunks = [54, 39, 39, 39, 39, 21]
+    worst = 0.0
+    for ci, T in enumerate(chunks):
+        x = syn.make_features(1, T, seed=8900 + ci)
+        y = st.forward(torch.from_numpy(x).cuda(), ci == 0, ci == len(chunks) - 1)
+        ref = om.forward(x, ci == 0, ci == len(chunks) - 1)
+        assert (y is None) == (ref is None)
+        if ref is not None:
+            assert tuple(y.shape) == ref.shape
+            worst = max(worst, float(np.abs(y.cpu().numpy() - ref).max()))
+    print("CPUStreamingRNN shape: max |probs - oracle| = %.3g" % worst)
+    assert worst < 1e-4
+    st.close(); m.close()

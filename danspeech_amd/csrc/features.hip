@@ -89,21 +89,51 @@ __global__ __launch_bounds__(256) void stft_logmag_kernel(const void* pcm, int d
         s_x[i] = v;
     }
     __syncthreads();
+    // Real input: x[n] and x[N-n] meet the same cosine and opposite sines, so fold the frame once
+    // (e[n] = x[n] + x[N-n], o[n] = x[n] - x[N-n], n = 1 .. N/2-1) and run half as many multiply-adds per bin.
+    const bool fold = (n_fft & 1) == 0;
+    const int nh = n_fft / 2;
+    if (fold) {
+        for (int i = tid; i < (nh - 1) * FT; i += 256) {
+            const int f = i % FT, n = 1 + i / FT;
+            const double a = s_x[n * FT + f], c = s_x[(n_fft - n) * FT + f];
+            s_x[n * FT + f] = a + c;
+            s_x[(n_fft - n) * FT + f] = a - c;
+        }
+        __syncthreads();
+    }
     for (int k = tid; k < n_freq; k += 256) {
         double re[FT], im[FT];
-#pragma unroll
-        for (int f = 0; f < FT; ++f) { re[f] = 0.0; im[f] = 0.0; }
         int idx = 0;
-        for (int n = 0; n < n_fft; ++n) {
-            const double c = s_tw[2 * idx], s = s_tw[2 * idx + 1];
+        if (fold) {
+            const double sgn = (k & 1) ? -1.0 : 1.0;          // cos(pi k) of the tap n = N/2
 #pragma unroll
-            for (int f = 0; f < FT; ++f) {
-                const double x = s_x[n * FT + f];
-                re[f] = fma(x, c, re[f]);
-                im[f] = fma(-x, s, im[f]);
+            for (int f = 0; f < FT; ++f) { re[f] = fma(sgn, s_x[nh * FT + f], s_x[f]); im[f] = 0.0; }
+            idx = k;
+            for (int n = 1; n < nh; ++n) {
+                const double c = s_tw[2 * idx], s = s_tw[2 * idx + 1];
+#pragma unroll
+                for (int f = 0; f < FT; ++f) {
+                    re[f] = fma(s_x[n * FT + f], c, re[f]);
+                    im[f] = fma(-s_x[(n_fft - n) * FT + f], s, im[f]);
+                }
+                idx += k;
+                if (idx >= n_fft) idx -= n_fft;
             }
-            idx += k;
-            if (idx >= n_fft) idx -= n_fft;
+        } else {
+#pragma unroll
+            for (int f = 0; f < FT; ++f) { re[f] = 0.0; im[f] = 0.0; }
+            for (int n = 0; n < n_fft; ++n) {
+                const double c = s_tw[2 * idx], s = s_tw[2 * idx + 1];
+#pragma unroll
+                for (int f = 0; f < FT; ++f) {
+                    const double x = s_x[n * FT + f];
+                    re[f] = fma(x, c, re[f]);
+                    im[f] = fma(-x, s, im[f]);
+                }
+                idx += k;
+                if (idx >= n_fft) idx -= n_fft;
+            }
         }
 #pragma unroll
         for (int f = 0; f < FT; ++f) {

@@ -193,14 +193,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
 // W is split and tiled once on the host (pack_gemm_w_split: [n-tile][k-tile][plane][128][32] fp16, so
 // the operand loads are fully coalesced 16-byte copies); the activations are split ONCE per GEMM
 // by split_a_kernel, fused with the same producer transforms as the fp32 kernel (direction sum +
-// BatchNorm1d, conv transpose), into the same tiled form.  Tile 128x128x32, 4 waves in 2x2, one
-// LDS stage (40 KiB), next tile's global loads in flight in registers during the MFMAs.
+// BatchNorm1d, conv transpose), into the same tiled form.  Tile 128x128x32, 4 waves in 2x2, two
+// LDS stages filled by direct global->LDS loads (no VGPR staging), one barrier per k-tile.
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 
-constexpr int XS = 40;                 // LDS row stride in halfs (80 B: 16 consecutive rows hit 64 distinct banks)
-constexpr int XPLANE = 128 * XS;       // elements per plane of one operand tile
 constexpr int XT_STRIDE = 129;         // f32 transpose tile [32 k][129] (GEMM_A_CONV)
 constexpr float kLoScale = 2048.f, kLoInv = 1.f / 2048.f;
 
@@ -273,8 +271,6 @@ __global__ __launch_bounds__(256) void split_a_kernel(GemmSplitArgs p, uint16_t*
 template <bool CONV_ROWS>
 __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmSplitArgs p, const uint16_t* a_sp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
-    _Float16* As = reinterpret_cast<_Float16*>(smem3);        // [2 k-tiles][2 planes][128][XS]
-    _Float16* Ws = As + 4 * XPLANE;                            // [2 k-tiles][2 planes][128][XS]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1;
     const int li = lane & 31, hk = lane >> 5;
@@ -297,36 +293,35 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmSplitArgs p, con
     int m0 = mt * BM, bb = 0, t0 = 0;
     if (CONV_ROWS) { bb = mt / p.tiles_per_b; t0 = (mt % p.tiles_per_b) * BM; }
 
-    // Pipeline: LDS holds two stages (k-tiles), so there is ONE barrier per k-tile: tile kt+1 is written to the
-    // other stage at the end of iteration kt (its global loads were issued a whole iteration earlier), and the
-    // fragments of the next k-step are read from LDS while the current k-step's 12 MFMAs run.
-    u32x4 ra[4], rw[4];
-    const u32x4* atile = reinterpret_cast<const u32x4*>(a_sp) + (size_t)mt * p.ktiles * (2 * 128 * 4);
-    const u32x4* wtile = reinterpret_cast<const u32x4*>(p.w_sp) + (size_t)nt * p.ktiles * (2 * 128 * 4);
-    auto load_global = [&](int kt) {
-        const u32x4* at = atile + (size_t)kt * (2 * 128 * 4);
-        const u32x4* wt = wtile + (size_t)kt * (2 * 128 * 4);
+    // Pipeline: LDS holds two stages (k-tiles) that are filled by direct global->LDS loads (global_load_lds_dwordx4:
+    // no VGPR staging, no ds_write instructions); tile kt+1 is requested at the top of iteration kt and must have
+    // landed at its end: ONE barrier per k-tile.  A wave instruction deposits 1 KiB contiguously, so the rows are
+    // unpadded (64 B) and bank conflicts are avoided by XOR-swizzling the four 16-byte chunks of a row with
+    // (row >> 2) & 3 -- applied on the global address when loading and on the LDS address when reading fragments.
+    const unsigned char* atile = reinterpret_cast<const unsigned char*>(a_sp) + (size_t)mt * p.ktiles * 16384;
+    const unsigned char* wtile = reinterpret_cast<const unsigned char*>(p.w_sp) + (size_t)nt * p.ktiles * 16384;
+    unsigned char* lds = smem3;                                    // [stage][A hi, A lo, W hi, W lo][128 rows][64 B]
+    const int drow = lane >> 2, dchunk = (lane & 3) ^ ((lane >> 4) & 3);        // this lane's row within a 16-row block, logical chunk
+    auto dma = [&](int kt, int stage) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { ra[i] = at[tid + 256 * i]; rw[i] = wt[tid + 256 * i]; }
-    };
-    auto store_lds = [&](int stage) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = tid + 256 * i;
-            const int off = stage * (2 * XPLANE) + (c >> 9) * XPLANE + ((c >> 2) & 127) * XS + (c & 3) * 8;
-            *reinterpret_cast<u32x4*>(As + off) = ra[i];
-            *reinterpret_cast<u32x4*>(Ws + off) = rw[i];
+        for (int i = 0; i < 8; ++i) {
+            const int j = wid * 8 + i;                 // 1-KiB block 0..31: operand j >> 4, plane (j >> 3) & 1, rows 16 * (j & 7) ..
+            const unsigned char* src = ((j >> 4) ? wtile : atile) + (size_t)kt * 16384 + ((j >> 3) & 1) * 8192 +
+                                       (16 * (j & 7) + drow) * 64 + dchunk * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(lds + stage * 32768 + j * 1024), 16, 0, 0);
         }
     };
     f16x8 af[2][2][2], wf[2][2][2];      // [buffer][tile][plane]
     auto read_frags = [&](int buf, int stage, int ks) {
-        const int sub = stage * (2 * XPLANE) + ks * 16 + hk * 8;
+        const unsigned char* st = lds + stage * 32768;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) {
-                af[buf][mi][pl] = *reinterpret_cast<const f16x8*>(As + sub + pl * XPLANE + (wr * 64 + mi * 32 + li) * XS);
-                wf[buf][mi][pl] = *reinterpret_cast<const f16x8*>(Ws + sub + pl * XPLANE + (wc * 64 + mi * 32 + li) * XS);
+                const int ra_ = wr * 64 + mi * 32 + li, rw_ = wc * 64 + mi * 32 + li;
+                af[buf][mi][pl] = *reinterpret_cast<const f16x8*>(st + pl * 8192 + ra_ * 64 + (((ks * 2 + hk) ^ ((ra_ >> 2) & 3)) * 16));
+                wf[buf][mi][pl] = *reinterpret_cast<const f16x8*>(st + 16384 + pl * 8192 + rw_ * 64 + (((ks * 2 + hk) ^ ((rw_ >> 2) & 3)) * 16));
             }
     };
 
@@ -338,13 +333,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmSplitArgs p, con
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; acl[i][j][r] = 0.f; }
 
-    load_global(0);
-    store_lds(0);
+    dma(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (p.ktiles > 1) load_global(1);
     read_frags(0, 0, 0);
     for (int kt = 0; kt < p.ktiles; ++kt) {
         const int stage = kt & 1;
+        if (kt + 1 < p.ktiles) dma(kt + 1, stage ^ 1);      // the other stage was last read in iteration kt-1 (barrier below)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             if (ks == 0) read_frags(1, stage, 1);          // next k-step of this tile, while this one computes
@@ -365,13 +360,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmSplitArgs p, con
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
                     acl[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cb][mi][0], wf[cb][ni][1], acl[mi][ni], 0, 0, 0);
-            if (ks == 0 && kt + 1 < p.ktiles) store_lds(stage ^ 1);      // tile kt+1 -> the other stage (last read in iteration kt-1)
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's share of tile kt+1 has landed
         __syncthreads();
-        if (kt + 1 < p.ktiles) {
-            if (kt + 2 < p.ktiles) load_global(kt + 2);
-            read_frags(0, stage ^ 1, 0);
-        }
+        if (kt + 1 < p.ktiles) read_frags(0, stage ^ 1, 0);
     }
 
 #pragma unroll
@@ -437,7 +429,7 @@ void launch_gemm(const GemmLaunch& g, hipStream_t s) {
         }
         a.ntiles = ceil_div(g.N, BN); a.mtiles = mtiles3;
         const dim3 grid3(8 * ceil_div(a.ntiles * a.mtiles, 8));
-        const size_t lds3 = (size_t)8 * XPLANE * 2;     // 80 KiB: two workgroups fill the CU's 160 KiB exactly
+        const size_t lds3 = (size_t)2 * 32768;          // two stages of four 8-KiB operand planes
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
         if (g.mode == GEMM_A_CONV) DSMI_LAUNCH(gemm_f16x3_kernel<true>, grid3, dim3(256), lds3, s, g.ev, a, (const uint16_t*)g.a_sp);

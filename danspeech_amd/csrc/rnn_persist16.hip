@@ -33,6 +33,7 @@ constexpr int QRP = 20;                // row pitch (words) of the reduce buffer
 constexpr int QMAXZ = 8;               // batch tiles one workgroup can walk
 constexpr unsigned Q_SPIN_LIMIT = 1u << 22;
 constexpr size_t Q_LDS = 82 * 1024;    // > half of the CU's LDS: one workgroup per CU
+constexpr size_t Q_LDS_PIPE = 112 * 1024;   // pipelined variant: two reduce buffers
 
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
@@ -265,6 +266,212 @@ __global__ __launch_bounds__(QNT) void rnn_persist16_kernel(P16Args p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Several batch tiles per workgroup (more 16-clip tiles than fit side by side): the tile instances (step s, tile z)
+// are software-pipelined.  While the cell of instance i runs (LDS reduce, exp/rcp, stores), the state of instance
+// i+1 is already on its way from L2, and instance i is signalled behind instance i+1's MFMAs (its write-through
+// stores drain meanwhile): the per-instance chain shrinks from wait + load + MFMA + reduce + cell + drain to
+// max(wait, ...) + MFMA + reduce + cell.  The reduce buffer is double-buffered because a fast wave may write
+// instance i+1's partial tiles while a cell wave still reads instance i's.
+// Every wave issues the same two 2-byte state stores after its state loads (the non-cell waves' go out of the buffer's
+// bounds and are dropped by the hardware, but still count), so that "wait until at most two memory operations are
+// outstanding" means "my state loads have landed" for every wave.
+template <int KIND, int NKW>
+__global__ __launch_bounds__(QNT) void rnn_persist16_pipe_kernel(P16Args p) {
+    constexpr int NG = KIND == DSMI_RNN_GRU ? 3 : (KIND == DSMI_RNN_LSTM ? 4 : 1);
+    constexpr int RED = QNW * 4 * 16 * QRP;                          // words per reduce buffer
+    extern __shared__ __attribute__((aligned(16))) float qlds[];
+    float* red0 = qlds;                                              // [2][QNW][4][16 units][QRP]
+    int& s_dead = *reinterpret_cast<int*>(red0 + 2 * RED);
+    float* st_h = red0 + 2 * RED + 32;                               // [QMAXZ][256] carried state of the tiles
+    float* st_c = st_h + QMAXZ * 256;
+    int* st_len = reinterpret_cast<int*>(st_c + QMAXZ * 256);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int v = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ln = lane & 15, lg = lane >> 4;
+    const int w = blockIdx.x;
+    const int d = blockIdx.y / p.pgroups, pg = blockIdx.y - d * p.pgroups;
+    const int nz = (p.ntiles - pg + p.pgroups - 1) / p.pgroups;
+    const int GU = NG * QU;
+    const size_t xcol = (size_t)d * p.nwg * GU + (size_t)w * GU;
+    if (tid == 0) s_dead = 0;
+
+    const int kb0 = (v * p.nkb) / QNW, kb1 = ((v + 1) * p.nkb) / QNW;
+    f16x8 wv[NKW][NG][2];
+    {
+        const u32x4* wp = reinterpret_cast<const u32x4*>(p.whh[d]) + ((size_t)w * p.nkb) * (NG * 2 * 64) + lane;
+#pragma unroll
+        for (int i = 0; i < NKW; ++i) {
+            const int kb = min(kb0 + i, max(kb1 - 1, kb0));
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) wv[i][g][pl] = __builtin_bit_cast(f16x8, wp[(((size_t)kb * NG + g) * 2 + pl) * 64]);
+        }
+    }
+    const size_t hp_par = (size_t)p.D * p.ntiles * p.nkb * 2048;
+    const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.hpack, 0, (int)(2 * hp_par), 0x00020000);
+    const unsigned oob = (unsigned)(2 * hp_par) + 64u;               // out of bounds: dropped, but counted by vmcnt
+
+    const int cuh = tid >> 7, ce = tid & 7, cj = (tid >> 3) & 15;
+    const int cu = 8 * cuh + ce;
+    const int cunit = w * QU + cu;
+    const bool cunit_ok = tid < 256 && cunit < p.H;
+    float bh[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) bh[g] = cunit_ok ? p.bhh[d][g * p.H + cunit] : 0.f;
+    if (tid < 256)
+        for (int z = 0; z < nz; ++z) {
+            const int eb = (pg + z * p.pgroups) * QB + cj;
+            st_h[z * 256 + tid] = 0.f; st_c[z * 256 + tid] = 0.f;
+            st_len[z * 256 + tid] = (cunit_ok && eb < p.B) ? p.lens[eb] : 0;
+        }
+    __syncthreads();
+
+    const int NI = p.T * nz;                                         // tile instances i = s * nz + z
+    auto tile_of = [&](int z) { return pg + z * p.pgroups; };
+    auto xp_of = [&](int s, int z) {
+        const int t = d == 0 ? s : p.T - 1 - s;
+        return p.xp + ((size_t)t * p.B + tile_of(z) * QB + cj) * p.Np + xcol + cu;
+    };
+    auto active = [&](int z) { return cunit_ok && cj < min(QB, p.B - tile_of(z) * QB); };
+
+    f16x8 hv[NKW][2];
+#pragma unroll
+    for (int i = 0; i < NKW; ++i) { hv[i][0] = f16x8{0, 0, 0, 0, 0, 0, 0, 0}; hv[i][1] = hv[i][0]; }
+    float xg[NG], xn[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) { xg[g] = 0.f; xn[g] = 0.f; }
+    if (active(0)) {
+        const float* xr = xp_of(0, 0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) xg[g] = xr[g * QU];
+    }
+    unsigned* pend = nullptr;
+
+    for (int i = 0; i < NI; ++i) {
+        const int s = i / nz, z = i - s * nz;
+        const int t = d == 0 ? s : p.T - 1 - s;
+        const int tile = tile_of(z);
+        const int chain = d * p.ntiles + tile;
+        unsigned* cnt = p.cnt + (size_t)chain * p.T * kPersist16CntWords;
+        float* red = red0 + (i & 1) * RED;
+        // ---- B(i): multiply (the state of instance i was requested during the previous iteration)
+        f32x4 acc[NG], acl[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) { acc[g] = f32x4{0.f, 0.f, 0.f, 0.f}; acl[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        if (s > 0) {
+#pragma unroll
+            for (int k = 0; k < NKW; ++k) {
+                if (kb0 + k < kb1) {
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) acl[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[k][g][1], hv[k][0], acl[g], 0, 0, 0);
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[k][g][0], hv[k][0], acc[g], 0, 0, 0);
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) acl[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[k][g][0], hv[k][1], acl[g], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                red[((v * 4 + g) * 16 + 4 * lg + r) * QRP + ln] = acc[g][r] + acl[g][r] * kLoInv;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // instance i-1's state stores are acknowledged
+        __syncthreads();
+        if (tid == 0 && pend) __hip_atomic_fetch_add(pend, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // ---- A(i+1): wait for the producers of the next instance and request its state and x-projection
+        if (i + 1 < NI) {
+            const int s1 = (i + 1) / nz, z1 = (i + 1) - s1 * nz;
+            if (s1 > 0) {
+                const int chain1 = d * p.ntiles + tile_of(z1);
+                const unsigned* c1 = p.cnt + (size_t)chain1 * p.T * kPersist16CntWords + (size_t)(s1 - 1) * kPersist16CntWords;
+                if (v == 0 && !s_dead) {
+                    unsigned spins = 0;
+                    const unsigned* cp = c1 + (lane & (kPersist16Shards - 1)) * 64;
+                    const unsigned need = (unsigned)((p.nwg + kPersist16Shards - 1 - (lane & (kPersist16Shards - 1))) / kPersist16Shards);
+                    while (true) {
+                        const unsigned got = lane < kPersist16Shards ? __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need;
+                        if (__builtin_amdgcn_ballot_w64(got < need) == 0) break;
+                        __builtin_amdgcn_s_sleep(1);
+                        ++spins;
+                        if ((spins & 1023u) == 0 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { s_dead = 1; break; }
+                        if (spins > Q_SPIN_LIMIT) { atomicExch(p.err, 1u); s_dead = 1; break; }
+                    }
+                }
+                __syncthreads();
+                const unsigned hbase = (unsigned)(((s1 - 1) & 1) * hp_par) + (unsigned)((size_t)chain1 * p.nkb * 2048) + (unsigned)lane * 16u;
+#pragma unroll
+                for (int k = 0; k < NKW; ++k) {
+                    const int kb = min(kb0 + k, max(kb1 - 1, kb0));
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl)
+                        hv[k][pl] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(hrs, hbase + (unsigned)(kb * 2 + pl) * 1024u, 0, 16));
+                }
+            }
+            if (active(z1)) {
+                const float* xr = xp_of(s1, z1);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) xn[g] = xr[g * QU];
+            }
+        }
+        // ---- C(i): reduce + cell + publish
+        float hn = 0.f;
+        const bool eact = active(z);
+        const int eb = tile * QB + cj;
+        if (tid < 256) {
+            const int mylen = st_len[z * 256 + tid];
+            const float hprev_own = st_h[z * 256 + tid];
+            float cprev_own = st_c[z * 256 + tid];
+            if (eact) {
+                float hg[NG];
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int k = 0; k < QNW; ++k) sum += red[((k * 4 + g) * 16 + cu) * QRP + cj];
+                    hg[g] = sum + bh[g];
+                }
+                if (KIND == DSMI_RNN_GRU) {
+                    const float r = qsigmoid(xg[0] + hg[0]);
+                    const float zz = qsigmoid(xg[1] + hg[1]);
+                    const float n = qtanh(xg[2] + r * hg[2]);
+                    hn = (1.f - zz) * n + zz * hprev_own;
+                } else if (KIND == DSMI_RNN_LSTM) {
+                    const float ig = qsigmoid(xg[0] + hg[0]);
+                    const float fg = qsigmoid(xg[1] + hg[1]);
+                    const float gg = qtanh(xg[2] + hg[2]);
+                    const float og = qsigmoid(xg[3] + hg[3]);
+                    const float cn = fg * cprev_own + ig * gg;
+                    hn = og * qtanh(cn);
+                    if (t < mylen) cprev_own = cn;
+                } else {
+                    hn = qtanh(xg[0] + hg[0]);
+                }
+                if (t >= mylen) hn = 0.f;
+                st_h[z * 256 + tid] = hn;
+                if (KIND == DSMI_RNN_LSTM) st_c[z * 256 + tid] = cprev_own;
+                p.out[d][((size_t)t * p.B + eb) * p.Hs + cunit] = hn;
+            } else if (cj < min(QB, p.B - tile * QB) && cunit < p.Hs) {
+                p.out[d][((size_t)t * p.B + eb) * p.Hs + cunit] = 0.f;
+            }
+        }
+        {
+            const _Float16 h1 = (_Float16)hn;
+            const _Float16 h2 = (_Float16)((hn - (float)h1) * kLoScale);
+            const unsigned off = tid < 256 ? (unsigned)((s & 1) * hp_par) + (unsigned)((size_t)chain * p.nkb * 2048) + (unsigned)(w >> 1) * 2048u +
+                                                 (unsigned)(2 * (w & 1) + cuh) * 256u + (unsigned)cj * 16u + (unsigned)ce * 2u
+                                           : oob;
+            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, h1), hrs, off, 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, h2), hrs, tid < 256 ? off + 1024u : oob, 0, 16);
+        }
+        pend = &cnt[(size_t)s * kPersist16CntWords + (w & (kPersist16Shards - 1)) * 64];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) xg[g] = xn[g];
+    }
+}
+
 inline uint16_t q_f16_bits(_Float16 h) {
     uint16_t u;
     std::memcpy(&u, &h, 2);
@@ -285,6 +492,21 @@ bool launch16(const P16Args& a, hipStream_t s, const EvPair& ev) {
         if (nkw > 4) return false;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rnn_persist16_kernel<KIND, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Q_LDS);
         hipLaunchKernelGGL((rnn_persist16_kernel<KIND, 4, true>), grid, block, Q_LDS, s, a);
+        return true;
+    }
+    if (ceil_div(a.ntiles, a.pgroups) > 2) {      // three or more tiles per workgroup: the software-pipelined kernel (with two
+                                                   // tiles the next instance's producers were signalled a moment ago: nothing to overlap)
+#define LAUNCH_QP(N)                                                                                                 \
+    do {                                                                                                             \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rnn_persist16_pipe_kernel<KIND, N>),                  \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)Q_LDS_PIPE);                       \
+        DSMI_LAUNCH((rnn_persist16_pipe_kernel<KIND, N>), grid, block, Q_LDS_PIPE, s, ev, a);                         \
+    } while (0)
+        if (nkw <= 2) LAUNCH_QP(2);
+        else if (nkw <= 4) LAUNCH_QP(4);
+        else if (nkw <= 5 && KIND != DSMI_RNN_LSTM) LAUNCH_QP(5);
+        else return false;
+#undef LAUNCH_QP
         return true;
     }
     if (nkw <= 2) LAUNCH_Q(2);

@@ -346,3 +346,29 @@ def test_full_width_variants_vs_oracle(native, kind, H, L, cl, bidir):
     print("%s H=%d L=%d conv=%d bidir=%d: max |probs - oracle| = %.3g" % (kind, H, L, cl, bidir, err))
     assert err < 1e-4
     m.close()
+
+
+@pytest.mark.parametrize("kind,B,why", [("gru", 20, "two tiles per workgroup: deferred signalling"),
+                                        ("gru", 40, "three tiles per workgroup: software-pipelined kernel"),
+                                        ("lstm", 56, "four tiles, LSTM cell state carried per tile")])
+def test_second_generation_walks_several_tiles_vs_oracle(native, kind, B, why):
+    """H = 1024: 64 workgroups x 2 directions leave room for ONE tile group on 256 CUs, so every workgroup of
+    rnn_persist16.hip walks ceil(B / 16) batch tiles per step (ragged lengths, ragged last tile)."""
+    from oracle import model as om
+    H = 1024
+    sd = syn.make_state_dict(2, kind, H, 1, seed=44, fc_gain=4.0)
+    cfg = _cfg(2, kind, H, 1)
+    rng = np.random.default_rng(45)
+    lens = np.sort(rng.integers(7, 44, size=B))[::-1].astype(np.int32).copy()
+    lens[0] = 44
+    x = syn.make_features(B, 44, seed=46)
+    for b, L in enumerate(lens):
+        x[b, :, :, L:] = 0
+    m = native.NativeModel(cfg, sd)
+    m.set_profiling(2)
+    p, ol = m.forward(_dev(x), lens)
+    ref, ol_ref = om.forward(sd, cfg, x, lens)
+    assert np.array_equal(ol, ol_ref)
+    np.testing.assert_allclose(p.cpu().numpy(), ref, rtol=0, atol=1e-4)
+    assert m.kernel_stats()["rnn_layer_persistent"]["launches"] == 1
+    m.close()

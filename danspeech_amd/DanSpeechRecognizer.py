@@ -1,11 +1,20 @@
-"""The engine of the drop-in surface (reference danspeech/DanSpeechRecognizer.py:13-231,
-non-streaming part): owns the device, the model, the audio parser and the decoder.
+"""The engine behind ``Recognizer`` (the role of reference danspeech/DanSpeechRecognizer.py): it owns the
+device, the acoustic model, the audio parser and the CTC decoder, and turns recordings into text.
 
-Same constructor, ``update_model`` / ``update_decoder`` state machine, prints and warnings as
-the reference; ``transcribe`` is the reference's batch-1 path and ``transcribe_batch`` is the
-batched extension the MI355X needs to be fed properly.  Everything numeric
-runs on the GPU through libdsmi.so; there is no CPU path, so ``with_gpu=False`` is accepted
-for signature compatibility but the device is still the MI355X.
+Behaviour kept from the reference, because callers and the parity tests rely on it:
+
+* constructor arguments and defaults (``alpha=1.3, beta=0.2, beam_width=64``, DanSpeechRecognizer.py:16-17), the
+  ``Using device:`` line, ``ModelNotInitialized`` when a language model is given without a model (:36-38);
+* ``update_decoder``: only truthy arguments that differ from the current setting count as a change, the decoder object
+  is rebuilt only on a change, the very first call selects greedy decoding (:58-95); the beam decoder is created with
+  ``num_processes=6, cutoff_prob=1.0, cutoff_top_n=40`` and the blank at ``labels.index('_')`` (:89-94);
+* ``transcribe``: one recording -> best transcription, or every beam with ``show_all`` (with a
+  ``NoLmInstantiatedWarning`` when there is no language model, :218-231);
+* the chunked real-time protocol ``enable_streaming`` / ``streaming_transcribe`` / ``disable_streaming`` (:97-216).
+
+What is new is batching: ``transcribe_batch`` runs many recordings as ONE padded batch, and ``transcribe_batches``
+keeps one batch in flight on the GPU while the next one is staged and uploaded and the previous one is decoded.
+Everything numeric runs in libdsmi.so on the MI355X; ``with_gpu`` is accepted for signature compatibility only.
 """
 import warnings
 
@@ -20,187 +29,168 @@ class NoLmInstantiatedWarning(Warning):
     pass
 
 
+# decoder settings update_decoder can change, in the order the reference examines them
+_DECODER_SETTINGS = ("lm", "alpha", "beta", "labels", "beam_width")
+
+
+class _StreamingSession(object):
+    """Running state of one utterance that arrives in parts (reference DanSpeechRecognizer.py:97-216): the text so
+    far, the model outputs of every part (for a final pass of the language-model decoder) and, when a secondary
+    model gives the final text, the spectrograms of every part."""
+
+    def __init__(self, secondary_model, string_parts):
+        self.secondary_model = secondary_model
+        self.string_parts = string_parts
+        self.clear()
+
+    def clear(self):
+        self.text = ""
+        self.outputs = []
+        self.spectrograms = []
+
+    def extend_text(self, piece):
+        """Append a part's greedy text; a part that starts with the character the text ends with continues that
+        character (CTC collapse across the part boundary).  Returns what this part contributed."""
+        if self.text and piece and self.text[-1] == piece[0]:
+            piece = piece[1:]
+        self.text += piece
+        return piece
+
+
+class _BatchJob(object):
+    """One batch between enqueue and decode."""
+    __slots__ = ("order", "probs", "sizes", "count")
+
+    def __init__(self, order, probs, sizes, count):
+        self.order, self.probs, self.sizes, self.count = order, probs, sizes, count
+
+
 class DanSpeechRecognizer(object):
 
     def __init__(self, model_name=None, lm_name=None, alpha=1.3, beta=0.2, with_gpu=False, beam_width=64):
         import torch
         self.device = torch.device("cuda")
         print("Using device: {0}".format(self.device))
-        # state first (the reference reads self.lm / self.decoder inside update_model before
-        # they exist when a model is passed here, DanSpeechRecognizer.py:23-24 vs 43-46)
         self.lm = None
         self.decoder = None
-        self.alpha = alpha
-        self.beta = beta
-        self.beam_width = beam_width
+        self.alpha, self.beta, self.beam_width = alpha, beta, beam_width
+        self.model = self.model_name = self.labels = self.audio_config = self.audio_parser = None
+        self._session = None
+        self._side_streams = {}
         if model_name:
             self.update_model(model_name)
-        else:
-            self.model = None
-            self.model_name = None
-            self.labels = None
-            self.audio_config = None
-            self.audio_parser = None
         if lm_name:
             if not self.model:
                 raise ModelNotInitialized("Trying to initialize LM without also choosing a DanSpeech model.")
-            else:
-                self.update_decoder(lm_name)
-                self.lm = lm_name
+            self.update_decoder(lm_name)
+
+    # ---- model / decoder lifecycle ----------------------------------------------------------------------------------
+    def _device_index(self):
+        name = str(self.model.device)
+        return int(name.split(":")[1]) if ":" in name else 0
 
     def update_model(self, model):
         self.audio_config = model.audio_conf
         self.model = model.to(self.device)
         self.model.eval()
-        index = int(str(self.model.device).split(":")[1]) if ":" in str(self.model.device) else 0
-        self.audio_parser = SpectrogramAudioParser(self.audio_config, device=index)
-        self.labels = self.model.labels
-        # When updating model, always update decoder because of labels
-        self.update_decoder(labels=self.labels)
+        self.audio_parser = SpectrogramAudioParser(self.audio_config, device=self._device_index())
+        # a new model may bring a new alphabet: the decoder follows
+        self.update_decoder(labels=self.model.labels)
+
+    def _build_decoder(self):
+        blank = self.labels.index("_")
+        if self.lm == "greedy":
+            return GreedyDecoder(labels=self.labels, blank_index=blank)
+        return BeamCTCDecoder(labels=self.labels, lm_path=self.lm, alpha=self.alpha, beta=self.beta,
+                              beam_width=self.beam_width, num_processes=6, cutoff_prob=1.0, cutoff_top_n=40,
+                              blank_index=blank)
 
     def update_decoder(self, lm=None, alpha=None, beta=None, labels=None, beam_width=None):
-        """DanSpeechRecognizer.py:58-95, verbatim semantics: falsy arguments are ignored, the decoder
-        is rebuilt only when something changed, the first call selects greedy decoding."""
-        update = False
-        if not self.lm and not self.decoder:
-            update = True
+        requested = dict(lm=lm, alpha=alpha, beta=beta, labels=labels, beam_width=beam_width)
+        stale = not self.lm and not self.decoder
+        if stale:
             self.lm = "greedy"
-        if lm and self.lm != lm:
-            update = True
-            self.lm = lm
-        if alpha and self.alpha != alpha:
-            update = True
-            self.alpha = alpha
-        if beta and self.beta != beta:
-            update = True
-            self.beta = beta
-        if labels and labels != self.labels:
-            update = True
-            self.labels = labels
-        if beam_width and beam_width != self.beam_width:
-            update = True
-            self.beam_width = beam_width
-        if update:
-            if self.lm != "greedy":
-                self.decoder = BeamCTCDecoder(labels=self.labels, lm_path=self.lm,
-                                              alpha=self.alpha, beta=self.beta,
-                                              beam_width=self.beam_width, num_processes=6, cutoff_prob=1.0,
-                                              cutoff_top_n=40, blank_index=self.labels.index('_'))
-            else:
-                self.decoder = GreedyDecoder(labels=self.labels, blank_index=self.labels.index('_'))
+        for name in _DECODER_SETTINGS:
+            value = requested[name]
+            if value and value != getattr(self, name):
+                setattr(self, name, value)
+                stale = True
+        if stale:
+            self.decoder = self._build_decoder()
 
-    # ---- streaming (DanSpeechRecognizer.py:97-216) -----------------------------------------------
-    def _device_index(self):
-        return int(str(self.model.device).split(":")[1]) if ":" in str(self.model.device) else 0
-
-    def enable_streaming(self, secondary_model=None, return_string_parts=True):
-        """DanSpeechRecognizer.py:97-127."""
-        self.full_output = []
-        self.iterating_transcript = ""
-        if secondary_model:
-            self.secondary_model = secondary_model.to(self.device)
-            self.secondary_model.eval()
-        else:
-            self.secondary_model = None
-        self.spectrograms = []
-        self.greedy_decoder = GreedyDecoder(labels=self.labels, blank_index=self.labels.index('_'))
-        self.audio_parser = InferenceSpectrogramAudioParser(audio_config=self.audio_config, device=self._device_index())
-        self.string_parts = bool(return_string_parts)
-
-    def disable_streaming(self, keep_secondary_model=False):
-        """DanSpeechRecognizer.py:129-136."""
-        self.audio_parser = SpectrogramAudioParser(self.audio_config, device=self._device_index())
-        self.greedy_decoder = None
-        self.reset_streaming_params()
-        self.string_parts = False
-        if not keep_secondary_model:
-            self.secondary_model = None
-
-    def reset_streaming_params(self):
-        self.iterating_transcript = ""
-        self.full_output = []
-        self.spectrograms = []
-
-    def streaming_transcribe(self, recording, is_last, is_first):
-        """DanSpeechRecognizer.py:144-216: one part of an utterance through the streaming model; greedy text of
-        the part (or the whole running text), and on ``is_last`` the final transcription (secondary model
-        on the collected spectrograms, or the LM decoder on the collected outputs, or the running text)."""
+    # ---- batches ----------------------------------------------------------------------------------------------------
+    def _side_stream(self, name):
+        """A per-engine HIP stream beside the compute stream ("decode": the decoder of batch i runs while batch
+        i+1 computes)."""
         import torch
-        recording = self.audio_parser.parse_audio(recording, is_last)
-        out = ""
-        if len(recording) != 0:
-            if self.secondary_model:
-                self.spectrograms.append(recording)
-            recording = recording.view(1, 1, recording.size(0), recording.size(1))
-            recording = recording.to(self.device)
-            out = self.model(recording, is_first, is_last)
-            if is_first:
-                return ""
-            self.full_output.append(out)
-            decoded_out, _ = self.greedy_decoder.decode(out)
-            transcript = decoded_out[0][0]
-            # Collapsing characters hack
-            if self.iterating_transcript and transcript and self.iterating_transcript[-1] == transcript[0]:
-                self.iterating_transcript = self.iterating_transcript + transcript[1:]
-                transcript = transcript[1:]
-            else:
-                self.iterating_transcript += transcript
-            if self.string_parts:
-                out = transcript
-            else:
-                out = self.iterating_transcript
-        if is_last:
-            if len(self.iterating_transcript) > 1:
-                if self.secondary_model:
-                    final = torch.cat(self.spectrograms, dim=1)
-                    self.spectrograms = []
-                    final = final.view(1, 1, final.size(0), final.size(1))
-                    final = final.to(self.device)
-                    input_sizes = torch.IntTensor([final.size(3)]).int()
-                    out, _ = self.secondary_model(final, input_sizes)
-                    decoded_out, _ = self.decoder.decode(out)
-                    decoded_out = decoded_out[0][0]
-                    self.reset_streaming_params()
-                    return decoded_out
-                else:
-                    if self.lm != "greedy":
-                        final_out = torch.cat(self.full_output, dim=1)
-                        decoded_out, _ = self.decoder.decode(final_out)
-                        decoded_out = decoded_out[0][0]
-                        self.reset_streaming_params()
-                        return decoded_out
-                    else:
-                        out = self.iterating_transcript
-                        self.reset_streaming_params()
-                        return out
-            else:
-                return ""
-        return out
+        key = (name, self._device_index())
+        if key not in self._side_streams:
+            self._side_streams[key] = torch.cuda.Stream(device=key[1])
+        return self._side_streams[key]
+
+    def _enqueue_batch(self, recordings):
+        """Stage + upload + spectrograms + forward of one batch, all asynchronous.  Clips run longest first
+        (pack_padded_sequence's order, reference model.py:117)."""
+        import torch
+        order = np.argsort([-len(r) for r in recordings], kind="stable")
+        feats, frames = self.audio_parser.parse_batch([recordings[i] for i in order])
+        probs, sizes = self.model.enqueue(feats, torch.from_numpy(frames.astype(np.int32)))
+        return _BatchJob(order, probs, sizes, len(recordings))
+
+    def _finish_batch(self, job, show_all, warn=True):
+        import torch
+        self.model.collect()                     # waits for the forward; a timed-out batch has been recomputed by now
+        side = self._side_stream("decode")
+        job.probs.record_stream(side)
+        with torch.cuda.stream(side):
+            decoded, _ = self.decoder.decode(job.probs, job.sizes)
+        if warn and show_all and self.lm == "greedy":
+            warnings.warn("You are trying to get all beams but no LM has been instantiated.", NoLmInstantiatedWarning)
+        results = [None] * job.count
+        for pos, i in enumerate(job.order):
+            results[i] = decoded[pos] if show_all else decoded[pos][0]
+        return results
+
+    def transcribe_batch(self, recordings, show_all=False):
+        """``[transcribe(r) for r in recordings]`` as one batch; results in the caller's order."""
+        if len(recordings) == 0:
+            return []
+        return self._finish_batch(self._enqueue_batch(recordings), show_all)
+
+    def transcribe_batches(self, batches, show_all=False):
+        """Generator over ``transcribe_batch(b)`` for every ``b`` of ``batches``, software-pipelined: while the GPU
+        computes batch i, the host stages and uploads batch i+1 (pinned double buffer, copy stream) and the decoder
+        of batch i-1 runs on a side stream.  Results come out in order, one list per batch."""
+        waiting = None
+        for recordings in batches:
+            job = self._enqueue_batch(recordings) if len(recordings) else None
+            if waiting is not None:
+                yield self._finish_batch(waiting, show_all) if waiting != "empty" else []
+            waiting = job if job is not None else "empty"
+        if waiting is not None:
+            yield self._finish_batch(waiting, show_all) if waiting != "empty" else []
+
+    def transcribe_device(self, pcm, n_samples, show_all=False):
+        """Clips that already sit back to back in GPU memory (int16 / float32 / float64, longest first), e.g. a
+        shard received over RCCL (``parallel.recognize_sharded``): no host staging at all."""
+        import torch
+        feats, frames = self.audio_parser._frontend().features(pcm, np.asarray(n_samples, dtype=np.int64))
+        probs, sizes = self.model(feats, torch.from_numpy(frames.astype(np.int32)))
+        decoded, _ = self.decoder.decode(probs, sizes)
+        return [d if show_all else d[0] for d in decoded]
 
     def transcribe(self, recording, show_all=False):
-        """DanSpeechRecognizer.py:218-231."""
-        import torch
-        recording = self.audio_parser.parse_audio(recording)
-        recording = recording.view(1, 1, recording.size(0), recording.size(1))
-        recording = recording.to(self.device)
-        input_sizes = torch.IntTensor([recording.size(3)]).int()
-        out, output_sizes = self.model(recording, input_sizes)
-        decoded_output, _ = self.decoder.decode(out, output_sizes)
-        if show_all:
-            if self.lm == 'greedy':
-                warnings.warn("You are trying to get all beams but no LM has been instantiated.",
-                              NoLmInstantiatedWarning)
-            return decoded_output[0]
-        else:
-            return decoded_output[0][0]
+        beams = self._finish_batch(self._enqueue_batch([recording]), True, warn=show_all)[0]
+        return beams if show_all else beams[0]
 
+    # ---- long recordings and files ----------------------------------------------------------------------------------
     def transcribe_long(self, recording, energy_threshold=600, step=1024, pause_threshold=0.55, phrase_threshold=0.2,
                         max_batch=32, show_all=False):
         """Long-form transcription: the energy gate of the reference's
-        example_scripts/video_transcribe_simulation.py:68-143 cuts the recording into phrases
-        (``dsmi_segment``: hop energies on the GPU), the phrases are transcribed in batches of at most
-        ``max_batch`` (longest first), and ``[(start_sample, end_sample, transcription), ...]`` comes back
-        in time order.  The recording is uploaded once; phrases are sliced on the device."""
+        example_scripts/video_transcribe_simulation.py:68-143 cuts the recording into phrases (``dsmi_segment``: hop
+        energies on the GPU), the phrases are transcribed in batches of at most ``max_batch`` (longest first), and
+        ``[(start_sample, end_sample, transcription), ...]`` comes back in time order.  The recording is uploaded
+        once; phrases are sliced on the device."""
         import torch
         parser = self.audio_parser
         pcm = torch.from_numpy(np.ascontiguousarray(recording, dtype=np.float64)).to("cuda:%d" % parser.device)
@@ -246,19 +236,65 @@ class DanSpeechRecognizer(object):
             warnings.warn("You are trying to get all beams but no LM has been instantiated.", NoLmInstantiatedWarning)
         return res
 
-    def transcribe_batch(self, recordings, show_all=False):
-        """Batched ``transcribe``: clips are sorted by length (pack_padded_sequence's order,
-        reference model.py:117), run as ONE batch, and results return in the caller's order."""
+    # ---- utterances that arrive in parts ----------------------------------------------------------------------------
+    def enable_streaming(self, secondary_model=None, return_string_parts=True):
+        if secondary_model:
+            secondary_model = secondary_model.to(self.device)
+            secondary_model.eval()
+        self._session = _StreamingSession(secondary_model or None, bool(return_string_parts))
+        self.greedy_decoder = GreedyDecoder(labels=self.labels, blank_index=self.labels.index('_'))
+        self.audio_parser = InferenceSpectrogramAudioParser(audio_config=self.audio_config, device=self._device_index())
+
+    def disable_streaming(self, keep_secondary_model=False):
+        self.audio_parser = SpectrogramAudioParser(self.audio_config, device=self._device_index())
+        self.greedy_decoder = None
+        kept = self._session.secondary_model if (self._session and keep_secondary_model) else None
+        self._session = _StreamingSession(kept, False)
+
+    def reset_streaming_params(self):
+        if self._session:
+            self._session.clear()
+
+    # attribute names of the reference object, for code that peeks at them
+    secondary_model = property(lambda self: self._session.secondary_model if self._session else None)
+    string_parts = property(lambda self: self._session.string_parts if self._session else False)
+    iterating_transcript = property(lambda self: self._session.text if self._session else "")
+    full_output = property(lambda self: self._session.outputs if self._session else [])
+    spectrograms = property(lambda self: self._session.spectrograms if self._session else [])
+
+    def _final_text(self, ses):
+        """The utterance is over: the secondary model on all spectrograms, else the language-model decoder on all
+        outputs, else the running greedy text."""
         import torch
-        if len(recordings) == 0:
-            return []
-        order = np.argsort([-len(r) for r in recordings], kind="stable")
-        feats, frames = self.audio_parser.parse_batch([recordings[i] for i in order])
-        out, output_sizes = self.model(feats, torch.from_numpy(frames.astype(np.int32)))
-        decoded_output, _ = self.decoder.decode(out, output_sizes)
-        if show_all and self.lm == 'greedy':
-            warnings.warn("You are trying to get all beams but no LM has been instantiated.", NoLmInstantiatedWarning)
-        res = [None] * len(recordings)
-        for pos, i in enumerate(order):
-            res[i] = decoded_output[pos] if show_all else decoded_output[pos][0]
-        return res
+        if ses.secondary_model:
+            spect = torch.cat(ses.spectrograms, dim=1)
+            spect = spect.view(1, 1, spect.size(0), spect.size(1)).to(self.device)
+            probs, _ = ses.secondary_model(spect, torch.IntTensor([spect.size(3)]).int())
+            text = self.decoder.decode(probs)[0][0][0]
+        elif self.lm != "greedy":
+            text = self.decoder.decode(torch.cat(ses.outputs, dim=1))[0][0][0]
+        else:
+            text = ses.text
+        ses.clear()
+        return text
+
+    def streaming_transcribe(self, recording, is_last, is_first):
+        """One part of an utterance through the streaming model.  Returns this part's text (or the whole text so far
+        when string parts are off); on the first part nothing (the lookahead is filling); on the last part the final
+        text of the utterance, provided more than one character was recognised."""
+        ses = self._session
+        spect = self.audio_parser.parse_audio(recording, is_last)
+        said = ""
+        if len(spect) != 0:
+            if ses.secondary_model:
+                ses.spectrograms.append(spect)
+            spect = spect.view(1, 1, spect.size(0), spect.size(1)).to(self.device)
+            probs = self.model(spect, is_first, is_last)
+            if is_first:
+                return ""
+            ses.outputs.append(probs)
+            piece = ses.extend_text(self.greedy_decoder.decode(probs)[0][0][0])
+            said = piece if ses.string_parts else ses.text
+        if not is_last:
+            return said
+        return self._final_text(ses) if len(ses.text) > 1 else ""

@@ -38,6 +38,23 @@ class Recognizer(object):
         """``recognize`` for a list of clips in one batched pass over the GPU."""
         return self.danspeech_recognizer.transcribe_batch(audio_list, show_all=show_all)
 
+    def recognize_batches(self, batches, show_all=False):
+        """Generator: ``recognize_batch`` over a sequence of batches, with the upload of the next batch and the
+        decoding of the previous one overlapped with the GPU's work on the current one."""
+        return self.danspeech_recognizer.transcribe_batches(batches, show_all=show_all)
+
+    def recognize_batch_distributed(self, audio_list):
+        """``recognize_batch`` sharded over the ranks of an initialised ``torch.distributed`` job (one process per
+        GPU, backend "nccl" = RCCL): rank 0 passes the clips and receives the transcriptions in its order, the
+        other ranks pass ``None`` and receive ``None``.  Clips are dealt longest-first round-robin
+        (``parallel.plan_shards``), int16/float32/float64 PCM travels in its own sample type."""
+        import torch
+        import torch.distributed as dist
+        from . import parallel
+        eng = self.danspeech_recognizer
+        dev = torch.device("cuda", eng._device_index())
+        return parallel.recognize_sharded(eng, audio_list, dist.get_rank(), dist.get_world_size(), dev)
+
     # ---- real-time streaming (Recognizer.py:499-720) without the microphone -----------------------------
     def enable_real_time_streaming(self, streaming_model, secondary_model=None, string_parts=True):
         """Recognizer.py:499-533: switch to a unidirectional streaming model (e.g.

@@ -22,6 +22,8 @@ DSMI_ERR_CONV = -2
 DSMI_ERR_NOT_READY = -3
 DSMI_ERR_UNSORTED = -4
 DSMI_ERR_CAPACITY = -8
+DSMI_ERR_TIMEOUT = -9
+DSMI_RECOMPUTED = 1
 
 
 class NativeLibraryMissing(RuntimeError):
@@ -83,6 +85,8 @@ _PROTOS = {
     "dsmi_decoder_set_lm": (C.c_int, [_vp, C.c_char_p, C.c_double, C.c_double]),
     "dsmi_beam": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _vp, _vp, _vp, _vp, _vp]),
     "dsmi_forward": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "dsmi_forward_status": (C.c_int, [_vp]),
+    "dsmi_recompute_count": (C.c_int, [_vp]),
     "dsmi_conv_stack": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
     "dsmi_rnn_layer": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
     "dsmi_greedy": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
@@ -180,15 +184,22 @@ class NativeModel:
         self._check(lib().dsmi_reserve(self._h, int(max_batch), int(max_frames)))
 
     # ---- device entry points (torch tensors only as containers)
-    @staticmethod
-    def _stream():
-        import torch
-        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    def _stream(self):
+        return _stream(self.device)
 
-    def forward(self, feat, lens, out=None):
-        """feat: CUDA float32 [B,1,F,T] contiguous; lens sorted descending. -> (probs [B,T',C], out_lens)."""
+    def _on_device(self, t):
+        assert t.is_cuda and t.device.index == self.device, "tensor on %s, handle on cuda:%d" % (t.device, self.device)
+
+    def forward(self, feat, lens, out=None, check=True):
+        """feat: CUDA float32 [B,1,F,T] contiguous; lens sorted descending. -> (probs [B,T',C], out_lens).
+
+        The kernels are enqueued asynchronously.  With ``check=True`` (default) the call then waits for them and
+        collects the forward's status (``dsmi_forward_status``: a batch whose persistent recurrent kernel timed
+        out is recomputed before this returns), so the probabilities are valid for any consumer.  A pipelining
+        caller passes ``check=False`` and calls ``status()`` itself before consuming ``probs``."""
         import torch
-        assert feat.is_cuda and feat.dtype == torch.float32 and feat.is_contiguous()
+        assert feat.dtype == torch.float32 and feat.is_contiguous()
+        self._on_device(feat)
         B, T = feat.shape[0], feat.shape[-1]
         lens = np.ascontiguousarray(lens, dtype=np.int32)
         To = int(self.seq_lens(np.array([T], dtype=np.int32))[0])
@@ -196,7 +207,29 @@ class NativeModel:
         out_lens = np.empty(B, dtype=np.int32)
         self._check(lib().dsmi_forward(self._h, feat.data_ptr(), _np_ptr(lens), B, T, probs.data_ptr(),
                                        _np_ptr(out_lens), self._stream()))
+        if not hasattr(self, "_inflight"):
+            self._inflight = []
+        self._inflight.append((feat, probs))      # dsmi_forward_status may recompute from / into these buffers
+        del self._inflight[:-4]
+        if check:
+            self.status()
         return probs, out_lens
+
+    def status(self):
+        """Wait for the oldest forward whose status has not been collected and collect it.  True when the batch had
+        to be recomputed on the per-step path (results are valid either way; raises if the recompute failed)."""
+        rc = lib().dsmi_forward_status(self._h)
+        if getattr(self, "_inflight", None):
+            self._inflight.pop(0)
+        if rc == DSMI_RECOMPUTED:
+            import warnings
+            warnings.warn((lib().dsmi_last_error(self._h) or b"").decode(), RuntimeWarning)
+            return True
+        self._check(rc)
+        return False
+
+    def recompute_count(self):
+        return int(lib().dsmi_recompute_count(self._h))
 
     def conv_stack(self, feat, lens):
         import torch
@@ -249,9 +282,10 @@ class NativeModel:
         return n.value, a.value, b.value
 
 
-def _stream():
+def _stream(device=None):
+    """The torch stream current on ``device`` (the HANDLE's device, not torch's current device)."""
     import torch
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
 class NativeFrontend:
@@ -315,7 +349,7 @@ class NativeFrontend:
         feat = torch.empty((B, 1, self.n_freq, t_stride), dtype=torch.float32, device=pcm_dev.device)
         fr = np.empty(B, dtype=np.int32)
         rc = lib().dsmi_features(self._h, pcm_dev.data_ptr(), dt, _np_ptr(n_samples), B, feat.data_ptr(),
-                                 int(t_stride), _np_ptr(fr), _stream())
+                                 int(t_stride), _np_ptr(fr), _stream(self.device))
         if rc != 0:
             raise DsmiError(rc, (lib().dsmi_frontend_last_error(self._h) or b"").decode())
         return feat, fr
@@ -339,7 +373,7 @@ def _segment(self, pcm_dev, energy_threshold=600, step=1024, pause_hops=9, phras
     e = np.zeros(max(nhops, 1), dtype=np.float64)
     found = C.c_int(0)
     rc = lib().dsmi_segment(self._h, pcm_dev.data_ptr(), dt, n, int(step), float(energy_threshold), int(pause_hops),
-                            int(phrase_hops), _np_ptr(st), _np_ptr(en), cap, C.byref(found), _np_ptr(e), _stream())
+                            int(phrase_hops), _np_ptr(st), _np_ptr(en), cap, C.byref(found), _np_ptr(e), _stream(self.device))
     if rc != 0:
         raise DsmiError(rc, (lib().dsmi_frontend_last_error(self._h) or b"").decode())
     seg = np.stack([st[:found.value], en[:found.value]], axis=1)
@@ -360,7 +394,7 @@ def _features_stream(self, pcm_dev, state):
     feat = torch.empty((self.n_freq, max(nfr, 1)), dtype=torch.float32, device=pcm_dev.device)
     fr = np.zeros(1, dtype=np.int32)
     rc = lib().dsmi_features_stream(self._h, pcm_dev.data_ptr(), dt, n, _np_ptr(state), feat.data_ptr(), feat.shape[1],
-                                    _np_ptr(fr), _stream())
+                                    _np_ptr(fr), _stream(self.device))
     if rc != 0:
         raise DsmiError(rc, (lib().dsmi_frontend_last_error(self._h) or b"").decode())
     return feat[:, :int(fr[0])]
@@ -395,7 +429,7 @@ class NativeStream:
             probs = torch.empty((cap, self.model.n_labels), dtype=torch.float32, device=feat.device)
             tout = np.zeros(1, dtype=np.int32)
             rc = lib().dsmi_stream_forward(self._h, feat.data_ptr(), T, int(bool(is_first)), int(bool(is_last)),
-                                           probs.data_ptr(), cap, _np_ptr(tout), _stream())
+                                           probs.data_ptr(), cap, _np_ptr(tout), _stream(self.model.device))
             if rc == DSMI_ERR_CAPACITY and cap < (1 << 24):
                 # nothing was consumed: the capacity check precedes every state update of the lookahead
                 cap *= 4
@@ -426,6 +460,7 @@ class NativeDecoder:
     def __init__(self, labels, blank_index=0, device=0):
         L = lib()
         self.labels = labels
+        self.device = device
         arr = (C.c_char_p * len(labels))(*[c.encode("utf-8") for c in labels])
         h = _vp()
         rc = L.dsmi_decoder_create(device, arr, len(labels), int(blank_index), C.byref(h))
@@ -459,7 +494,7 @@ class NativeDecoder:
         n = np.empty(B, dtype=np.int32)
         sz = None if sizes is None else np.ascontiguousarray(sizes, dtype=np.int32)
         self._check(lib().dsmi_greedy(self._h, probs.data_ptr(), None if sz is None else _np_ptr(sz), B, T,
-                                      _np_ptr(ids), _np_ptr(offs), _np_ptr(n), _stream()))
+                                      _np_ptr(ids), _np_ptr(offs), _np_ptr(n), _stream(self.device)))
         return [(ids[b, :n[b]].copy(), offs[b, :n[b]].copy()) for b in range(B)]
 
     def beam(self, probs, sizes=None, beam_width=64, cutoff_top_n=40, cutoff_prob=1.0):
@@ -472,5 +507,5 @@ class NativeDecoder:
         sz = None if sizes is None else np.ascontiguousarray(sizes, dtype=np.int32)
         self._check(lib().dsmi_beam(self._h, probs.data_ptr(), None if sz is None else _np_ptr(sz), B, T, int(beam_width),
                                     int(cutoff_top_n), float(cutoff_prob), _np_ptr(tok), _np_ptr(ts), _np_ptr(ln),
-                                    _np_ptr(sc), _stream()))
+                                    _np_ptr(sc), _stream(self.device)))
         return tok, ts, ln, sc

@@ -39,23 +39,49 @@ class SpectrogramAudioParser(AudioParser):
             self._native = _native.NativeFrontend(conf, device=self.device, pad_mode=self.pad_mode)
         return self._native
 
-    def parse_batch(self, recordings):
-        """list of 1-D arrays -> (features [B,1,F,Tmax] CUDA float32, frames int32[B]); batched extension."""
+    # sample types dsmi_features reads directly; anything else (and mixed batches) goes up as float64, the type
+    # load_audio hands to recognize() (reference resources.py:640) -- the conversion is exact for all three
+    _NATIVE_PCM = (np.dtype(np.int16), np.dtype(np.float32), np.dtype(np.float64))
+
+    def _staging(self, nbytes):
+        """Two pinned host buffers used alternately, each with the event of the upload that last read it: the host
+        fills one while the copy engine still drains the other, and nothing waits for the GPU's compute stream."""
         import torch
+        if getattr(self, "_slots", None) is None:
+            self._slots = [dict(buf=None, done=None), dict(buf=None, done=None)]
+            self._turn = 0
+            self._copy_stream = torch.cuda.Stream(device=self.device)
+        slot = self._slots[self._turn]
+        self._turn ^= 1
+        if slot["done"] is not None:
+            slot["done"].synchronize()                    # the upload issued two batches ago
+        if slot["buf"] is None or slot["buf"].numel() < nbytes:
+            slot["buf"] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8).pin_memory()
+        return slot
+
+    def parse_batch(self, recordings):
+        """list of 1-D arrays -> (features [B,1,F,Tmax] CUDA float32, frames int32[B]); batched extension.
+        Asynchronous: the upload runs on a copy stream, the kernels on the current stream behind it."""
+        import torch
+        recordings = [np.asarray(r) for r in recordings]
+        kinds = {r.dtype for r in recordings}
+        dtype = kinds.pop() if len(kinds) == 1 and next(iter(kinds)) in self._NATIVE_PCM else np.dtype(np.float64)
         n = np.array([len(r) for r in recordings], dtype=np.int64)
         total = int(n.sum())
-        # one pinned staging buffer (grow-only): clips are copied into it once and cross PCIe asynchronously
-        if getattr(self, "_stage", None) is None or self._stage.numel() < total:
-            self._stage = torch.empty(max(total, 1), dtype=torch.float64).pin_memory()
-        host = self._stage[:total].numpy()
+        slot = self._staging(total * dtype.itemsize)
+        host = slot["buf"][:total * dtype.itemsize].numpy().view(dtype)
         off = 0
         for r, k in zip(recordings, n):
-            host[off:off + k] = r              # converts to float64 like the reference's parser input (resources.py:640)
+            host[off:off + k] = r
             off += int(k)
-        pcm = self._stage[:total].to("cuda:%d" % self.device, non_blocking=True)
-        out = self._frontend().features(pcm, n)
-        torch.cuda.current_stream(self.device).synchronize()      # the staging buffer is reused by the next call
-        return out
+        main = torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(self._copy_stream):
+            pcm = slot["buf"][:total * dtype.itemsize].to("cuda:%d" % self.device, non_blocking=True)
+            slot["done"] = torch.cuda.Event()
+            slot["done"].record(self._copy_stream)
+        main.wait_event(slot["done"])
+        pcm.record_stream(main)
+        return self._frontend().features(pcm.view({2: torch.int16, 4: torch.float32, 8: torch.float64}[dtype.itemsize]), n)
 
     def parse_wav_frames(self, raws, width, channels):
         """Raw PCM WAV frames (``read_wav_frames``; one common sample width / channel count) ->
@@ -76,7 +102,8 @@ class InferenceSpectrogramAudioParser(AudioParser):
     parts of a recording with one hop carried over, normalised with statistics that move from the NST
     dataset's to the input's over the first second.
 
-    The sample bookkeeping (parsers.py:112-133) is host logic on a few hundred samples and stays here;
+    The sample bookkeeping (which samples are analysed now, which are carried to the next call) is host logic on a
+    few hundred samples and stays here;
     the STFT (no centre padding), log1p and the adaptive normalisation (parsers.py:136-161) run in
     ``dsmi_features_stream`` and the spectrogram stays on the GPU."""
 
@@ -106,22 +133,21 @@ class InferenceSpectrogramAudioParser(AudioParser):
         return self._native
 
     def parse_audio(self, part_of_recording, is_last=False):
+        """Spectrogram of the next part of the utterance.  The samples not yet analysed are the carry of the previous
+        call plus this part; whole hops of them are analysed now, and the last analysed hop plus the remainder are
+        carried over so that consecutive parts tile the signal exactly like one long STFT without centre padding.
+        A closing part shorter than one window ends the utterance with nothing."""
         import torch
-        if is_last and len(part_of_recording) < self.n_fft:            # parsers.py:106-110
+        if is_last and len(part_of_recording) < self.n_fft:
             self.reset()
             return []
-        part_of_recording = np.asarray(part_of_recording, dtype=np.float64)
+        samples = np.asarray(part_of_recording, dtype=np.float64).reshape(-1)
         if self.has_buffer:
-            part_of_recording = np.concatenate((self.buffer, part_of_recording), axis=None)
-        extra_samples = len(part_of_recording) % self.hop_length
-        if extra_samples != 0:
-            extra_samples_array = part_of_recording[-extra_samples:]
-            part_of_recording = part_of_recording[:-extra_samples]
-        self.buffer = part_of_recording[-self.hop_length:]
-        if extra_samples != 0:
-            self.buffer = np.concatenate((self.buffer, extra_samples_array), axis=None)
+            samples = np.concatenate((self.buffer, samples))
+        usable = len(samples) - len(samples) % self.hop_length
+        self.buffer = samples[max(usable - self.hop_length, 0):].copy()
         self.has_buffer = True
-        pcm = torch.from_numpy(np.ascontiguousarray(part_of_recording)).to("cuda:%d" % self.device)
+        pcm = torch.from_numpy(np.ascontiguousarray(samples[:usable])).to("cuda:%d" % self.device)
         return self._frontend().features_stream(pcm, self._state)
 
     def reset(self):

@@ -9,6 +9,9 @@
 #include <cstring>
 #include <cstdlib>
 #include <mutex>
+#include <fcntl.h>
+#include <sys/file.h>
+#include <unistd.h>
 
 using namespace dsmi;
 
@@ -59,16 +62,44 @@ static void timer_resolve(dsmi_model* m) {
     }
 }
 
-static hipEvent_t persist_gate(int device) {
+// Persistent kernels need every workgroup co-resident, so two of them must never share the device.
+//  * Within the process: one gate per device.  wait(gate) -> launch -> record(gate) runs under the gate's mutex, so
+//    two host threads with two handles / streams always chain their launches one behind the other.
+//  * Across processes: the first handle of a process takes an exclusive flock on a per-device lock file (named by
+//    the device's PCI bus id, so HIP_VISIBLE_DEVICES remapping does not matter); a process that cannot get it runs
+//    its recurrent layers on the per-step path.  DSMI_PERSIST_SHARED=1 skips the lock (one process per GPU is
+//    guaranteed by the caller).
+struct PersistGate { std::mutex mu; hipEvent_t ev = nullptr; int lock_fd = -1; bool lock_tried = false; };
+static PersistGate* persist_gate(int device) {
     static std::mutex mu;
-    static std::map<int, hipEvent_t> gates;
+    static std::map<int, PersistGate*> gates;
     std::lock_guard<std::mutex> lk(mu);
     auto it = gates.find(device);
     if (it != gates.end()) return it->second;
-    hipEvent_t e = nullptr;
-    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
-    gates[device] = e;
-    return e;
+    PersistGate* g = new PersistGate();
+    if (hipEventCreateWithFlags(&g->ev, hipEventDisableTiming) != hipSuccess) g->ev = nullptr;
+    gates[device] = g;
+    return g;
+}
+
+// true when this process may run persistent kernels on `device`
+static bool persist_process_lock(int device) {
+    const char* shared = std::getenv("DSMI_PERSIST_SHARED");
+    if (shared && shared[0] == '1') return true;
+    PersistGate* g = persist_gate(device);
+    std::lock_guard<std::mutex> lk(g->mu);
+    if (g->lock_tried) return g->lock_fd >= 0 || g->lock_fd == -2;
+    g->lock_tried = true;
+    char bus[64] = "unknown";
+    (void)hipDeviceGetPCIBusId(bus, sizeof(bus), device);
+    for (char* c = bus; *c; ++c) if (*c == ':' || *c == '.' || *c == '/') *c = '_';
+    const char* tmp = std::getenv("TMPDIR");
+    const std::string path = std::string(tmp && tmp[0] ? tmp : "/tmp") + "/dsmi-persist-" + bus + ".lock";
+    const int fd = open(path.c_str(), O_CREAT | O_RDWR, 0666);
+    if (fd < 0) { g->lock_fd = -2; return true; }          // no lock directory: nothing to arbitrate with
+    if (flock(fd, LOCK_EX | LOCK_NB) != 0) { close(fd); g->lock_fd = -1; return false; }
+    g->lock_fd = fd;                                        // held until the process exits
+    return true;
 }
 
 constexpr float kF16Safe = 60000.f;    // below fp16's 65504 with room for rounding
@@ -122,6 +153,14 @@ extern "C" int dsmi_model_create(const dsmi_model_desc* d, int device, dsmi_mode
         m->gemm_mode = (gm && std::string(gm) == "f32") ? 0 : 1;
         const char* cm = std::getenv("DSMI_CONV_MODE");       // "f32" forces the fp32-MFMA conv for all layers
         m->conv_mode = (cm && std::string(cm) == "f32") ? 0 : 1;
+        // test hooks for the hand-off timeout path (tests/test_gpu_timeout.py)
+        if (const char* sl = std::getenv("DSMI_DEBUG_SPIN_LIMIT")) m->spin_limit = (unsigned)std::max(1L, std::atol(sl));
+        if (const char* ds = std::getenv("DSMI_DEBUG_DROP_SIGNAL"))
+            if (std::sscanf(ds, "%d:%d:%d", &m->drop_layer, &m->drop_wg, &m->drop_step) != 3) m->drop_layer = -1;
+        if (m->rnn_mode == 1 && !persist_process_lock(device)) {
+            m->rnn_mode = 0;
+            m->err = "another process holds this GPU's persistent-kernel lock: recurrent layers run one launch per step";
+        }
     }
     *out = m;
     return DSMI_OK;
@@ -385,7 +424,12 @@ extern "C" void dsmi_model_destroy(dsmi_model* m) {
     if (m->finalized)
         for (int i = 0; i < 8; ++i) (void)hipEventDestroy(m->ev[i]);
     timer_resolve(m);
-    if (m->perr_host) (void)hipHostFree(m->perr_host);
+    for (auto& f : m->fwd) {
+        if (f.err_host) (void)hipHostFree(f.err_host);
+        if (f.done) (void)hipEventDestroy(f.done);
+    }
+    if (m->lens_stage) (void)hipHostFree(m->lens_stage);
+    for (hipEvent_t e : m->stage_ev) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : m->kt.free_events) (void)hipEventDestroy(e);
     delete m;
 }
@@ -458,13 +502,19 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
         for (int dd = 0; dd < 2; ++dd) { pl.whh16[dd] = m->rnn[l].whh16_sp[dd]; pl.bhh[dd] = m->rnn[l].bhh[dd]; pl.out[dd] = m->hbuf[dst][dd]; }
         pl.xp = m->xp; pl.lens_dev = m->lens_dev; pl.hpack16 = m->hpack16; pl.counters = m->pcnt; pl.err = m->perr;
         pl.B = B; pl.T = To; pl.pgroups = pgroups;
+        pl.spin_limit = m->spin_limit;
+        if (m->drop_layer == l) { pl.drop_wg = m->drop_wg; pl.drop_step = m->drop_step; }
         (void)hipMemsetAsync(m->pcnt, 0, sizeof(unsigned) * (size_t)m->geom.D * ceil_div(B, 16) * To * kPersist16CntWords, s);
-        hipEvent_t gate = persist_gate(m->device);
-        if (gate) (void)hipStreamWaitEvent(s, gate, 0);
         pl.ev = timer_arm(m, KK_PERSIST, true, 2.0 * Dd * GH * m->desc.rnn_hidden_size * sumlen,
                           4.0 * Dd * (GH * m->desc.rnn_hidden_size + (double)To * B * (GH + 2.0 * m->desc.rnn_hidden_size)));
-        const bool ok = launch_rnn_persist16(pl, s);
-        if (gate) (void)hipEventRecord(gate, s);
+        bool ok;
+        {
+            PersistGate* gate = persist_gate(m->device);
+            std::lock_guard<std::mutex> lk(gate->mu);       // wait -> launch -> record is atomic against other host threads
+            if (gate->ev) (void)hipStreamWaitEvent(s, gate->ev, 0);
+            ok = launch_rnn_persist16(pl, s);
+            if (gate->ev) (void)hipEventRecord(gate->ev, s);
+        }
         if (ok) return;
         // (not reachable for eligible shapes; the x-projection is in the other column order, so redo it)
         gl.w_sp = m->rnn[l].wih_sp; gl.bias = m->rnn[l].bih; gl.N = m->geom.Np; gl.ldc = m->geom.Np; gl.ev = EvPair{};
@@ -476,13 +526,15 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
         pl.g = m->geom;
         for (int dd = 0; dd < 2; ++dd) { pl.whh_sp[dd] = m->rnn[l].whh_sp[dd]; pl.bhh[dd] = m->rnn[l].bhh[dd]; pl.out[dd] = m->hbuf[dst][dd]; }
         pl.xp = m->xp; pl.lens_dev = m->lens_dev; pl.hpack_sp = m->hpack_sp; pl.counters = m->pcnt; pl.err = m->perr; pl.B = B; pl.T = To;
+        pl.spin_limit = m->spin_limit;
+        if (m->drop_layer == l) { pl.drop_wg = m->drop_wg; pl.drop_step = m->drop_step; }
         (void)hipMemsetAsync(m->pcnt, 0, sizeof(unsigned) * (size_t)m->geom.D * ceil_div(B, 32) * To, s);
-        // Persistent kernels need every workgroup co-resident, so two of them must never share
-        // the device (e.g. two handles on two streams): chain them through a per-device event.
-        // A layer too wide for both directions at once runs them one after the other.
+        // Two persistent kernels must never share the device (see persist_gate): chain them through the per-device
+        // event.  A layer too wide for both directions at once runs them one after the other.
         const int ny = m->geom.nwg * m->geom.D <= m->n_cus ? m->geom.D : 1;
-        hipEvent_t gate = persist_gate(m->device);
-        if (gate) (void)hipStreamWaitEvent(s, gate, 0);
+        PersistGate* gate = persist_gate(m->device);
+        std::lock_guard<std::mutex> lk(gate->mu);
+        if (gate->ev) (void)hipStreamWaitEvent(s, gate->ev, 0);
         bool ok = true;
         for (int d0 = 0; d0 < m->geom.D && ok; d0 += ny) {
             const double part = (double)ny;
@@ -491,7 +543,7 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
                               4.0 * part * (GH * m->desc.rnn_hidden_size + (double)To * B * (GH + 2.0 * m->desc.rnn_hidden_size)));
             ok = launch_rnn_persist(pl, s);
         }
-        if (gate) (void)hipEventRecord(gate, s);
+        if (gate->ev) (void)hipEventRecord(gate->ev, s);
         if (ok) return;
     }
     RnnStepLaunch st;
@@ -523,6 +575,64 @@ static GemmLaunch xproj_gemm(dsmi_model* m, int l, int B, int To) {
     return gl;
 }
 
+// host_out_lens -> lens_dev through a small ring of pinned staging slots (an async copy must not read pageable
+// memory that the next call overwrites); a slot is reused only after the copy that read it has completed.
+static int stage_lens(dsmi_model* m, int B, hipStream_t s) {
+    if (B > m->stage_cap) {
+        HIP_OK(m, hipDeviceSynchronize());
+        if (m->lens_stage) (void)hipHostFree(m->lens_stage);
+        m->lens_stage = nullptr;
+        const int cap = std::max(B, 64);
+        HIP_OK(m, hipHostMalloc((void**)&m->lens_stage, sizeof(int32_t) * (size_t)cap * dsmi_model::kStage, hipHostMallocDefault));
+        m->stage_cap = cap;
+        for (int i = 0; i < dsmi_model::kStage; ++i) {
+            if (!m->stage_ev[i]) HIP_OK(m, hipEventCreateWithFlags(&m->stage_ev[i], hipEventDisableTiming));
+            m->stage_used[i] = false;
+        }
+    }
+    const int slot = m->stage_next++ % dsmi_model::kStage;
+    if (m->stage_used[slot]) HIP_OK(m, hipEventSynchronize(m->stage_ev[slot]));
+    int32_t* h = m->lens_stage + (size_t)slot * m->stage_cap;
+    std::memcpy(h, m->host_out_lens.data(), sizeof(int32_t) * B);
+    HIP_OK(m, hipMemcpyAsync(m->lens_dev, h, sizeof(int32_t) * B, hipMemcpyHostToDevice, s));
+    HIP_OK(m, hipEventRecord(m->stage_ev[slot], s));
+    m->stage_used[slot] = true;
+    return DSMI_OK;
+}
+
+static int forward_enqueue(dsmi_model* m, const float* feat, int B, int T, float* probs, hipStream_t s);
+
+// After a hand-off timeout: clear the error word and keep this handle on the per-step path from now on.
+static int persist_give_up(dsmi_model* m, hipStream_t s) {
+    m->rnn_mode = 0;
+    HIP_OK(m, hipMemsetAsync(m->perr, 0, sizeof(unsigned), s));
+    return DSMI_OK;
+}
+
+// Collect the oldest uncollected forward (its event has completed or `wait`): DSMI_OK, DSMI_RECOMPUTED or < 0.
+static int collect_oldest(dsmi_model* m, bool recompute) {
+    dsmi_model::FwdSlot& f = m->fwd[m->fwd_head];
+    HIP_OK(m, hipEventSynchronize(f.done));
+    m->fwd_head = (m->fwd_head + 1) % dsmi_model::kFwdRing;
+    m->fwd_count -= 1;
+    if (*f.err_host == 0) return DSMI_OK;
+    *f.err_host = 0;
+    hipStream_t s = (hipStream_t)f.stream;
+    int rc;
+    if ((rc = persist_give_up(m, s))) return rc;
+    if (!recompute)
+        return fail(m, DSMI_ERR_TIMEOUT, "the persistent recurrent kernel timed out in an earlier forward whose status was never "
+                                         "collected with dsmi_forward_status: those results were invalid; this handle now runs "
+                                         "one launch per step");
+    m->host_out_lens.resize(f.B);
+    for (int i = 0; i < f.B; ++i) m->host_out_lens[i] = seq_len(m, f.lens[i]);
+    if ((rc = forward_enqueue(m, f.feat, f.B, f.T, f.probs, s))) return rc;
+    HIP_OK(m, hipStreamSynchronize(s));
+    m->recomputed += 1;
+    m->err = "a hand-off wait of the persistent recurrent kernel timed out; the batch was recomputed with one launch per step";
+    return DSMI_RECOMPUTED;
+}
+
 extern "C" int dsmi_forward(dsmi_model* m, const float* feat, const int32_t* lens, int B, int T, float* probs,
                             int32_t* out_lens, void* stream) {
     if (!m) return DSMI_ERR_INVALID;
@@ -532,18 +642,43 @@ extern "C" int dsmi_forward(dsmi_model* m, const float* feat, const int32_t* len
     if ((rc = dsmi_reserve(m, B, T))) return rc;
     HIP_OK(m, hipSetDevice(m->device));
     hipStream_t s = (hipStream_t)stream;
-    if (m->perr_host && *m->perr_host) {      // a wait inside the previous forward's persistent kernel timed out
-        *m->perr_host = 0;
-        m->rnn_mode = 0;
-        HIP_OK(m, hipMemsetAsync(m->perr, 0, sizeof(unsigned), s));
-        return fail(m, DSMI_ERR_HIP, "the persistent recurrent kernel timed out in the previous forward (results invalid); "
-                                     "falling back to one launch per step");
+    // Forwards whose status the caller has not collected: drop the finished good ones, fail loudly on a finished bad one
+    // (its results were invalid and may have been consumed), and never keep more than the ring holds in flight.
+    while (m->fwd_count > 0) {
+        const bool full = m->fwd_count == dsmi_model::kFwdRing;
+        if (!full && hipEventQuery(m->fwd[m->fwd_head].done) != hipSuccess) break;
+        if ((rc = collect_oldest(m, false)) < 0) return rc;
     }
-    const dsmi_model_desc& d = m->desc;
-    const int To = seq_len(m, T), ys = round_up(To, 4);
     for (int i = 0; i < B; ++i) out_lens[i] = seq_len(m, lens[i]);
     m->host_out_lens.assign(out_lens, out_lens + B);
-    HIP_OK(m, hipMemcpyAsync(m->lens_dev, m->host_out_lens.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice, s));
+    if ((rc = forward_enqueue(m, feat, B, T, probs, s))) return rc;
+    dsmi_model::FwdSlot& f = m->fwd[(m->fwd_head + m->fwd_count) % dsmi_model::kFwdRing];
+    f.feat = feat; f.probs = probs; f.lens.assign(lens, lens + B); f.B = B; f.T = T; f.stream = stream;
+    if (!f.done) {
+        HIP_OK(m, hipEventCreateWithFlags(&f.done, hipEventDisableTiming));
+        HIP_OK(m, hipHostMalloc((void**)&f.err_host, sizeof(unsigned), hipHostMallocDefault));
+        *f.err_host = 0;
+    }
+    HIP_OK(m, hipMemcpyAsync(f.err_host, m->perr, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    HIP_OK(m, hipEventRecord(f.done, s));
+    m->fwd_count += 1;
+    return DSMI_OK;
+}
+
+// See include/dsmi.h.  Collects the OLDEST dsmi_forward of this handle whose status has not been collected yet.
+extern "C" int dsmi_forward_status(dsmi_model* m) {
+    if (!m) return DSMI_ERR_INVALID;
+    if (m->fwd_count == 0) return DSMI_OK;
+    HIP_OK(m, hipSetDevice(m->device));
+    return collect_oldest(m, true);
+}
+
+static int forward_enqueue(dsmi_model* m, const float* feat, int B, int T, float* probs, hipStream_t s) {
+    int rc;
+    const dsmi_model_desc& d = m->desc;
+    const int To = seq_len(m, T), ys = round_up(To, 4);
+    const int32_t* out_lens = m->host_out_lens.data();
+    if ((rc = stage_lens(m, B, s))) return rc;
     if (m->Hs != d.rnn_hidden_size)
         for (int i = 0; i < 2; ++i)
             for (int dd = 0; dd < m->geom.D; ++dd)
@@ -583,13 +718,6 @@ extern "C" int dsmi_forward(dsmi_model* m, const float* feat, const int32_t* len
                          4.0 * To * B * ((d.bidirectional ? 2.0 : 1.0) * m->Hs + d.n_labels));
     }
     launch_head(h, s);
-    if (m->rnn_mode == 1) {
-        if (!m->perr_host) {
-            HIP_OK(m, hipHostMalloc((void**)&m->perr_host, sizeof(unsigned), hipHostMallocDefault));
-            *m->perr_host = 0;
-        }
-        HIP_OK(m, hipMemcpyAsync(m->perr_host, m->perr, sizeof(unsigned), hipMemcpyDeviceToHost, s));
-    }
     if (m->profiling) HIP_OK(m, hipEventRecord(m->ev[3], s));
     HIP_OK(m, hipGetLastError());
 
@@ -636,7 +764,7 @@ extern "C" int dsmi_conv_stack(dsmi_model* m, const float* feat, const int32_t* 
     const int To = seq_len(m, T), ys = round_up(To, 4);
     m->host_out_lens.resize(B);
     for (int i = 0; i < B; ++i) m->host_out_lens[i] = seq_len(m, lens[i]);
-    HIP_OK(m, hipMemcpyAsync(m->lens_dev, m->host_out_lens.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice, s));
+    if ((rc = stage_lens(m, B, s))) return rc;
     const float* cx;
     run_conv(m, feat, B, T, To, ys, s, &cx);
     // strip the time-stride padding: [B][C*F][ys] -> [B][C*F][To]
@@ -665,24 +793,36 @@ extern "C" int dsmi_rnn_layer(dsmi_model* m, int layer, const float* x, const in
     hipStream_t s = (hipStream_t)stream;
     const int H = m->desc.rnn_hidden_size;
     m->host_out_lens.assign(out_lens, out_lens + B);
-    HIP_OK(m, hipMemcpyAsync(m->lens_dev, m->host_out_lens.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice, s));
-    for (int dd = 0; dd < m->geom.D; ++dd)
-        HIP_OK(m, hipMemsetAsync(m->hbuf[0][dd], 0, sizeof(float) * (size_t)To * B * m->Hs, s));
+    if ((rc = stage_lens(m, B, s))) return rc;
     const RnnW& r = m->rnn[layer];
     const int I = layer == 0 ? m->I0 : H;
-    launch_pad_rows(x, m->xin, (size_t)To * B, I, r.ldw, s);
-    GemmLaunch gl = xproj_gemm(m, layer, B, To);
-    if (layer == 0) {
-        gl.mode = GEMM_A_ROWMAJOR; gl.a = m->xin; gl.lda = r.ldw;
-    } else {
-        gl.mode = GEMM_A_SUM_BN; gl.a = m->xin; gl.a2 = nullptr; gl.alpha = r.bn_a; gl.beta = r.bn_b; gl.lda = r.ldw;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        for (int dd = 0; dd < m->geom.D; ++dd)
+            HIP_OK(m, hipMemsetAsync(m->hbuf[0][dd], 0, sizeof(float) * (size_t)To * B * m->Hs, s));
+        launch_pad_rows(x, m->xin, (size_t)To * B, I, r.ldw, s);
+        GemmLaunch gl = xproj_gemm(m, layer, B, To);
+        if (layer == 0) {
+            gl.mode = GEMM_A_ROWMAJOR; gl.a = m->xin; gl.lda = r.ldw;
+        } else {
+            gl.mode = GEMM_A_SUM_BN; gl.a = m->xin; gl.a2 = nullptr; gl.alpha = r.bn_a; gl.beta = r.bn_b; gl.lda = r.ldw;
+        }
+        run_rnn_layer(m, layer, gl, B, To, 0, s);
+        launch_add2(m->hbuf[0][0], m->geom.D == 2 ? m->hbuf[0][1] : nullptr, y, (size_t)To * B, H, m->Hs, s);
+        HIP_OK(m, hipStreamSynchronize(s));
+        HIP_OK(m, hipGetLastError());
+        // a hand-off timeout of the persistent kernel: recompute this layer with one launch per step, in this call
+        unsigned e = 0;
+        HIP_OK(m, hipMemcpy(&e, m->perr, sizeof(unsigned), hipMemcpyDeviceToHost));
+        if (!e) return DSMI_OK;
+        if (attempt == 1) return fail(m, DSMI_ERR_TIMEOUT, "recurrent layer timed out on the per-step path");
+        HIP_OK(m, hipMemset(m->perr, 0, sizeof(unsigned)));
+        m->rnn_mode = 0;
+        m->recomputed += 1;
     }
-    run_rnn_layer(m, layer, gl, B, To, 0, s);
-    launch_add2(m->hbuf[0][0], m->geom.D == 2 ? m->hbuf[0][1] : nullptr, y, (size_t)To * B, H, m->Hs, s);
-    HIP_OK(m, hipStreamSynchronize(s));
-    HIP_OK(m, hipGetLastError());
     return DSMI_OK;
 }
+
+extern "C" int dsmi_recompute_count(const dsmi_model* m) { return m ? m->recomputed : DSMI_ERR_INVALID; }
 
 extern "C" int dsmi_set_profiling(dsmi_model* m, int level) {
     if (!m) return DSMI_ERR_INVALID;

@@ -125,6 +125,10 @@ struct RnnStepLaunch {
 };
 void launch_rnn_step(const RnnStepLaunch& p, hipStream_t s);
 
+// Polls of one hand-off wait before a persistent workgroup gives up (~1 us each: seconds, against a wait of
+// microseconds when every workgroup is resident).  DSMI_DEBUG_SPIN_LIMIT overrides it per handle (tests).
+constexpr unsigned kPersistSpinLimit = 1u << 22;
+
 // rnn_persist.hip: all T steps of one layer in one launch (weights resident in registers,
 // counter-based hand-off of h between workgroups).  Needs every workgroup co-resident.
 struct RnnPersistLaunch {
@@ -136,6 +140,8 @@ struct RnnPersistLaunch {
     unsigned* err;               // one word, set on a wait timeout
     int B, T;
     int d0 = 0, ny = 1;          // this launch covers directions d0 .. d0+ny-1 (grid = nwg x ny workgroups, all co-resident)
+    unsigned spin_limit = kPersistSpinLimit;
+    int drop_wg = -1, drop_step = -1;    // test hook: see DSMI_DEBUG_DROP_SIGNAL in api.hip
     EvPair ev;
     unsigned long long* dbg = nullptr;   // diagnostics: accumulated per-wave phase times
 };
@@ -154,6 +160,8 @@ struct RnnPersist16Launch {
     unsigned* counters;          // [D * ceil(B/16)][T][kPersist16CntWords], zeroed before the launch
     unsigned* err;
     int B, T, pgroups;           // pgroups from rnn_persist16_eligible
+    unsigned spin_limit = kPersistSpinLimit;
+    int drop_wg = -1, drop_step = -1;    // test hook: see DSMI_DEBUG_DROP_SIGNAL in api.hip
     EvPair ev;
     unsigned long long* dbg = nullptr;   // diagnostics: accumulated per-wave phase times
 };

@@ -73,7 +73,24 @@ struct dsmi_model {
     uint16_t* a_sp = nullptr;       // split A operand of the x-projection GEMM
     unsigned* pcnt = nullptr;     // persistent-kernel step counters [layers][D*ceil(B/32)][T]
     unsigned* perr = nullptr;     // persistent-kernel timeout word (device)
-    unsigned* perr_host = nullptr; // pinned mirror, refreshed at the end of every forward
+    // ---- a forward whose persistent kernel timed out is recomputed by dsmi_forward_status (api.hip).  Forwards are
+    // asynchronous, so a small ring remembers the ones whose status has not been collected yet (oldest first).
+    struct FwdSlot {
+        const float* feat = nullptr; float* probs = nullptr; std::vector<int32_t> lens; int B = 0, T = 0; void* stream = nullptr;
+        hipEvent_t done = nullptr;     // recorded behind the error word's copy at the end of the forward
+        unsigned* err_host = nullptr;  // pinned mirror of the error word as that forward left it
+    };
+    static constexpr int kFwdRing = 4;
+    FwdSlot fwd[kFwdRing];
+    int fwd_head = 0, fwd_count = 0;   // oldest uncollected slot, number of uncollected forwards
+    int recomputed = 0;            // forwards recomputed on the per-step path so far
+    unsigned spin_limit = dsmi::kPersistSpinLimit;   // DSMI_DEBUG_SPIN_LIMIT
+    int drop_layer = -1, drop_wg = -1, drop_step = -1;   // DSMI_DEBUG_DROP_SIGNAL=layer:workgroup:step (tests: force a timeout)
+    int persist_lock_fd = -1;      // this process holds the device's persistent-kernel lock file
+    // pinned staging of the per-batch lengths (pageable memory must not back an async copy)
+    static constexpr int kStage = 4;
+    int32_t* lens_stage = nullptr; int stage_cap = 0, stage_next = 0;
+    hipEvent_t stage_ev[kStage] = {nullptr, nullptr, nullptr, nullptr}; bool stage_used[kStage] = {false, false, false, false};
     int n_cus = 0;
     int conv_mode = 1;            // 1: split-fp16 conv for the 32-input-channel layers, 0: fp32 MFMA conv
     int gemm_mode = 1;            // 1: split-fp16 GEMM, 0: fp32 MFMA GEMM

@@ -42,7 +42,6 @@ namespace {
 constexpr int PNW = 8;                 // waves per workgroup
 constexpr int PNT = PNW * 64;
 constexpr int PU = 8;                  // hidden units per workgroup (rnn geometry U)
-constexpr unsigned SPIN_LIMIT = 1u << 22;
 constexpr int RP = 40;                 // row pitch of the reduce buffer in words
 constexpr size_t PERSIST_LDS = 82 * 1024;   // > half of the CU's 160 KiB: at most one workgroup per CU
 
@@ -58,6 +57,8 @@ struct PersistArgs {
     int B, T, G, H, Hs, npair, Np, nwg;
     int nz;                    // batch tiles of 32 clips, all walked by every workgroup each step
     int d0, nd;                // first direction of this launch, directions in the layer (chains are numbered over the layer)
+    unsigned spin_limit;       // polls of one wait before the workgroup raises *err and stops waiting
+    int drop_wg, drop_step;    // test hook (DSMI_DEBUG_DROP_SIGNAL): this workgroup of direction 0 never signals that step (-1: off)
     unsigned long long* dbg;   // diagnostics build only: per-wave accumulated phase times [wg][wave][8]
 };
 
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(PNT) void rnn_persist_kernel(PersistArgs p) {
                     __builtin_amdgcn_s_sleep(1);
                     ++spins;
                     if ((spins & 1023u) == 0 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { s_dead = 1; break; }
-                    if (spins > SPIN_LIMIT) { atomicExch(p.err, 1u); s_dead = 1; break; }
+                    if (spins > p.spin_limit) { atomicExch(p.err, 1u); s_dead = 1; break; }
                 }
             }
             __syncthreads();
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(PNT) void rnn_persist_kernel(PersistArgs p) {
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave drains its own stores
             __syncthreads();
-            if (tid == 0) __hip_atomic_fetch_add(&cnt[s], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0 && !(d == 0 && w == p.drop_wg && s == p.drop_step)) __hip_atomic_fetch_add(&cnt[s], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         PSTAMP(5);   // publish + drain + signal
       }
@@ -347,6 +348,7 @@ bool launch_rnn_persist(const RnnPersistLaunch& p, hipStream_t s) {
     a.xp = p.xp; a.lens = p.lens_dev; a.hpack_sp = p.hpack_sp; a.cnt = p.counters; a.err = p.err; a.dbg = p.dbg;
     a.B = p.B; a.T = p.T; a.G = p.g.G; a.H = p.g.H; a.Hs = p.g.Kp; a.npair = ceil_div(p.g.nq, 2); a.Np = p.g.Np; a.nwg = p.g.nwg;
     a.nz = ceil_div(p.B, 32); a.d0 = p.d0; a.nd = p.g.D;
+    a.spin_limit = p.spin_limit; a.drop_wg = p.drop_wg; a.drop_step = p.drop_step;
     switch (p.g.kind) {
         case DSMI_RNN_GRU: return launch_kind<DSMI_RNN_GRU>(a, p.ny, s, p.ev);
         case DSMI_RNN_LSTM: return launch_kind<DSMI_RNN_LSTM>(a, p.ny, s, p.ev);

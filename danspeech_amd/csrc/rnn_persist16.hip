@@ -31,7 +31,6 @@ constexpr int QU = 16;                 // hidden units per workgroup
 constexpr int QB = 16;                 // clips per batch tile
 constexpr int QRP = 20;                // row pitch (words) of the reduce buffer: conflict-free for the MFMA-layout writes
 constexpr int QMAXZ = 8;               // batch tiles one workgroup can walk
-constexpr unsigned Q_SPIN_LIMIT = 1u << 22;
 constexpr size_t Q_LDS = 82 * 1024;    // > half of the CU's LDS: one workgroup per CU
 constexpr size_t Q_LDS_PIPE = 112 * 1024;   // pipelined variant: two reduce buffers
 
@@ -47,6 +46,8 @@ struct P16Args {
     int ntiles;                // 16-clip batch tiles
     int pgroups;               // tile groups running side by side (gridDim.y = D * pgroups); a workgroup walks tiles pg, pg + pgroups, ...
     int D;
+    unsigned spin_limit;       // polls of one wait before the workgroup raises *err and stops waiting
+    int drop_wg, drop_step;    // test hook (DSMI_DEBUG_DROP_SIGNAL): workgroup drop_wg of chain 0 never signals step drop_step (-1: off)
     unsigned long long* dbg;   // diagnostics build only: per-wave accumulated phase times [workgroup][wave][8]
 };
 
@@ -129,6 +130,7 @@ __global__ __launch_bounds__(QNT) void rnn_persist16_kernel(P16Args p) {
     __syncthreads();
 
     unsigned* pend = nullptr;          // several tiles: counter of the tile just published, signalled behind the next tile's MFMAs
+    bool pend_drop = false;
     for (int s = 0; s < p.T; ++s) {
         const int t = d == 0 ? s : p.T - 1 - s;
         for (int z = 0; z < nz; ++z) {
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(QNT) void rnn_persist16_kernel(P16Args p) {
                         __builtin_amdgcn_s_sleep(1);
                         ++spins;
                         if ((spins & 1023u) == 0 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { s_dead = 1; break; }
-                        if (spins > Q_SPIN_LIMIT) { atomicExch(p.err, 1u); s_dead = 1; break; }
+                        if (spins > p.spin_limit) { atomicExch(p.err, 1u); s_dead = 1; break; }
                     }
                 }
                 __syncthreads();
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(QNT) void rnn_persist16_kernel(P16Args p) {
                     red[((v * 4 + g) * 16 + 4 * lg + r) * QRP + ln] = acc[g][r] + acl[g][r] * kLoInv;
             if (multi) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the previous tile's state stores are acknowledged
             __syncthreads();
-            if (multi && tid == 0 && pend) __hip_atomic_fetch_add(pend, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (multi && tid == 0 && pend && !pend_drop) __hip_atomic_fetch_add(pend, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             QSTAMP(3);   // partial tiles to LDS + barrier (wave skew)
             // ---- K-split reduction (fixed order) + cell + publish, one (unit, clip) pair per thread
             if (tid < 256) {
@@ -250,12 +252,14 @@ __global__ __launch_bounds__(QNT) void rnn_persist16_kernel(P16Args p) {
                 __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, h2), hrs, off + 1024u, 0, 16);
             }
             QSTAMP(4);   // reduction + cell + publish stores issued
+            const bool drop = chain == 0 && w == p.drop_wg && s == p.drop_step;
             if (multi) {
                 pend = &cnt[(size_t)s * kPersist16CntWords + (w & (kPersist16Shards - 1)) * 64];
+                pend_drop = drop;
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave drains its own stores
                 __syncthreads();
-                if (tid == 0) __hip_atomic_fetch_add(&cnt[(size_t)s * kPersist16CntWords + (w & (kPersist16Shards - 1)) * 64], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (tid == 0 && !drop) __hip_atomic_fetch_add(&cnt[(size_t)s * kPersist16CntWords + (w & (kPersist16Shards - 1)) * 64], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             QSTAMP(5);   // drain + barrier + signal
         }
@@ -348,6 +352,7 @@ __global__ __launch_bounds__(QNT) void rnn_persist16_pipe_kernel(P16Args p) {
         for (int g = 0; g < NG; ++g) xg[g] = xr[g * QU];
     }
     unsigned* pend = nullptr;
+    bool pend_drop = false;
 
     for (int i = 0; i < NI; ++i) {
         const int s = i / nz, z = i - s * nz;
@@ -380,7 +385,7 @@ __global__ __launch_bounds__(QNT) void rnn_persist16_pipe_kernel(P16Args p) {
                 red[((v * 4 + g) * 16 + 4 * lg + r) * QRP + ln] = acc[g][r] + acl[g][r] * kLoInv;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // instance i-1's state stores are acknowledged
         __syncthreads();
-        if (tid == 0 && pend) __hip_atomic_fetch_add(pend, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0 && pend && !pend_drop) __hip_atomic_fetch_add(pend, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // ---- A(i+1): wait for the producers of the next instance and request its state and x-projection
         if (i + 1 < NI) {
             const int s1 = (i + 1) / nz, z1 = (i + 1) - s1 * nz;
@@ -397,7 +402,7 @@ __global__ __launch_bounds__(QNT) void rnn_persist16_pipe_kernel(P16Args p) {
                         __builtin_amdgcn_s_sleep(1);
                         ++spins;
                         if ((spins & 1023u) == 0 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { s_dead = 1; break; }
-                        if (spins > Q_SPIN_LIMIT) { atomicExch(p.err, 1u); s_dead = 1; break; }
+                        if (spins > p.spin_limit) { atomicExch(p.err, 1u); s_dead = 1; break; }
                     }
                 }
                 __syncthreads();
@@ -467,6 +472,7 @@ __global__ __launch_bounds__(QNT) void rnn_persist16_pipe_kernel(P16Args p) {
             __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, h2), hrs, tid < 256 ? off + 1024u : oob, 0, 16);
         }
         pend = &cnt[(size_t)s * kPersist16CntWords + (w & (kPersist16Shards - 1)) * 64];
+        pend_drop = chain == 0 && w == p.drop_wg && s == p.drop_step;
 #pragma unroll
         for (int g = 0; g < NG; ++g) xg[g] = xn[g];
     }
@@ -575,6 +581,7 @@ bool launch_rnn_persist16(const RnnPersist16Launch& p, hipStream_t s) {
     a.xp = p.xp; a.lens = p.lens_dev; a.hpack = p.hpack16; a.cnt = p.counters; a.err = p.err;
     a.B = p.B; a.T = p.T; a.H = p.g.H; a.Hs = p.g.Kp; a.Np = p.g.Np; a.nwg = p.g.nwg; a.nkb = ceil_div(p.g.H, 32);
     a.ntiles = ceil_div(p.B, QB); a.pgroups = p.pgroups; a.D = p.g.D; a.dbg = p.dbg;
+    a.spin_limit = p.spin_limit; a.drop_wg = p.drop_wg; a.drop_step = p.drop_step;
     switch (p.g.kind) {
         case DSMI_RNN_GRU: return launch16<DSMI_RNN_GRU>(a, s, p.ev);
         case DSMI_RNN_LSTM: return launch16<DSMI_RNN_LSTM>(a, s, p.ev);

@@ -139,6 +139,22 @@ class DeepSpeech(object):
         probs, out_lens = self._native.forward(x, lengths.numpy())
         return probs, torch.from_numpy(out_lens.copy()).int()
 
+    def enqueue(self, x, lengths):
+        """``forward`` without waiting for the GPU: the kernels are enqueued on the current stream and the
+        probabilities may be consumed only after ``collect()`` (once per ``enqueue``, in order).  For callers that
+        keep several batches in flight (``DanSpeechRecognizer.transcribe_batches``)."""
+        import torch
+        if self._native is None:
+            raise RuntimeError("this DeepSpeech runs only on an MI355X: call model.to('cuda') first (no CPU path)")
+        lengths = torch.as_tensor(lengths).cpu().int()
+        x = torch.as_tensor(x, dtype=torch.float32).to(torch.device(self.device)).contiguous()
+        probs, out_lens = self._native.forward(x, lengths.numpy(), check=False)
+        return probs, torch.from_numpy(out_lens.copy()).int()
+
+    def collect(self):
+        """Wait for the oldest ``enqueue`` and validate it (``dsmi_forward_status``)."""
+        return self._native.status()
+
     def streaming_forward(self, x, is_first, is_last):
         """model.py:517-537: one chunk [1,1,F,T] of the streaming parser's output -> probs [1,T_out,C], or None
         on the first pass (the lookahead is still buffering).  Conv context, recurrent state and lookahead
@@ -164,7 +180,7 @@ class DeepSpeech(object):
     @classmethod
     def load_model(cls, path):
         import torch
-        package = torch.load(path, map_location=lambda storage, loc: storage, weights_only=False)
+        package = torch.load(path, map_location="cpu", weights_only=True)     # plain dicts / lists / tensors: nothing to unpickle
         return cls.load_model_package(package)
 
     @classmethod

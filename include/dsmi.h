@@ -45,7 +45,9 @@ typedef enum {
     DSMI_ERR_HIP = -5,         /* HIP runtime failure                                */
     DSMI_ERR_NOMEM = -6,
     DSMI_ERR_IO = -7,          /* LM file unreadable / malformed                     */
-    DSMI_ERR_CAPACITY = -8     /* batch/time exceeds dsmi_reserve()                  */
+    DSMI_ERR_CAPACITY = -8,    /* batch/time exceeds dsmi_reserve()                  */
+    DSMI_ERR_TIMEOUT = -9,     /* a persistent recurrent kernel's hand-off wait timed out and the batch could not be recomputed */
+    DSMI_RECOMPUTED = 1        /* dsmi_forward_status: the batch was recomputed on the per-step path; results valid now */
 } dsmi_status;
 
 enum { DSMI_RNN_GRU = 0, DSMI_RNN_LSTM = 1, DSMI_RNN_TANH = 2 };
@@ -167,6 +169,22 @@ int dsmi_segment(dsmi_frontend* f, const void* pcm_dev, int pcm_dtype, int64_t n
  * probabilities where T_out = seq_lens(T); out_lens_host[B]. */
 int dsmi_forward(dsmi_model* m, const float* feat_dev, const int32_t* lens_host, int B, int T,
                  float* probs_dev, int32_t* out_lens_host, void* stream);
+/* dsmi_forward is asynchronous on `stream`; dsmi_forward_status blocks until the handle's OLDEST dsmi_forward whose
+ * status has not been collected yet has finished, and says whether its results are valid (the reference's forward is
+ * synchronous and cannot fail this way: torch's CPU kernels do not depend on co-residency).  Call it once per forward,
+ * in order, before consuming that forward's probs_dev; its feat_dev, probs_dev and stream must still be alive.  Up to 4
+ * forwards may be in flight uncollected (a pipelining caller enqueues batch i+1 before collecting batch i).
+ *   DSMI_OK          results valid.
+ *   DSMI_RECOMPUTED  a hand-off wait inside the persistent recurrent kernel timed out (not all of its workgroups were
+ *                    resident: another kernel or process occupied compute units).  The SAME batch has been recomputed
+ *                    with one launch per time step into the same probs_dev before this call returned: results valid
+ *                    now, and the handle keeps using the per-step path.  dsmi_last_error() holds a description.
+ *   < 0              the recompute itself failed.
+ * Uncollected forwards that finished well are forgotten by the next dsmi_forward; one that finished with a timeout
+ * makes the next dsmi_forward fail with DSMI_ERR_TIMEOUT (its results were invalid and may have been consumed). */
+int dsmi_forward_status(dsmi_model* m);
+/* Number of batches / layers this handle had to recompute after a hand-off timeout (0 in normal operation). */
+int dsmi_recompute_count(const dsmi_model* m);
 
 /* Stage-level entry points (same arithmetic as inside dsmi_forward), used by the
  * parity tests against the reference's MaskConv (model.py:65-81) and BatchRNN

@@ -1,0 +1,187 @@
+"""GPU tests of the failure and guard paths around the persistent recurrent kernels:
+
+* a hand-off wait that times out (forced with the DSMI_DEBUG_DROP_SIGNAL / DSMI_DEBUG_SPIN_LIMIT test
+  hooks: one workgroup never signals one step) must be reported by the SAME forward -- the batch is
+  recomputed on the per-step path inside ``dsmi_forward_status`` / ``dsmi_rnn_layer`` and the results
+  equal the oracle's;
+* weights outside the fp16 range of the split operands (|w| >= 60000) route the affected stage to the
+  fp32-MFMA kernels at load time; tiny weights (fp16-subnormal ``hi`` terms) and saturating gates
+  (the hardware exp / rcp cell) stay within the parity bound.
+"""
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+from danspeech_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def native():
+    from danspeech_amd import _native
+    assert torch.cuda.is_available()
+    _native.lib()
+    return _native
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _cfg(H, L, kind="gru", cl=2):
+    return dict(conv_layers=cl, rnn_type=kind, rnn_hidden_size=H, rnn_layers=L, bidirectional=True, context=20)
+
+
+def _batch(B=5, T=161, seed=3):
+    lens = np.sort(np.random.default_rng(seed).integers(T // 2, T + 1, size=B))[::-1].astype(np.int32)
+    lens[0] = T
+    x = syn.make_features(B, T, seed=seed)
+    for b, L in enumerate(lens):
+        x[b, :, :, L:] = 0
+    return x, lens
+
+
+class _env:
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        os.environ.update(self.kv)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("H", [64, 40])          # 64: rnn_persist16 (H % 16 == 0); 40: first-generation kernel
+def test_timeout_is_reported_and_recomputed_by_the_same_forward(native, H):
+    from oracle import torch_port as tp
+    cfg = _cfg(H, 3)
+    sd = syn.make_state_dict(2, "gru", H, 3, seed=21, **syn.TALKATIVE)
+    x, lens = _batch()
+    ref, ol_ref = tp.forward(sd, cfg, x, lens)
+    # workgroup 1 of direction 0 never signals step 7 of layer 1; a wait gives up after 3000 polls
+    with _env(DSMI_DEBUG_DROP_SIGNAL="1:1:7", DSMI_DEBUG_SPIN_LIMIT="3000"):
+        m = native.NativeModel(cfg, sd)
+    xd = _dev(x)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        p, ol = m.forward(xd, lens, check=False)
+        assert m.status() is True                       # this very forward reports it ...
+    assert any("timed out" in str(x.message) for x in w)
+    assert m.recompute_count() == 1
+    assert np.array_equal(ol, ol_ref)
+    np.testing.assert_allclose(p.cpu().numpy(), ref, rtol=0, atol=1e-4)     # ... and its results are the recomputed ones
+    # the handle stays usable (per-step path from now on), nothing left to report
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        p2, _ = m.forward(xd, lens)
+    assert not w and m.recompute_count() == 1
+    np.testing.assert_allclose(p2.cpu().numpy(), ref, rtol=0, atol=1e-4)
+    m.close()
+
+
+def test_uncollected_timeout_fails_the_next_forward(native):
+    cfg = _cfg(64, 2)
+    sd = syn.make_state_dict(2, "gru", 64, 2, seed=22)
+    x, lens = _batch()
+    with _env(DSMI_DEBUG_DROP_SIGNAL="0:0:3", DSMI_DEBUG_SPIN_LIMIT="3000"):
+        m = native.NativeModel(cfg, sd)
+    xd = _dev(x)
+    m.forward(xd, lens, check=False)
+    torch.cuda.synchronize()
+    with pytest.raises(native.DsmiError) as e:         # status never collected: loud failure, not silent garbage
+        m.forward(xd, lens, check=False)
+    assert e.value.code == native.DSMI_ERR_TIMEOUT
+    p, _ = m.forward(xd, lens)                          # recovered: per-step path
+    from oracle import torch_port as tp
+    np.testing.assert_allclose(p.cpu().numpy(), tp.forward(sd, cfg, x, lens)[0], rtol=0, atol=1e-4)
+    m.close()
+
+
+def test_rnn_layer_entry_recomputes_after_timeout(native):
+    from oracle import model as om
+    H = 64
+    cfg = _cfg(H, 2, cl=1)
+    audio_conf = dict(sampling_rate=100, window_size=0.02)       # n_freq = 2 -> layer-0 input size 32
+    sd = syn.make_state_dict(1, "gru", H, 2, seed=23, sample_rate=100)
+    with _env(DSMI_DEBUG_DROP_SIGNAL="1:2:4", DSMI_DEBUG_SPIN_LIMIT="3000"):
+        m = native.NativeModel(cfg, sd, audio_conf=audio_conf)
+    rng = np.random.default_rng(5)
+    lens = np.array([30, 22, 9], dtype=np.int32)
+    x = rng.standard_normal((30, 3, H)).astype(np.float32)
+    y = m.rnn_layer(1, _dev(x), lens).cpu().numpy()
+    ref = om.batch_rnn(sd, 1, "gru", x, lens, True, True)
+    np.testing.assert_allclose(y, ref, rtol=0, atol=5e-6)
+    assert m.recompute_count() == 1
+    m.close()
+
+
+@pytest.mark.parametrize("where", ["conv", "w_ih", "w_hh", "bn"])
+def test_fp16_range_guard_falls_back_to_fp32_kernels(native, where):
+    """One weight beyond fp16's range: the stage must leave the split-fp16 kernels (a split would produce inf)."""
+    from oracle import torch_port as tp
+    H = 64
+    cfg = _cfg(H, 2)
+    sd = syn.make_state_dict(2, "gru", H, 2, seed=24)
+    if where == "conv":
+        sd["conv.seq_module.3.weight"][3, 5, 7, 2] = 7.0e4
+    elif where == "w_ih":
+        sd["rnns.1.rnn.weight_ih_l0"][10, 3] = -7.0e4
+    elif where == "w_hh":
+        sd["rnns.0.rnn.weight_hh_l0_reverse"][100, 17] = 6.6e4
+    else:
+        sd["rnns.1.batch_norm.module.weight"][5] = 5.0e4        # 2|a| + |b| bound of the GEMM's A operand
+    x, lens = _batch(B=4, T=121, seed=8)
+    m = native.NativeModel(cfg, sd)
+    p, ol = m.forward(_dev(x), lens)
+    ref, _ = tp.forward(sd, cfg, x, lens)
+    pn = p.cpu().numpy()
+    assert np.isfinite(pn).all()
+    np.testing.assert_allclose(pn, ref, rtol=0, atol=1e-4)
+    m.close()
+
+
+@pytest.mark.parametrize("kind", ["gru", "lstm", "rnn"])
+def test_tiny_weights_and_saturating_gates(native, kind):
+    """|w| ~ 1e-7 (the fp16 ``hi`` term is subnormal or zero, the value lives in ``lo``) in one layer, and biases of
+    +-100 in another (exp overflows to inf / underflows to 0 in the hardware-exp cell: sigmoid and tanh must
+    saturate to exactly 0 / 1 / -1, never NaN)."""
+    from oracle import torch_port as tp
+    from oracle import model as om
+    H = 64
+    cfg = _cfg(H, 3, kind=kind)
+    sd = syn.make_state_dict(2, kind, H, 3, seed=25, **syn.TALKATIVE)
+    for sfx in ("", "_reverse"):
+        sd["rnns.1.rnn.weight_hh_l0" + sfx] = (sd["rnns.1.rnn.weight_hh_l0" + sfx] * np.float32(1e-6)).astype(np.float32)
+        sd["rnns.1.rnn.weight_ih_l0" + sfx] = (sd["rnns.1.rnn.weight_ih_l0" + sfx] * np.float32(1e-6)).astype(np.float32)
+        b = sd["rnns.2.rnn.bias_hh_l0" + sfx]
+        b[0::7] = 100.0
+        b[3::7] = -100.0
+    x, lens = _batch(B=3, T=141, seed=9)
+    m = native.NativeModel(cfg, sd)
+    p, ol = m.forward(_dev(x), lens)
+    pn = p.cpu().numpy()
+    assert np.isfinite(pn).all()
+    ref, _ = tp.forward(sd, cfg, x, lens)
+    np.testing.assert_allclose(pn, ref, rtol=0, atol=1e-4)
+    # the layer with the tiny weights on its own, at stage tolerance
+    audio_conf = dict(sampling_rate=100, window_size=0.02)
+    sd1 = syn.make_state_dict(1, kind, H, 2, seed=26, sample_rate=100)
+    for sfx in ("", "_reverse"):
+        sd1["rnns.1.rnn.weight_hh_l0" + sfx] = (sd1["rnns.1.rnn.weight_hh_l0" + sfx] * np.float32(3e-6)).astype(np.float32)
+    m1 = native.NativeModel(_cfg(H, 2, kind=kind, cl=1), sd1, audio_conf=audio_conf)
+    rng = np.random.default_rng(6)
+    l1 = np.array([40, 33, 12], dtype=np.int32)
+    x1 = rng.standard_normal((40, 3, H)).astype(np.float32)
+    y = m1.rnn_layer(1, _dev(x1), l1).cpu().numpy()
+    np.testing.assert_allclose(y, om.batch_rnn(sd1, 1, kind, x1, l1, True, True), rtol=0, atol=5e-6)
+    m.close(); m1.close()

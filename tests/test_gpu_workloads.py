@@ -1,0 +1,226 @@
+"""GPU parity on the BASELINE.json configurations AS WORKLOADS (the geometries bench.py and
+tools/run_configs.py time), against the CPU oracle on the same seeded inputs:
+
+  config 2  cfgA (2 conv + 5 x BiGRU 800), greedy, B = 32 ragged 4..10 s clips -- the benchmarked batch:
+            2 directions x 2 sixteen-clip tiles x 50 workgroups of the persistent recurrent kernel
+  config 3  the same batch through the 3-gram beam search (beam 64)
+  config 4  cfgB (2 conv + 7 x BiGRU 1200) + 5-gram, beam 128, B = 64 ragged clips through
+            Recognizer.recognize_batch(show_all=True); 3 s clips bound the oracle's time
+  config 5  one GPU's share of the long-form job: cfgA, B = 128 x 30 s (T = 3001), 3-gram beam 64: the
+            software-pipelined multi-tile recurrent kernel; oracle on a sampled subset of the clips +
+            batch invariance on all of them
+
+The model oracle is oracle/torch_port.py (pinned to the reference's golden vectors by
+tests/test_oracle_torch_port.py); weights are ``syn.TALKATIVE`` so that transcripts carry 40-170 tokens
+with repeats, blanks and spaces (checked).  Tolerances: features 2e-5, probabilities 1e-4 (north_star),
+greedy transcripts + offsets identical, beam strings/timesteps identical and scores within 1e-4 on
+identical probabilities.
+"""
+import numpy as np
+import pytest
+
+from danspeech_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+LABELS = syn.DANSPEECH_LABELS
+
+
+@pytest.fixture(scope="module")
+def native():
+    from danspeech_amd import _native
+    assert torch.cuda.is_available()
+    _native.lib()
+    return _native
+
+
+def _cfg(H, L):
+    return dict(conv_layers=2, rnn_type="gru", rnn_hidden_size=H, rnn_layers=L, bidirectional=True, context=20)
+
+
+def _ragged_clips(B, lo, hi, seed, first=None):
+    rng = np.random.default_rng(seed)
+    n = np.sort(rng.integers(lo, hi + 1, size=B))[::-1].copy()
+    n[0] = first or hi
+    return [syn.make_clip(100 * seed + i, int(k)) for i, k in enumerate(n)]
+
+
+def _gpu_pipeline(native, cfg, sd, clips):
+    m = native.NativeModel(cfg, sd)
+    fe = native.NativeFrontend()
+    n = np.array([len(c) for c in clips], dtype=np.int64)
+    pcm = torch.from_numpy(np.concatenate(clips)).cuda()
+    feat, frames = fe.features(pcm, n)
+    probs, out_lens = m.forward(feat, frames)
+    assert m.recompute_count() == 0, "the persistent kernel timed out: this test must exercise it"
+    return m, fe, feat, frames, probs, out_lens
+
+
+def _margins(p, ol):
+    top2 = np.sort(p, axis=-1)[..., -2:]
+    mar = top2[..., 1] - top2[..., 0]
+    return np.array([mar[b, :ol[b]].min() for b in range(p.shape[0])])
+
+
+def _check_greedy(native, probs, out_lens, p_ref, ol_ref, err, min_tokens):
+    """Transcripts and offsets identical to the oracle's for every clip whose top-2 margin is well above the
+    measured probability error (all of them, in practice); the weights must make that a real check."""
+    from oracle import decoder as od
+    gd = native.NativeDecoder(LABELS, blank_index=0)
+    dec = gd.greedy(probs, out_lens)
+    s_ref, o_ref = od.greedy_decode(p_ref, ol_ref, LABELS, 0)
+    mar = _margins(p_ref, ol_ref)
+    safe = mar > 20 * max(err, 1e-7)
+    assert safe.mean() >= 0.9, "top-2 margins too small for a bit-exact transcript check: %s" % np.sort(mar)[:4]
+    lens = []
+    for b in range(len(dec)):
+        got = "".join(LABELS[i] for i in dec[b][0])
+        lens.append(len(got))
+        if safe[b]:
+            assert got == s_ref[b][0], (b, got, s_ref[b][0])
+            assert np.array_equal(dec[b][1], o_ref[b][0]), b
+    assert min(lens) >= min_tokens, lens
+    text = "".join("".join(LABELS[i] for i in d[0]) for d in dec)
+    assert " " in text and len(set(text)) >= 10
+    gd.close()
+    return lens
+
+
+def test_config2_cfgA_batch32_ragged_greedy(native):
+    """The benchmarked geometry itself."""
+    from oracle import torch_port as tp
+    cfg = _cfg(800, 5)
+    sd = syn.make_state_dict(2, "gru", 800, 5, seed=0, **syn.TALKATIVE)
+    clips = _ragged_clips(32, 64000, 160000, seed=1)
+    m, fe, feat, frames, probs, out_lens = _gpu_pipeline(native, cfg, sd, clips)
+    x_ref, fr_ref = tp.spectrogram_batch(clips)
+    assert np.array_equal(frames, fr_ref) and int(frames.max()) == 1001
+    np.testing.assert_allclose(feat.cpu().numpy(), x_ref, rtol=0, atol=2e-5)
+    p_ref, ol_ref = tp.forward(sd, cfg, x_ref, fr_ref)
+    assert np.array_equal(out_lens, ol_ref)
+    pn = probs.cpu().numpy()
+    for b in range(32):
+        pn[b, ol_ref[b]:] = p_ref[b, ol_ref[b]:]        # rows past a clip's length are never consumed (decoders stop at sizes)
+    err = float(np.abs(pn - p_ref).max())
+    print("config 2 (cfgA, B=32 ragged): max |probs - oracle| = %.3g" % err)
+    assert err < 1e-4
+    lens = _check_greedy(native, probs, out_lens, p_ref, ol_ref, err, min_tokens=30)
+    print("config 2 transcript lengths: min %d max %d" % (min(lens), max(lens)))
+    m.close(); fe.close()
+
+
+def _compare_beams(native, probs_gpu, out_lens, lm_path, alpha, beta, beam, clips_to_check, n_check=10):
+    """GPU beam search vs the oracle's on the SAME probabilities (the GPU's, copied to the host)."""
+    from oracle import beam as ob
+    dec = native.NativeDecoder(LABELS, blank_index=0)
+    dec.set_lm(lm_path, alpha, beta)
+    tok, ts, ln, sc = dec.beam(probs_gpu, out_lens, beam_width=beam, cutoff_top_n=40, cutoff_prob=1.0)
+    scorer = ob.Scorer(alpha, beta, lm_path, LABELS)
+    ph = probs_gpu.cpu().numpy().astype(np.float64)
+    for b in clips_to_check:
+        ref = ob.ctc_beam_search(ph[b, :out_lens[b]], LABELS, beam, scorer=scorer)
+        for k in range(min(n_check, len(ref))):
+            got = "".join(LABELS[i] for i in tok[b, k, :ln[b, k]])
+            want = "".join(LABELS[c] for c in ref[k][1])
+            assert got == want, (b, k, got, want)
+            assert list(ts[b, k, :ln[b, k]]) == list(ref[k][2]), (b, k)
+            assert abs(float(sc[b, k]) - ref[k][0]) < 1e-4 * max(1.0, abs(ref[k][0]) / 100.0), (b, k, sc[b, k], ref[k][0])
+    dec.close()
+    return tok, ln, sc
+
+
+def test_config3_cfgA_batch32_beam64_3gram(native, tmp_path):
+    cfg = _cfg(800, 5)
+    sd = syn.make_state_dict(2, "gru", 800, 5, seed=0, **syn.TALKATIVE)
+    clips = _ragged_clips(32, 64000, 160000, seed=1)
+    lm = str(tmp_path / "syn3.arpa")
+    syn.make_arpa(lm, order=3, n_words=5000, seed=11, ngrams_per_order=20000)
+    m, fe, feat, frames, probs, out_lens = _gpu_pipeline(native, cfg, sd, clips)
+    tok, ln, sc = _compare_beams(native, probs, out_lens, lm, 1.3, 0.2, 64, range(32))
+    assert (ln[:, 0] >= 5).all() and ln[:, 0].max() >= 25      # dictionary-constrained beams are shorter than the greedy path
+    m.close(); fe.close()
+
+
+def test_config4_cfgB_batch64_beam128_5gram_through_recognizer(native, tmp_path):
+    """TransferLearned-shape workload of BASELINE.json configs[3]: 7 x BiGRU 1200 (wide persistent variant, one
+    launch per direction), B = 64 ragged, beam 128 + 5-gram, through the public surface."""
+    from danspeech_amd import Recognizer
+    from danspeech_amd.deepspeech.model import DeepSpeech
+    from danspeech_amd.language_models import CustomLanguageModel
+    from oracle import torch_port as tp, beam as ob
+    H, L, B = 1200, 7, 64
+    cfg = _cfg(H, L)
+    sd = syn.make_state_dict(2, "gru", H, L, seed=4, **syn.TALKATIVE)
+    lm = str(tmp_path / "syn5.arpa")
+    syn.make_arpa(lm, order=5, n_words=5000, seed=12, ngrams_per_order=20000)
+    model = DeepSpeech("cfgB", rnn_type="gru", rnn_hidden_size=H, rnn_layers=L, conv_layers=2).load_state_dict(sd)
+    rec = Recognizer(model=model, lm=CustomLanguageModel(lm), alpha=1.2, beta=0.15, beam_width=128)
+    clips = _ragged_clips(B, 24000, 48000, seed=2)
+    order = np.random.default_rng(3).permutation(B)              # the caller's order is arbitrary
+    shuffled = [clips[i] for i in order]
+    beams = rec.recognize_batch(shuffled, show_all=True)
+    best = rec.recognize_batch(shuffled)
+    eng = rec.danspeech_recognizer
+    assert eng.model._native.recompute_count() == 0
+    assert len(beams) == B and all(len(b) == 128 for b in beams)
+    assert [b[0] for b in beams] == best
+    # oracle: features + forward on the length-sorted batch, beam search per clip
+    x_ref, fr_ref = tp.spectrogram_batch(clips)
+    p_ref, ol_ref = tp.forward(sd, cfg, x_ref, fr_ref)
+    feats, frames = eng.audio_parser.parse_batch(clips)
+    probs, out_lens = eng.model(feats, torch.from_numpy(frames.astype(np.int32)))
+    pn = probs.cpu().numpy()
+    err = max(float(np.abs(pn[b, :ol_ref[b]] - p_ref[b, :ol_ref[b]]).max()) for b in range(B))
+    print("config 4 (cfgB, B=64 ragged): max |probs - oracle| = %.3g" % err)
+    assert err < 1e-4
+    # decoder parity on identical probabilities, every clip
+    tok, ln, sc = _compare_beams(native, probs, out_lens.numpy(), lm, 1.2, 0.15, 128, range(B), n_check=8)
+    # end to end: the surface's beams are those beams, in the caller's order
+    for pos, i in enumerate(order):
+        assert beams[pos][0] == "".join(LABELS[c] for c in tok[i, 0, :ln[i, 0]])
+    # and the oracle pipeline (its own probabilities) agrees on the best beam wherever its top-2 score gap is clear
+    scorer = ob.Scorer(1.2, 0.15, lm, LABELS)
+    clear = same = 0
+    for b in range(0, B, 4):
+        ref = ob.ctc_beam_search(p_ref[b, :ol_ref[b]].astype(np.float64), LABELS, 128, scorer=scorer)
+        if len(ref) > 1 and abs(ref[1][0] - ref[0][0]) > 1e-2:
+            clear += 1
+            same += int("".join(LABELS[c] for c in ref[0][1]) == "".join(LABELS[c] for c in tok[b, 0, :ln[b, 0]]))
+    assert clear >= 4 and same == clear, (clear, same)
+
+
+def test_config5_share_cfgA_batch128_30s_pipelined_kernel(native, tmp_path):
+    """B = 128 x 30 s: eight 16-clip tiles per direction on 200 CUs -> two tile groups x 4 tiles per workgroup,
+    the software-pipelined kernel.  Oracle on 6 sampled clips (as their own batches: the reference's batch
+    invariance is <= 1.2e-8), batch invariance of the GPU path on all 128."""
+    from oracle import torch_port as tp
+    cfg = _cfg(800, 5)
+    sd = syn.make_state_dict(2, "gru", 800, 5, seed=0, **syn.TALKATIVE)
+    B = 128
+    clips = _ragged_clips(B, 240000, 480000, seed=5)
+    m, fe, feat, frames, probs, out_lens = _gpu_pipeline(native, cfg, sd, clips)
+    assert int(frames.max()) == 3001 and int(out_lens.max()) == 1501
+    pn = probs.cpu().numpy()
+    sample = [0, 17, 31, 64, 100, 127]
+    worst = 0.0
+    for b in sample:
+        x1, f1 = tp.spectrogram_batch([clips[b]])
+        p1, o1 = tp.forward(sd, cfg, x1, f1)
+        assert o1[0] == out_lens[b]
+        worst = max(worst, float(np.abs(pn[b, :o1[0]] - p1[0]).max()))
+    print("config 5 share (cfgA, B=128 x 30 s): max |probs - oracle| over %d sampled clips = %.3g" % (len(sample), worst))
+    assert worst < 1e-4
+    # batch invariance: the same clips in four batches of 32 (the single-tile kernel) give the same probabilities
+    for k in range(0, B, 32):
+        sub = clips[k:k + 32]
+        n = np.array([len(c) for c in sub], dtype=np.int64)
+        f2, fr2 = fe.features(torch.from_numpy(np.concatenate(sub)).cuda(), n)
+        p2, o2 = m.forward(f2, fr2)
+        p2 = p2.cpu().numpy()
+        for j in range(32):
+            np.testing.assert_allclose(p2[j, :o2[j]], pn[k + j, :o2[j]], rtol=0, atol=3e-6)
+    # beam 64 + 3-gram on the long clips: decoder parity on a sample
+    lm = str(tmp_path / "syn3.arpa")
+    syn.make_arpa(lm, order=3, n_words=5000, seed=11, ngrams_per_order=20000)
+    _compare_beams(native, probs, out_lens, lm, 1.3, 0.2, 64, [0, 63, 127], n_check=5)
+    m.close(); fe.close()

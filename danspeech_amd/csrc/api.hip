@@ -69,7 +69,22 @@ static void timer_resolve(dsmi_model* m) {
 //    the device's PCI bus id, so HIP_VISIBLE_DEVICES remapping does not matter); a process that cannot get it runs
 //    its recurrent layers on the per-step path.  DSMI_PERSIST_SHARED=1 skips the lock (one process per GPU is
 //    guaranteed by the caller).
-struct PersistGate { std::mutex mu; hipEvent_t ev = nullptr; int lock_fd = -1; bool lock_tried = false; };
+//  * DSMI_PERSIST_LANES=2 splits the device into two halves: a persistent kernel whose grid fits half of the CUs
+//    takes ONE lane (handle-affine), so the recurrent layers of two batches in flight (two handles on two streams)
+//    run side by side; a kernel that needs more takes every lane.
+constexpr int kMaxLanes = 2;
+struct PersistGate { std::mutex mu; hipEvent_t ev[kMaxLanes] = {nullptr, nullptr}; int lock_fd = -1; bool lock_tried = false; int next_lane = 0; };
+
+// Under g->mu: make stream `s` wait for the lanes this launch needs ...
+static void gate_wait(PersistGate* g, hipStream_t s, int lane, bool all) {
+    for (int i = 0; i < kMaxLanes; ++i)
+        if ((all || i == lane) && g->ev[i]) (void)hipStreamWaitEvent(s, g->ev[i], 0);
+}
+// ... and publish the launch on them.
+static void gate_record(PersistGate* g, hipStream_t s, int lane, bool all) {
+    for (int i = 0; i < kMaxLanes; ++i)
+        if ((all || i == lane) && g->ev[i]) (void)hipEventRecord(g->ev[i], s);
+}
 static PersistGate* persist_gate(int device) {
     static std::mutex mu;
     static std::map<int, PersistGate*> gates;
@@ -77,7 +92,8 @@ static PersistGate* persist_gate(int device) {
     auto it = gates.find(device);
     if (it != gates.end()) return it->second;
     PersistGate* g = new PersistGate();
-    if (hipEventCreateWithFlags(&g->ev, hipEventDisableTiming) != hipSuccess) g->ev = nullptr;
+    for (int i = 0; i < kMaxLanes; ++i)
+        if (hipEventCreateWithFlags(&g->ev[i], hipEventDisableTiming) != hipSuccess) g->ev[i] = nullptr;
     gates[device] = g;
     return g;
 }
@@ -157,6 +173,13 @@ extern "C" int dsmi_model_create(const dsmi_model_desc* d, int device, dsmi_mode
         if (const char* sl = std::getenv("DSMI_DEBUG_SPIN_LIMIT")) m->spin_limit = (unsigned)std::max(1L, std::atol(sl));
         if (const char* ds = std::getenv("DSMI_DEBUG_DROP_SIGNAL"))
             if (std::sscanf(ds, "%d:%d:%d", &m->drop_layer, &m->drop_wg, &m->drop_step) != 3) m->drop_layer = -1;
+        const char* ln = std::getenv("DSMI_PERSIST_LANES");
+        m->lanes = (ln && std::atoi(ln) == 2) ? 2 : 1;
+        {
+            PersistGate* g = persist_gate(device);
+            std::lock_guard<std::mutex> lk(g->mu);
+            m->lane = g->next_lane++ % kMaxLanes;
+        }
         if (m->rnn_mode == 1 && !persist_process_lock(device)) {
             m->rnn_mode = 0;
             m->err = "another process holds this GPU's persistent-kernel lock: recurrent layers run one launch per step";
@@ -489,7 +512,7 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
     const double GH = (double)m->geom.G * m->desc.rnn_hidden_size, Dd = m->geom.D;
     int pgroups = 0;
     const bool use16 = m->rnn_mode == 1 && m->persist_gen == 2 && m->gemm_mode == 1 && m->have16 && gl.w_sp &&
-                       rnn_persist16_eligible(m->geom16, B, m->n_cus, &pgroups);
+                       rnn_persist16_eligible(m->geom16, B, m->n_cus / m->lanes, &pgroups);
     if (use16) {      // the second-generation kernel reads the x-projection in its own column order
         gl.w_sp = m->rnn[l].wih16_sp; gl.bias = m->rnn[l].bih16; gl.N = m->geom16.Np; gl.ldc = m->geom16.Np;
     }
@@ -511,9 +534,9 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
         {
             PersistGate* gate = persist_gate(m->device);
             std::lock_guard<std::mutex> lk(gate->mu);       // wait -> launch -> record is atomic against other host threads
-            if (gate->ev) (void)hipStreamWaitEvent(s, gate->ev, 0);
+            gate_wait(gate, s, m->lane, m->lanes == 1);
             ok = launch_rnn_persist16(pl, s);
-            if (gate->ev) (void)hipEventRecord(gate->ev, s);
+            gate_record(gate, s, m->lane, m->lanes == 1);
         }
         if (ok) return;
         // (not reachable for eligible shapes; the x-projection is in the other column order, so redo it)
@@ -534,7 +557,7 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
         const int ny = m->geom.nwg * m->geom.D <= m->n_cus ? m->geom.D : 1;
         PersistGate* gate = persist_gate(m->device);
         std::lock_guard<std::mutex> lk(gate->mu);
-        if (gate->ev) (void)hipStreamWaitEvent(s, gate->ev, 0);
+        gate_wait(gate, s, 0, true);                   // the first-generation kernel is sized for the whole device
         bool ok = true;
         for (int d0 = 0; d0 < m->geom.D && ok; d0 += ny) {
             const double part = (double)ny;
@@ -543,7 +566,7 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
                               4.0 * part * (GH * m->desc.rnn_hidden_size + (double)To * B * (GH + 2.0 * m->desc.rnn_hidden_size)));
             ok = launch_rnn_persist(pl, s);
         }
-        if (gate->ev) (void)hipEventRecord(gate->ev, s);
+        gate_record(gate, s, 0, true);
         if (ok) return;
     }
     RnnStepLaunch st;

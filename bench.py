@@ -96,9 +96,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle run (and with it the parity check)")
     ap.add_argument("--no-public-surface", action="store_true")
     ap.add_argument("--no-kernel-sampling", action="store_true")
-    ap.add_argument("--pipeline", type=int, default=1,
-                    help="batches in flight per GPU: each has its own handle set and HIP stream, so the conv/GEMM "
-                         "kernels of batch i+1 overlap the latency-bound recurrent chain of batch i")
+    ap.add_argument("--pipeline", type=int, default=2,
+                    help="batches in flight per GPU (default 2): each has its own handle set and HIP stream; the recurrent "
+                         "layers of the two batches share every CU (half-CU persistent workgroups, one gate lane each) and "
+                         "the conv/GEMM kernels of one batch run in the waits of the other's recurrent chain")
     args = ap.parse_args()
 
     import torch

@@ -59,10 +59,10 @@ class _StreamingSession(object):
 
 class _BatchJob(object):
     """One batch between enqueue and decode."""
-    __slots__ = ("order", "probs", "sizes", "count")
+    __slots__ = ("order", "probs", "sizes", "count", "model")
 
-    def __init__(self, order, probs, sizes, count):
-        self.order, self.probs, self.sizes, self.count = order, probs, sizes, count
+    def __init__(self, order, probs, sizes, count, model):
+        self.order, self.probs, self.sizes, self.count, self.model = order, probs, sizes, count, model
 
 
 class DanSpeechRecognizer(object):
@@ -77,6 +77,7 @@ class DanSpeechRecognizer(object):
         self.model = self.model_name = self.labels = self.audio_config = self.audio_parser = None
         self._session = None
         self._side_streams = {}
+        self._replica = None
         if model_name:
             self.update_model(model_name)
         if lm_name:
@@ -93,6 +94,7 @@ class DanSpeechRecognizer(object):
         self.audio_config = model.audio_conf
         self.model = model.to(self.device)
         self.model.eval()
+        self._replica = None
         self.audio_parser = SpectrogramAudioParser(self.audio_config, device=self._device_index())
         # a new model may bring a new alphabet: the decoder follows
         self.update_decoder(labels=self.model.labels)
@@ -128,18 +130,19 @@ class DanSpeechRecognizer(object):
             self._side_streams[key] = torch.cuda.Stream(device=key[1])
         return self._side_streams[key]
 
-    def _enqueue_batch(self, recordings):
+    def _enqueue_batch(self, recordings, model=None, parser=None):
         """Stage + upload + spectrograms + forward of one batch, all asynchronous.  Clips run longest first
         (pack_padded_sequence's order, reference model.py:117)."""
         import torch
+        model = model or self.model
         order = np.argsort([-len(r) for r in recordings], kind="stable")
-        feats, frames = self.audio_parser.parse_batch([recordings[i] for i in order])
-        probs, sizes = self.model.enqueue(feats, torch.from_numpy(frames.astype(np.int32)))
-        return _BatchJob(order, probs, sizes, len(recordings))
+        feats, frames = (parser or self.audio_parser).parse_batch([recordings[i] for i in order])
+        probs, sizes = model.enqueue(feats, torch.from_numpy(frames.astype(np.int32)))
+        return _BatchJob(order, probs, sizes, len(recordings), model)
 
     def _finish_batch(self, job, show_all, warn=True):
         import torch
-        self.model.collect()                     # waits for the forward; a timed-out batch has been recomputed by now
+        job.model.collect()                      # waits for the forward; a timed-out batch has been recomputed by now
         side = self._side_stream("decode")
         job.probs.record_stream(side)
         with torch.cuda.stream(side):
@@ -158,12 +161,25 @@ class DanSpeechRecognizer(object):
         return self._finish_batch(self._enqueue_batch(recordings), show_all)
 
     def transcribe_batches(self, batches, show_all=False):
-        """Generator over ``transcribe_batch(b)`` for every ``b`` of ``batches``, software-pipelined: while the GPU
-        computes batch i, the host stages and uploads batch i+1 (pinned double buffer, copy stream) and the decoder
-        of batch i-1 runs on a side stream.  Results come out in order, one list per batch."""
-        waiting = None
+        """Generator over ``transcribe_batch(b)`` for every ``b`` of ``batches``, software-pipelined with TWO batches in
+        flight: batch i+1 is staged, uploaded (pinned double buffer, copy stream) and enqueued on the model's replica
+        -- its own stream and workspaces -- while batch i computes, so the latency-bound recurrent layers of the two
+        batches share the CUs and the dense kernels of one fill the other's waits; the decoder of a finished batch runs
+        on a side stream.  Results come out in order, one list per batch."""
+        import torch
+        if self._replica is None and hasattr(self.model, "replica"):
+            # the second batch in flight has its own model handle AND its own parser (frontend scratch, staging buffers)
+            self._replica = (self.model.replica(), SpectrogramAudioParser(self.audio_config, device=self._device_index()))
+        handles = [self.model, self._replica[0] if self._replica else self.model]
+        parsers = [self.audio_parser, self._replica[1] if self._replica else self.audio_parser]
+        streams = [torch.cuda.current_stream(self._device_index()), self._side_stream("second batch")]
+        waiting, turn = None, 0
         for recordings in batches:
-            job = self._enqueue_batch(recordings) if len(recordings) else None
+            job = None
+            if len(recordings):
+                with torch.cuda.stream(streams[turn]):
+                    job = self._enqueue_batch(recordings, handles[turn], parsers[turn])
+                turn ^= 1
             if waiting is not None:
                 yield self._finish_batch(waiting, show_all) if waiting != "empty" else []
             waiting = job if job is not None else "empty"

@@ -173,8 +173,10 @@ extern "C" int dsmi_model_create(const dsmi_model_desc* d, int device, dsmi_mode
         if (const char* sl = std::getenv("DSMI_DEBUG_SPIN_LIMIT")) m->spin_limit = (unsigned)std::max(1L, std::atol(sl));
         if (const char* ds = std::getenv("DSMI_DEBUG_DROP_SIGNAL"))
             if (std::sscanf(ds, "%d:%d:%d", &m->drop_layer, &m->drop_wg, &m->drop_step) != 3) m->drop_layer = -1;
-        const char* ln = std::getenv("DSMI_PERSIST_LANES");
-        m->lanes = (ln && std::atoi(ln) == 2) ? 2 : 1;
+        const char* ln = std::getenv("DSMI_PERSIST_LANES");     // default 2: two batches in flight share the CUs; 1: whole-device kernels only
+        m->lanes = (ln && std::atoi(ln) == 1) ? 1 : 2;
+        const char* pw = std::getenv("DSMI_PERSIST_WAVES");     // 4 / 8 forces the workgroup size of rnn_persist16
+        m->persist_waves = pw ? (std::atoi(pw) == 4 ? 4 : 8) : (m->lanes == 2 ? 4 : 8);
         {
             PersistGate* g = persist_gate(device);
             std::lock_guard<std::mutex> lk(g->mu);
@@ -510,9 +512,13 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
     double sumlen = 0;
     for (int i = 0; i < B; ++i) sumlen += m->host_out_lens[i];
     const double GH = (double)m->geom.G * m->desc.rnn_hidden_size, Dd = m->geom.D;
-    int pgroups = 0;
-    const bool use16 = m->rnn_mode == 1 && m->persist_gen == 2 && m->gemm_mode == 1 && m->have16 && gl.w_sp &&
-                       rnn_persist16_eligible(m->geom16, B, m->n_cus / m->lanes, &pgroups);
+    int pgroups = 0, waves = 8;
+    bool use16 = m->rnn_mode == 1 && m->persist_gen == 2 && m->gemm_mode == 1 && m->have16 && gl.w_sp;
+    if (use16) {
+        // half-CU workgroups when two batches may be in flight (DSMI_PERSIST_LANES=2), else one workgroup per CU
+        if (m->persist_waves == 4 && rnn_persist16_half_eligible(m->geom16, B, m->n_cus, &pgroups)) waves = 4;
+        else use16 = rnn_persist16_eligible(m->geom16, B, m->n_cus, &pgroups);
+    }
     if (use16) {      // the second-generation kernel reads the x-projection in its own column order
         gl.w_sp = m->rnn[l].wih16_sp; gl.bias = m->rnn[l].bih16; gl.N = m->geom16.Np; gl.ldc = m->geom16.Np;
     }
@@ -524,7 +530,7 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
         pl.g = m->geom16;
         for (int dd = 0; dd < 2; ++dd) { pl.whh16[dd] = m->rnn[l].whh16_sp[dd]; pl.bhh[dd] = m->rnn[l].bhh[dd]; pl.out[dd] = m->hbuf[dst][dd]; }
         pl.xp = m->xp; pl.lens_dev = m->lens_dev; pl.hpack16 = m->hpack16; pl.counters = m->pcnt; pl.err = m->perr;
-        pl.B = B; pl.T = To; pl.pgroups = pgroups;
+        pl.B = B; pl.T = To; pl.pgroups = pgroups; pl.waves = waves;
         pl.spin_limit = m->spin_limit;
         if (m->drop_layer == l) { pl.drop_wg = m->drop_wg; pl.drop_step = m->drop_step; }
         (void)hipMemsetAsync(m->pcnt, 0, sizeof(unsigned) * (size_t)m->geom.D * ceil_div(B, 16) * To * kPersist16CntWords, s);
@@ -534,9 +540,10 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
         {
             PersistGate* gate = persist_gate(m->device);
             std::lock_guard<std::mutex> lk(gate->mu);       // wait -> launch -> record is atomic against other host threads
-            gate_wait(gate, s, m->lane, m->lanes == 1);
+            const bool whole = !(waves == 4 && m->lanes == 2);     // a half-CU kernel takes one lane, anything else the device
+            gate_wait(gate, s, m->lane, whole);
             ok = launch_rnn_persist16(pl, s);
-            gate_record(gate, s, m->lane, m->lanes == 1);
+            gate_record(gate, s, m->lane, whole);
         }
         if (ok) return;
         // (not reachable for eligible shapes; the x-projection is in the other column order, so redo it)

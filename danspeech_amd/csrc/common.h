@@ -159,7 +159,8 @@ struct RnnPersist16Launch {
     const int32_t* lens_dev; uint16_t* hpack16;     // rnn_persist16_state_halfs(g, B) fp16 values
     unsigned* counters;          // [D * ceil(B/16)][T][kPersist16CntWords], zeroed before the launch
     unsigned* err;
-    int B, T, pgroups;           // pgroups from rnn_persist16_eligible
+    int B, T, pgroups;           // pgroups from rnn_persist16_eligible / rnn_persist16_half_eligible
+    int waves = 8;               // 8: one workgroup per CU; 4: the half-CU variant (two batches in flight share every CU)
     unsigned spin_limit = kPersistSpinLimit;
     int drop_wg = -1, drop_step = -1;    // test hook: see DSMI_DEBUG_DROP_SIGNAL in api.hip
     EvPair ev;
@@ -168,6 +169,7 @@ struct RnnPersist16Launch {
 constexpr int kPersist16Shards = 4;                        // shards of the hand-off counter of a (chain, step) ...
 constexpr int kPersist16CntWords = kPersist16Shards * 64;   // ... each on its own 256-byte line
 bool rnn_persist16_eligible(const RnnGeom& g16, int B, int n_cus, int* pgroups_out);
+bool rnn_persist16_half_eligible(const RnnGeom& g16, int B, int n_cus, int* pgroups_out);
 std::vector<uint16_t> pack_whh16(const RnnGeom& g16, const float* w_hh);
 size_t rnn_persist16_state_halfs(const RnnGeom& g16, int B);
 bool launch_rnn_persist16(const RnnPersist16Launch& p, hipStream_t s);

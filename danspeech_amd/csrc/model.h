@@ -86,6 +86,7 @@ struct dsmi_model {
     int recomputed = 0;            // forwards recomputed on the per-step path so far
     unsigned spin_limit = dsmi::kPersistSpinLimit;   // DSMI_DEBUG_SPIN_LIMIT
     int drop_layer = -1, drop_wg = -1, drop_step = -1;   // DSMI_DEBUG_DROP_SIGNAL=layer:workgroup:step (tests: force a timeout)
+    int persist_waves = 8;         // waves per workgroup of rnn_persist16 (4: half-CU workgroups)
     int lanes = 1, lane = 0;       // DSMI_PERSIST_LANES: persistent kernels of this handle take 1/lanes of the CUs, on this lane
     int persist_lock_fd = -1;      // this process holds the device's persistent-kernel lock file
     // pinned staging of the per-batch lengths (pageable memory must not back an async copy)

@@ -25,13 +25,15 @@ namespace dsmi {
 
 namespace {
 
-constexpr int QNW = 8;                 // waves per workgroup (K-split)
+constexpr int QNW = 8;                 // waves per workgroup (K-split) of the full-CU variants
 constexpr int QNT = QNW * 64;
+constexpr int QNKR4 = 6;               // four-wave variant: k-blocks of W_hh a wave keeps in registers; a seventh sits in LDS
 constexpr int QU = 16;                 // hidden units per workgroup
 constexpr int QB = 16;                 // clips per batch tile
 constexpr int QRP = 20;                // row pitch (words) of the reduce buffer: conflict-free for the MFMA-layout writes
 constexpr int QMAXZ = 8;               // batch tiles one workgroup can walk
 constexpr size_t Q_LDS = 82 * 1024;    // > half of the CU's LDS: one workgroup per CU
+constexpr size_t Q_LDS_HALF = 78 * 1024;   // four-wave variant: at most two workgroups per CU (its 256 registers per wave allow no third)
 constexpr size_t Q_LDS_PIPE = 112 * 1024;   // pipelined variant: two reduce buffers
 
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
@@ -64,18 +66,25 @@ struct P16Args {
 __device__ __forceinline__ float qsigmoid(float v) { return __frcp_rn(1.f + __expf(-v)); }
 __device__ __forceinline__ float qtanh(float v) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * v)); }
 
-// KIND: cell type; NKW: compile-time bound of the 32-wide k-blocks one wave owns.
-template <int KIND, int NKW, bool STAMP = false>
-__global__ __launch_bounds__(QNT) void rnn_persist16_kernel(P16Args p) {
+// KIND: cell type; NKW: compile-time bound of the 32-wide k-blocks one wave owns; NWV: waves per workgroup.
+// NWV = 8: one workgroup per CU (two waves per SIMD, <= 256 registers each).
+// NWV = 4: HALF a CU per workgroup -- one wave per SIMD, <= 256 registers, so that the recurrent layers of TWO batches in
+// flight (two handles, two streams, one gate lane each: api.hip) share every CU: a step is ~3 us of hand-off latency around
+// ~1 us of work, and a second, independent chain on the same CU runs in the other one's shadow.  A wave then owns up to 7
+// k-blocks of W_hh: six in registers, the seventh in LDS (read per MFMA, 1 KiB per wave instruction).
+template <int KIND, int NKW, int NWV, bool STAMP = false>
+__global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void rnn_persist16_kernel(P16Args p) {
     unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long tlast = STAMP ? __builtin_amdgcn_s_memrealtime() : 0;
     constexpr int NG = KIND == DSMI_RNN_GRU ? 3 : (KIND == DSMI_RNN_LSTM ? 4 : 1);
     extern __shared__ __attribute__((aligned(16))) float qlds[];
-    float* red = qlds;                                               // [QNW][NG][16 units][QRP]
-    int& s_dead = *reinterpret_cast<int*>(red + QNW * 4 * 16 * QRP);
-    float* st_h = red + QNW * 4 * 16 * QRP + 32;                    // [QMAXZ][256] carried state when a workgroup walks several tiles
+    constexpr int NKR = NWV == 4 ? (NKW < QNKR4 ? NKW : QNKR4) : NKW;   // k-blocks of W_hh in registers; the rest in LDS
+    float* red = qlds;                                               // [NWV][NG][16 units][QRP]
+    int& s_dead = *reinterpret_cast<int*>(red + NWV * 4 * 16 * QRP);
+    float* st_h = red + NWV * 4 * 16 * QRP + 32;                    // [QMAXZ][256] carried state when a workgroup walks several tiles
     float* st_c = st_h + QMAXZ * 256;
     int* st_len = reinterpret_cast<int*>(st_c + QMAXZ * 256);
+    u32x4* wlds = reinterpret_cast<u32x4*>(st_len + QMAXZ * 256);    // [NWV][NKW - NKR][NG][2 planes][64 lanes] 16-byte fragments
     const int tid = threadIdx.x, lane = tid & 63;
     const int v = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ln = lane & 15, lg = lane >> 4;                        // MFMA lane roles: column / row index, k-group / row-group
@@ -88,8 +97,9 @@ __global__ __launch_bounds__(QNT) void rnn_persist16_kernel(P16Args p) {
     if (tid == 0) s_dead = 0;
 
     // ---- resident operand: this wave's k-blocks of the split W_hh, all gates
-    const int kb0 = (v * p.nkb) / QNW, kb1 = ((v + 1) * p.nkb) / QNW;
-    f16x8 wv[NKW][NG][2];
+    const int kb0 = (v * p.nkb) / NWV, kb1 = ((v + 1) * p.nkb) / NWV;
+    f16x8 wv[NKR][NG][2];
+    u32x4* wl = wlds + (size_t)v * (NKW - NKR) * NG * 2 * 64 + lane;
     {
         const u32x4* wp = reinterpret_cast<const u32x4*>(p.whh[d]) + ((size_t)w * p.nkb) * (NG * 2 * 64) + lane;
 #pragma unroll
@@ -98,7 +108,11 @@ __global__ __launch_bounds__(QNT) void rnn_persist16_kernel(P16Args p) {
 #pragma unroll
             for (int g = 0; g < NG; ++g)
 #pragma unroll
-                for (int pl = 0; pl < 2; ++pl) wv[i][g][pl] = __builtin_bit_cast(f16x8, wp[(((size_t)kb * NG + g) * 2 + pl) * 64]);
+                for (int pl = 0; pl < 2; ++pl) {
+                    const u32x4 frag = wp[(((size_t)kb * NG + g) * 2 + pl) * 64];
+                    if (i < NKR) wv[i < NKR ? i : 0][g][pl] = __builtin_bit_cast(f16x8, frag);
+                    else wl[(((i - NKR) * NG + g) * 2 + pl) * 64] = frag;       // read back by this same lane only
+                }
         }
     }
     const size_t hp_par = (size_t)p.D * p.ntiles * p.nkb * 2048;     // bytes per parity
@@ -189,12 +203,19 @@ __global__ __launch_bounds__(QNT) void rnn_persist16_kernel(P16Args p) {
 #pragma unroll
                 for (int i = 0; i < NKW; ++i) {
                     if (kb0 + i < kb1) {
+                        f16x8 wa[NG][2];
 #pragma unroll
-                        for (int g = 0; g < NG; ++g) acl[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[i][g][1], hv[i][0], acl[g], 0, 0, 0);
+                        for (int g = 0; g < NG; ++g)
 #pragma unroll
-                        for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[i][g][0], hv[i][0], acc[g], 0, 0, 0);
+                            for (int pl = 0; pl < 2; ++pl)
+                                wa[g][pl] = i < NKR ? wv[i < NKR ? i : 0][g][pl]
+                                                    : __builtin_bit_cast(f16x8, wl[(((i - NKR) * NG + g) * 2 + pl) * 64]);
 #pragma unroll
-                        for (int g = 0; g < NG; ++g) acl[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[i][g][0], hv[i][1], acl[g], 0, 0, 0);
+                        for (int g = 0; g < NG; ++g) acl[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[g][1], hv[i][0], acl[g], 0, 0, 0);
+#pragma unroll
+                        for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[g][0], hv[i][0], acc[g], 0, 0, 0);
+#pragma unroll
+                        for (int g = 0; g < NG; ++g) acl[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[g][0], hv[i][1], acl[g], 0, 0, 0);
                     }
                 }
             }
@@ -218,7 +239,7 @@ __global__ __launch_bounds__(QNT) void rnn_persist16_kernel(P16Args p) {
                     for (int g = 0; g < NG; ++g) {
                         float sum = 0.f;
 #pragma unroll
-                        for (int k = 0; k < QNW; ++k) sum += red[((k * 4 + g) * 16 + cu) * QRP + cj];
+                        for (int k = 0; k < NWV; ++k) sum += red[((k * 4 + g) * 16 + cu) * QRP + cj];
                         hg[g] = sum + bh[g];
                     }
                     if (KIND == DSMI_RNN_GRU) {
@@ -485,19 +506,30 @@ inline uint16_t q_f16_bits(_Float16 h) {
 }
 
 template <int KIND>
-bool launch16(const P16Args& a, hipStream_t s, const EvPair& ev) {
-    const int nkw = ceil_div(a.nkb, QNW);
-    const dim3 grid(a.nwg, a.D * a.pgroups, 1), block(QNT);
-#define LAUNCH_Q(N)                                                                                                  \
+bool launch16(const P16Args& a, hipStream_t s, const EvPair& ev, int waves) {
+    const dim3 grid(a.nwg, a.D * a.pgroups, 1);
+#define LAUNCH_Q(N, W, LDS)                                                                                          \
     do {                                                                                                             \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rnn_persist16_kernel<KIND, N>),                       \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)Q_LDS);                            \
-        DSMI_LAUNCH((rnn_persist16_kernel<KIND, N>), grid, block, Q_LDS, s, ev, a);                                   \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rnn_persist16_kernel<KIND, N, W>),                    \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS));                            \
+        DSMI_LAUNCH((rnn_persist16_kernel<KIND, N, W>), grid, dim3(W * 64), LDS, s, ev, a);                           \
     } while (0)
+    if (waves == 4) {              // half-CU workgroups (see the kernel): one or two tiles per workgroup, no diagnostics build
+        const int nkw = ceil_div(a.nkb, 4);
+        if (a.dbg || ceil_div(a.ntiles, a.pgroups) > 2) return false;
+        if (nkw <= 2) LAUNCH_Q(2, 4, Q_LDS_HALF);
+        else if (nkw <= 4) LAUNCH_Q(4, 4, Q_LDS_HALF);
+        else if (nkw <= 6 && KIND != DSMI_RNN_LSTM) LAUNCH_Q(6, 4, Q_LDS_HALF);
+        else if (nkw <= 7 && KIND != DSMI_RNN_LSTM) LAUNCH_Q(7, 4, Q_LDS_HALF);
+        else return false;
+        return true;
+    }
+    const int nkw = ceil_div(a.nkb, QNW);
+    const dim3 block(QNT);
     if (a.dbg) {
         if (nkw > 4) return false;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rnn_persist16_kernel<KIND, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Q_LDS);
-        hipLaunchKernelGGL((rnn_persist16_kernel<KIND, 4, true>), grid, block, Q_LDS, s, a);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rnn_persist16_kernel<KIND, 4, QNW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Q_LDS);
+        hipLaunchKernelGGL((rnn_persist16_kernel<KIND, 4, QNW, true>), grid, block, Q_LDS, s, a);
         return true;
     }
     if (ceil_div(a.ntiles, a.pgroups) > 2) {      // three or more tiles per workgroup: the software-pipelined kernel (with two
@@ -515,9 +547,9 @@ bool launch16(const P16Args& a, hipStream_t s, const EvPair& ev) {
 #undef LAUNCH_QP
         return true;
     }
-    if (nkw <= 2) LAUNCH_Q(2);
-    else if (nkw <= 4) LAUNCH_Q(4);
-    else if (nkw <= 5 && KIND != DSMI_RNN_LSTM) LAUNCH_Q(5);
+    if (nkw <= 2) LAUNCH_Q(2, QNW, Q_LDS);
+    else if (nkw <= 4) LAUNCH_Q(4, QNW, Q_LDS);
+    else if (nkw <= 5 && KIND != DSMI_RNN_LSTM) LAUNCH_Q(5, QNW, Q_LDS);
     else return false;
 #undef LAUNCH_Q
     return true;
@@ -543,6 +575,20 @@ bool rnn_persist16_eligible(const RnnGeom& g16, int B, int n_cus, int* pgroups_o
     const int ntiles = ceil_div(B, QB);
     const int pg = std::min(ntiles, n_cus / (g16.nwg * g16.D));
     if (ceil_div(ntiles, pg) > QMAXZ) return false;
+    if (pgroups_out) *pgroups_out = pg;
+    return true;
+}
+
+// The half-CU (four-wave) variant: its register budget holds 6 + 1 k-blocks per wave for three gates (H <= 896), 4 for an
+// LSTM (H <= 512); at most two tiles per workgroup; one workgroup slot per CU and lane.
+bool rnn_persist16_half_eligible(const RnnGeom& g16, int B, int n_cus, int* pgroups_out) {
+    if (g16.U != QU || (g16.H % QU) != 0) return false;
+    const int nkw = ceil_div(ceil_div(g16.H, 32), 4);
+    if (nkw > (g16.kind == DSMI_RNN_LSTM ? 4 : 7)) return false;
+    if (g16.nwg * g16.D > n_cus) return false;
+    const int ntiles = ceil_div(B, QB);
+    const int pg = std::min(ntiles, n_cus / (g16.nwg * g16.D));
+    if (ceil_div(ntiles, pg) > 2) return false;
     if (pgroups_out) *pgroups_out = pg;
     return true;
 }
@@ -583,9 +629,9 @@ bool launch_rnn_persist16(const RnnPersist16Launch& p, hipStream_t s) {
     a.ntiles = ceil_div(p.B, QB); a.pgroups = p.pgroups; a.D = p.g.D; a.dbg = p.dbg;
     a.spin_limit = p.spin_limit; a.drop_wg = p.drop_wg; a.drop_step = p.drop_step;
     switch (p.g.kind) {
-        case DSMI_RNN_GRU: return launch16<DSMI_RNN_GRU>(a, s, p.ev);
-        case DSMI_RNN_LSTM: return launch16<DSMI_RNN_LSTM>(a, s, p.ev);
-        default: return launch16<DSMI_RNN_TANH>(a, s, p.ev);
+        case DSMI_RNN_GRU: return launch16<DSMI_RNN_GRU>(a, s, p.ev, p.waves);
+        case DSMI_RNN_LSTM: return launch16<DSMI_RNN_LSTM>(a, s, p.ev, p.waves);
+        default: return launch16<DSMI_RNN_TANH>(a, s, p.ev, p.waves);
     }
 }
 

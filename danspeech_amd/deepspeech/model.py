@@ -155,6 +155,16 @@ class DeepSpeech(object):
         """Wait for the oldest ``enqueue`` and validate it (``dsmi_forward_status``)."""
         return self._native.status()
 
+    def replica(self):
+        """A second handle on the same weights and device (own workspaces): a caller that keeps two batches in flight
+        alternates between the model and its replica, so that the recurrent layers of the two batches share the CUs
+        (half-CU persistent workgroups, one gate lane per handle: csrc/rnn_persist16.hip, csrc/api.hip)."""
+        other = DeepSpeech(self.model_name, rnn_type=self.rnn_type, labels=self.labels, rnn_hidden_size=self.rnn_hidden_size,
+                           rnn_layers=self.rnn_layers, audio_conf=self.audio_conf, bidirectional=self.bidirectional,
+                           context=self.context, conv_layers=self.conv_layers)
+        other._state = self._state
+        return other.to(self.device)
+
     def streaming_forward(self, x, is_first, is_last):
         """model.py:517-537: one chunk [1,1,F,T] of the streaming parser's output -> probs [1,T_out,C], or None
         on the first pass (the lookahead is still buffering).  Conv context, recurrent state and lookahead

@@ -185,3 +185,34 @@ def test_tiny_weights_and_saturating_gates(native, kind):
     y = m1.rnn_layer(1, _dev(x1), l1).cpu().numpy()
     np.testing.assert_allclose(y, om.batch_rnn(sd1, 1, kind, x1, l1, True, True), rtol=0, atol=5e-6)
     m.close(); m1.close()
+
+
+@pytest.mark.parametrize("waves", ["4", "8"])
+def test_two_batches_in_flight_on_two_handles(native, waves):
+    """Two handles, two streams, forwards enqueued back to back without waiting: with the half-CU workgroups (waves = 4)
+    the persistent kernels of the two batches are co-resident on the same CUs (one gate lane each); with whole-CU
+    workgroups (waves = 8) the gate chains them.  Either way both batches must equal the oracle, repeatedly."""
+    from oracle import torch_port as tp
+    cfg = _cfg(800, 2)
+    sd = syn.make_state_dict(2, "gru", 800, 2, seed=31, **syn.TALKATIVE)
+    with _env(DSMI_PERSIST_WAVES=waves):
+        models = [native.NativeModel(cfg, sd) for _ in range(2)]
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    batches = [_batch(B=32, T=301, seed=40), _batch(B=20, T=257, seed=41)]
+    refs = [tp.forward(sd, cfg, x, lens)[0] for x, lens in batches]
+    xs = [_dev(x) for x, _ in batches]
+    torch.cuda.synchronize()
+    for rep in range(3):
+        outs = []
+        for k in range(2):
+            with torch.cuda.stream(streams[k]):
+                outs.append(models[k].forward(xs[k], batches[k][1], check=False))
+        for k in range(2):
+            assert models[k].status() is False
+            p, ol = outs[k]
+            pn = p.cpu().numpy()
+            for b in range(pn.shape[0]):
+                np.testing.assert_allclose(pn[b, :ol[b]], refs[k][b, :ol[b]], rtol=0, atol=1e-4)
+    for m in models:
+        assert m.recompute_count() == 0
+        m.close()

@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="cfgA-greedy", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default: the config's 32)")
+    ap.add_argument("--hidden", type=int, default=None, help="experiments: another hidden size (the JSON line then names it)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle run (and with it the parity check)")
     ap.add_argument("--no-public-surface", action="store_true")
     ap.add_argument("--no-kernel-sampling", action="store_true")
@@ -117,7 +118,9 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
-    c = CONFIGS[args.config]
+    c = dict(CONFIGS[args.config])
+    if args.hidden:
+        c["rnn_hidden_size"] = args.hidden
     B = args.batch or c["batch"]
     n_samples = int(c["seconds"] * 16000)
     cfg = {k: c[k] for k in ("conv_layers", "rnn_type", "rnn_hidden_size", "rnn_layers", "bidirectional", "context")}
@@ -240,8 +243,8 @@ def main():
             "value": round(value, 2), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32 (two-term fp16 split operands, 3 MFMA products, fp32 accumulate)", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: 2conv + 5xBiGRU800 (DanSpeechPrimary per BASELINE), greedy CTC, "
-                                   "batch=%d x %.0f s 16 kHz clips per GPU, STFT+forward+decode" % (B, c["seconds"]),
+            "config": {"workload": "BASELINE.json configs[1]: 2conv + 5xBiGRU%d (DanSpeechPrimary per BASELINE), greedy CTC, "
+                                   "batch=%d x %.0f s 16 kHz clips per GPU, STFT+forward+decode" % (c["rnn_hidden_size"], B, c["seconds"]),
                        "clips_per_gpu": B, "clip_seconds": c["seconds"], "parallelism": "utterance-dp%d" % world,
                        "batches_in_flight": P},
             "roofline": roof,
@@ -284,17 +287,32 @@ def cpu_baseline_and_parity(cfg, sd, B, n_samples, labels, last, gpu_strings):
     from danspeech_amd import synthetic as syn
     from oracle import torch_port as tp, decoder as od
     cores, cpu_model = physical_cores()
-    torch.set_num_threads(cores)
     clips = [syn.make_clip(i, n_samples) for i in range(B)]
-    tp.forward(sd, cfg, *tp.spectrogram_batch(clips[:1]))          # thread pool + oneDNN primitive warm-up
+    # torch's CPU recurrent path is many small GEMMs per step: more threads than it can use make it SLOWER (128 threads: 17
+    # audio-s/s, 8 vCPUs: 50).  Calibrate on a short sample of the same batch shape and time the full batch at the best count.
+    probe = [c[:32000] for c in clips]
+    xq, fq = tp.spectrogram_batch(probe)
+    best, threads = None, cores
+    for cand in sorted({c for c in (8, 16, 32, 64, cores) if c <= cores}):
+        torch.set_num_threads(cand)
+        tp.forward(sd, cfg, xq[:2], fq[:2])                        # thread pool + oneDNN primitive warm-up
+        tq = time.perf_counter()
+        tp.forward(sd, cfg, xq, fq)
+        tq = time.perf_counter() - tq
+        if best is None or tq < best:
+            best, threads = tq, cand
+    torch.set_num_threads(threads)
+    tp.forward(sd, cfg, xq[:2], fq[:2])
     t0 = time.perf_counter()
     x, fr = tp.spectrogram_batch(clips)
     probs, out_lens = tp.forward(sd, cfg, x, fr)
     strings, _ = od.greedy_decode(probs, out_lens, labels, 0)
     dt = time.perf_counter() - t0
-    base = {"value": round(B * n_samples / 16000.0 / dt, 2), "unit": "audio-s/s", "cores": cores, "kind": "port", "cpu": cpu_model,
-            "sample": "one batch of %d x %.0f s clips through oracle/torch_port.py (F.conv2d / aten::gru / F.linear on %d threads) "
-                      "+ numpy STFT + greedy decode, %.1f s wall" % (B, n_samples / 16000.0, cores, dt)}
+    base = {"value": round(B * n_samples / 16000.0 / dt, 2), "unit": "audio-s/s", "cores": threads, "kind": "port", "cpu": cpu_model,
+            "host_physical_cores": cores,
+            "sample": "one batch of %d x %.0f s clips through oracle/torch_port.py (F.conv2d / aten::gru / F.linear on %d threads, the "
+                      "fastest of 8/16/32/64/%d on a 2 s probe of the same batch) + numpy STFT + greedy decode, %.1f s wall"
+                      % (B, n_samples / 16000.0, threads, cores, dt)}
     pg = last["probs"].cpu().numpy()
     err = max(float(np.abs(pg[b, :out_lens[b]] - probs[b, :out_lens[b]]).max()) for b in range(B))
     same = sum(int(g == s[0]) for g, s in zip(gpu_strings, strings))

@@ -540,7 +540,8 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
         {
             PersistGate* gate = persist_gate(m->device);
             std::lock_guard<std::mutex> lk(gate->mu);       // wait -> launch -> record is atomic against other host threads
-            const bool whole = !(waves == 4 && m->lanes == 2);     // a half-CU kernel takes one lane, anything else the device
+            static const bool force_lane = std::getenv("DSMI_PERSIST_FORCE_LANE") != nullptr;     // experiments only
+            const bool whole = !((waves == 4 || force_lane) && m->lanes == 2);     // a half-CU kernel takes one lane, anything else the device
             gate_wait(gate, s, m->lane, whole);
             ok = launch_rnn_persist16(pl, s);
             gate_record(gate, s, m->lane, whole);

@@ -97,6 +97,13 @@ _PROTOS = {
     "dsmi_debug_persist_stamps": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int64]),
     "dsmi_debug_step_stamps": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int64]),
     "dsmi_last_forward_stats": (C.c_int, [_vp, _i64p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "dsmi_lm_open": (C.c_int, [C.c_char_p, C.POINTER(_vp)]),
+    "dsmi_lm_close": (None, [_vp]),
+    "dsmi_lm_last_error": (C.c_char_p, [_vp]),
+    "dsmi_lm_info": (C.c_int, [_vp, C.POINTER(C.c_int), _i64p, C.POINTER(C.c_int)]),
+    "dsmi_lm_word_index": (C.c_int, [_vp, C.c_char_p]),
+    "dsmi_lm_lookup": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "dsmi_lm_cond_log10": (C.c_double, [_vp, _vp, C.c_int]),
 }
 
 
@@ -509,3 +516,45 @@ class NativeDecoder:
                                     int(cutoff_top_n), float(cutoff_prob), _np_ptr(tok), _np_ptr(ts), _np_ptr(ln),
                                     _np_ptr(sc), _stream(self.device)))
         return tok, ts, ln, sc
+
+
+class NativeLM:
+    """Host-only view of a language-model file through libdsmi.so's reader (``dsmi_lm_*``): no GPU needed."""
+    KINDS = {0: "arpa", 1: "klm-probing", 2: "klm-trie"}
+
+    def __init__(self, path):
+        h = _vp()
+        rc = lib().dsmi_lm_open(str(path).encode(), C.byref(h))
+        if rc != 0:
+            raise DsmiError(rc, (lib().dsmi_lm_last_error(None) or b"").decode())
+        self._h = h
+        o = C.c_int(); v = C.c_int64(); k = C.c_int()
+        lib().dsmi_lm_info(self._h, C.byref(o), C.byref(v), C.byref(k))
+        self.order, self.vocab_size, self.kind = o.value, v.value, self.KINDS[k.value]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().dsmi_lm_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def word_index(self, word):
+        return int(lib().dsmi_lm_word_index(self._h, word.encode("utf-8")))
+
+    def lookup(self, ids):
+        """(log10 prob, log10 backoff) of the n-gram, or None."""
+        a = np.ascontiguousarray(ids, dtype=np.int32)
+        lp = C.c_float(); bo = C.c_float()
+        rc = lib().dsmi_lm_lookup(self._h, _np_ptr(a), len(a), C.byref(lp), C.byref(bo))
+        if rc < 0:
+            raise DsmiError(rc, "bad n-gram")
+        return (lp.value, bo.value) if rc == 1 else None
+
+    def cond_log10(self, ids):
+        a = np.ascontiguousarray(ids, dtype=np.int32)
+        return float(lib().dsmi_lm_cond_log10(self._h, _np_ptr(a), len(a)))

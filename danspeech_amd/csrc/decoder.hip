@@ -21,6 +21,7 @@
 #include "common.h"
 #include "lm.h"
 #include "lm.cpp.inc"
+#include "lm_klm.cpp.inc"
 
 #include <algorithm>
 #include <cmath>
@@ -49,7 +50,7 @@ static_assert(sizeof(Node) == 64, "Node must be one 64-byte line");
 struct BeamArgs {
     const float* probs; const int32_t* sizes; int T, C, blank, space, beam, cutoff_top_n; float cutoff_prob;
     int has_lm, order; double alpha, beta;
-    const LmEntry* lm_tab; uint64_t lm_mask; const int32_t* trie_next; const int32_t* trie_word; int unk, bos;
+    LmView lm; const int32_t* trie_next; const int32_t* trie_word; int unk, bos;
     int ncap;                    // per-utterance node pool capacity
     Node* nodes; int32_t* childtab; int32_t* nnodes;
     // outputs
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(BT) void beam_kernel(BeamArgs a) {
                         float l10;
                         if (memo != MEMO_UNSET) l10 = __int_as_float(memo);
                         else {
-                            l10 = lm_cond_log10(a.lm_tab, a.lm_mask, nodes[pn].ctx, NCTX, arc, a.unk);
+                            l10 = lm_cond_log10(a.lm, nodes[pn].ctx, NCTX, arc, a.unk);
                             nodes[pn].memo = __float_as_int(l10);
                         }
                         lm = (double)l10 / (double)kLog10E;
@@ -444,7 +445,7 @@ __global__ __launch_bounds__(BT) void beam_kernel(BeamArgs a) {
                 if (n != 0 && ech[i] != a.space) {
                     const int w = a.trie_word[nodes[n].dstate];
                     double lm = kOovScore;
-                    if (w >= 0) lm = (double)lm_cond_log10(a.lm_tab, a.lm_mask, nodes[n].ctx, NCTX, w, a.unk) / (double)kLog10E;
+                    if (w >= 0) lm = (double)lm_cond_log10(a.lm, nodes[n].ctx, NCTX, w, a.unk) / (double)kLog10E;
                     double s = lm * a.alpha;
                     s += a.beta;
                     score[i] += s;
@@ -486,6 +487,7 @@ struct dsmi_decoder {
     HostLM lm;
     double alpha = 0, beta = 0;
     LmEntry* d_tab = nullptr; int32_t *d_next = nullptr, *d_word = nullptr;
+    unsigned char* d_klm = nullptr;      // device copy of a KenLM probing binary's search memory
     // beam workspace
     size_t ws_bytes = 0;
     unsigned char* ws = nullptr;
@@ -518,7 +520,8 @@ static void free_lm(dsmi_decoder* d) {
     if (d->d_tab) (void)hipFree(d->d_tab);
     if (d->d_next) (void)hipFree(d->d_next);
     if (d->d_word) (void)hipFree(d->d_word);
-    d->d_tab = nullptr; d->d_next = nullptr; d->d_word = nullptr;
+    if (d->d_klm) (void)hipFree(d->d_klm);
+    d->d_tab = nullptr; d->d_next = nullptr; d->d_word = nullptr; d->d_klm = nullptr;
     d->has_lm = false;
     d->lm = HostLM();
 }
@@ -541,9 +544,13 @@ extern "C" int dsmi_decoder_set_lm(dsmi_decoder* d, const char* path, double alp
     free_lm(d);
     d->alpha = alpha; d->beta = beta;
     if (!path || !*path) return DSMI_OK;
-    const std::string msg = d->lm.load_arpa(path, d->labels);
+    const std::string msg = d->lm.load(path, d->labels);         // ARPA text or KenLM binary (probing / trie)
     if (!msg.empty()) { d->lm = HostLM(); d->err = msg; return DSMI_ERR_IO; }
     if (d->lm.order > kMaxOrder) { d->err = "n-gram order above 6 is not supported"; d->lm = HostLM(); return DSMI_ERR_IO; }
+    if (d->lm.kind == 1) {
+        DEC_HIP(d, hipMalloc((void**)&d->d_klm, d->lm.klm_blob.size()));
+        DEC_HIP(d, hipMemcpy(d->d_klm, d->lm.klm_blob.data(), d->lm.klm_blob.size(), hipMemcpyHostToDevice));
+    }
     DEC_HIP(d, hipMalloc((void**)&d->d_tab, sizeof(LmEntry) * d->lm.table.size()));
     DEC_HIP(d, hipMalloc((void**)&d->d_next, sizeof(int32_t) * d->lm.trie_next.size()));
     DEC_HIP(d, hipMalloc((void**)&d->d_word, sizeof(int32_t) * d->lm.trie_word.size()));
@@ -617,7 +624,7 @@ extern "C" int dsmi_beam(dsmi_decoder* d, const float* probs, const int32_t* siz
     a.probs = probs; a.T = To; a.C = C; a.blank = d->blank; a.space = d->space; a.beam = beam;
     a.cutoff_top_n = cutoff_top_n; a.cutoff_prob = (float)cutoff_prob;
     a.has_lm = d->has_lm ? 1 : 0; a.order = d->has_lm ? d->lm.order : 1; a.alpha = d->alpha; a.beta = d->beta;
-    a.lm_tab = d->d_tab; a.lm_mask = d->lm.mask; a.trie_next = d->d_next; a.trie_word = d->d_word; a.unk = d->lm.unk; a.bos = d->lm.bos;
+    a.lm = d->lm.view(); a.lm.tab = d->d_tab; a.lm.klm.base = d->d_klm; a.trie_next = d->d_next; a.trie_word = d->d_word; a.unk = d->lm.unk; a.bos = d->lm.bos;
     a.ncap = ncap;
     a.nodes = (Node*)(w + o_nodes); a.childtab = (int32_t*)(w + o_child); a.nnodes = (int32_t*)(w + o_nn);
     a.out_tok = (int32_t*)(w + o_tok); a.out_step = (int32_t*)(w + o_step); a.out_len = (int32_t*)(w + o_len); a.out_n = (int32_t*)(w + o_n);
@@ -670,4 +677,46 @@ extern "C" int dsmi_beam(dsmi_decoder* d, const float* probs, const int32_t* siz
             scores[q] = (float)-approx;
         }
     return DSMI_OK;
+}
+
+
+// ---- host-only view of a language model file (no GPU needed): lets callers and the CPU tests inspect what
+// dsmi_decoder_set_lm would load.  See include/dsmi.h.
+struct dsmi_lm { dsmi::HostLM lm; std::string err; };
+static thread_local std::string g_lm_error;
+
+extern "C" int dsmi_lm_open(const char* path, dsmi_lm** out) {
+    if (!path || !out) { g_lm_error = "null argument"; return DSMI_ERR_INVALID; }
+    dsmi_lm* h = new dsmi_lm();
+    const std::string msg = h->lm.load(path, std::vector<std::string>());
+    if (!msg.empty()) { g_lm_error = msg; delete h; return DSMI_ERR_IO; }
+    *out = h;
+    return DSMI_OK;
+}
+extern "C" void dsmi_lm_close(dsmi_lm* h) { delete h; }
+extern "C" const char* dsmi_lm_last_error(const dsmi_lm* h) { return h ? h->err.c_str() : g_lm_error.c_str(); }
+extern "C" int dsmi_lm_info(const dsmi_lm* h, int* order, int64_t* vocab_size, int* kind) {
+    if (!h) return DSMI_ERR_INVALID;
+    if (order) *order = h->lm.order;
+    if (vocab_size) *vocab_size = (int64_t)h->lm.vocab.size();
+    if (kind) *kind = h->lm.kind;
+    return DSMI_OK;
+}
+extern "C" int dsmi_lm_word_index(const dsmi_lm* h, const char* word_utf8) {
+    if (!h || !word_utf8) return DSMI_ERR_INVALID;
+    auto it = h->lm.word2id.find(word_utf8);
+    return it == h->lm.word2id.end() ? -1 : it->second;
+}
+extern "C" int dsmi_lm_lookup(const dsmi_lm* h, const int32_t* ids, int n, float* log10_prob, float* log10_backoff) {
+    if (!h || !ids || n < 1 || n > h->lm.order) return DSMI_ERR_INVALID;
+    for (int i = 0; i < n; ++i) if (ids[i] < 0 || ids[i] >= (int32_t)h->lm.vocab.size()) return DSMI_ERR_INVALID;
+    float lp = 0.f, bo = 0.f;
+    const bool found = dsmi::lm_lookup(h->lm.view(), ids, n, &lp, &bo);
+    if (log10_prob) *log10_prob = lp;
+    if (log10_backoff) *log10_backoff = bo;
+    return found ? 1 : 0;
+}
+extern "C" double dsmi_lm_cond_log10(const dsmi_lm* h, const int32_t* ids, int n) {
+    if (!h || !ids || n < 1 || n > h->lm.order) return 0.0 / 0.0;
+    return (double)dsmi::lm_cond_log10(h->lm.view(), ids, n - 1, ids[n - 1], h->lm.unk);
 }

@@ -2,9 +2,12 @@
 
 Every factory returns the *path* of a language model file in the cache
 (``~/.danspeech/lms/<file>``), exactly what the reference hands to
-``Recognizer.update_decoder(lm=...)`` (reference dsl_3gram.py:7-20).  The decoder in this
-package accepts ARPA text files and its own ``.dsmilm`` binary; KenLM ``.klm`` binaries are
-read through ``danspeech_amd.lm`` when their format variant is supported.
+``Recognizer.update_decoder(lm=...)`` (reference dsl_3gram.py:7-20).  ``dsmi_decoder_set_lm``
+(csrc/decoder.hip) tells the file type by its first bytes and reads KenLM binaries
+(``.klm``: data structures ``probing`` -- build_binary's default -- and ``trie``, unquantised;
+csrc/lm_klm.cpp.inc) as well as ARPA text; the quantised / array-compressed trie variants are
+refused by name.  No ``.klm`` is obtainable offline, so the reader is checked against a
+restatement of KenLM's layout (oracle/klm.py), not against KenLM's own files.
 """
 from ..utils.data_utils import get_model
 

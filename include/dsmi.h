@@ -237,7 +237,9 @@ int dsmi_last_forward_stats(const dsmi_model* m, int64_t* n_step_launches, doubl
 /* ---- BeamCTCDecoder (decoder.py:91-144): what ctcdecode.CTCBeamDecoder(labels, lm_path, alpha,
  * beta, cutoff_top_n, cutoff_prob, beam_width, num_processes, blank_index).decode(probs, sizes)
  * does for the reference (third-party, not in the reference tree; restated in oracle/beam.py).
- * dsmi_decoder_set_lm: lm_path = ARPA text n-gram model (order <= 6) or NULL/"" for none.
+ * dsmi_decoder_set_lm: lm_path = an n-gram model of order <= 6 -- a KenLM binary (.klm, what the reference's
+ * language_models.* factories return, danspeech/language_models/dsl_3gram.py:16-20: data structures `probing` and
+ * `trie`, unquantised) or ARPA text -- or NULL/"" for none; the file type is told by its first bytes.
  * dsmi_beam outputs, all host: tokens/tsteps [B][beam][T_out] int32 (token ids and the frame
  * of each token's strongest emission), lens [B][beam], scores [B][beam] (ctcdecode's
  * "-approx_ctc", lower is better; beams are ordered best first).  Synchronises. */
@@ -245,6 +247,20 @@ int dsmi_decoder_set_lm(dsmi_decoder* d, const char* lm_path, double alpha, doub
 int dsmi_beam(dsmi_decoder* d, const float* probs_dev, const int32_t* sizes_host, int B, int T_out,
               int beam_width, int cutoff_top_n, double cutoff_prob, int32_t* tokens_host,
               int32_t* tsteps_host, int32_t* lens_host, float* scores_host, void* stream);
+
+/* ---- Host-only view of a language model file (no GPU involved): what dsmi_decoder_set_lm would load.
+ * kind: 0 ARPA text, 1 KenLM probing binary, 2 KenLM trie binary.  Word ids are the file's own (KenLM's WordIndex for
+ * binaries, <unk> = 0).  dsmi_lm_lookup: 1 = the n-gram ids[0..n) is in the model (its log10 probability and back-off
+ * weight are returned), 0 = absent.  dsmi_lm_cond_log10 = log10 p(ids[n-1] | ids[0..n-1)) by back-off, the quantity the
+ * beam search's scorer adds (ctcdecode Scorer::get_log_cond_prob / KenLM BaseScore). */
+typedef struct dsmi_lm dsmi_lm;
+int dsmi_lm_open(const char* path, dsmi_lm** out);
+void dsmi_lm_close(dsmi_lm* lm);
+const char* dsmi_lm_last_error(const dsmi_lm* lm);
+int dsmi_lm_info(const dsmi_lm* lm, int* order, int64_t* vocab_size, int* kind);
+int dsmi_lm_word_index(const dsmi_lm* lm, const char* word_utf8);
+int dsmi_lm_lookup(const dsmi_lm* lm, const int32_t* ids, int n, float* log10_prob, float* log10_backoff);
+double dsmi_lm_cond_log10(const dsmi_lm* lm, const int32_t* ids, int n);
 
 #ifdef __cplusplus
 }

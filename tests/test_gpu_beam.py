@@ -105,6 +105,36 @@ def test_beam_cutoff_prob_with_lm_and_long_utterance(native, tmp_path):
              cutoff_top_n=15, cutoff_prob=0.98, n_check=24)
 
 
+@pytest.mark.parametrize("order,beam", [(3, 64), (5, 128)])
+def test_beam_with_kenlm_binaries_equals_arpa(native, tmp_path, order, beam):
+    """The same model as ARPA text, as a KenLM probing binary (looked up in place on the GPU with KenLM's own hash
+    chain) and as a KenLM trie binary (converted at load time): identical beams, timesteps and scores.  Binaries from
+    oracle/klm.py's writer (parity with KenLM's own files is unpinned, tests/test_klm.py)."""
+    from oracle import klm
+    labels = syn.DANSPEECH_LABELS
+    arpa = str(tmp_path / "lm.arpa")
+    syn.make_arpa(arpa, order=order, n_words=400, seed=30 + order, ngrams_per_order=1500)
+    rng = np.random.default_rng(11 + order)
+    probs = _dev(_peaky_probs(rng, 3, 120, len(labels), sharp=2.0))
+    sizes = np.array([120, 97, 40], dtype=np.int32)
+    outs = {}
+    for name, mt in (("arpa", None), ("probing", klm.PROBING), ("trie", klm.TRIE)):
+        path = arpa
+        if mt is not None:
+            path = str(tmp_path / ("lm_%s.klm" % name))
+            klm.write_klm(arpa, path, mt)
+        dec = native.NativeDecoder(labels, blank_index=0)
+        dec.set_lm(path, 1.3, 0.2)
+        outs[name] = dec.beam(probs, sizes, beam_width=beam)
+        dec.close()
+    # and the oracle on the ARPA text
+    _compare(native, probs.cpu().numpy(), sizes, labels, beam=beam, lm_path=arpa, alpha=1.3, beta=0.2, n_check=20)
+    for name in ("probing", "trie"):
+        for a, b in zip(outs["arpa"], outs[name]):
+            assert np.array_equal(a, b), name
+    assert (outs["arpa"][2][:, 0] > 3).all()
+
+
 def test_lm_file_errors(native, tmp_path):
     dec = native.NativeDecoder(syn.DANSPEECH_LABELS, blank_index=0)
     with pytest.raises(native.DsmiError):

@@ -129,6 +129,8 @@ def main():
                              bidirectional=cfg["bidirectional"], seed=0, **syn.TALKATIVE)
     P = max(1, args.pipeline)
     models = [_native.NativeModel(cfg, sd, device=local, n_labels=len(labels)) for _ in range(P)]
+    for mdl in models:
+        mdl.set_inflight(P)
     frontends = [_native.NativeFrontend(device=local) for _ in range(P)]
     decoders = [_native.NativeDecoder(labels, blank_index=0, device=local) for _ in range(P)]
     streams = [torch.cuda.Stream(device=local) for _ in range(P)] if P > 1 else [torch.cuda.current_stream()]

@@ -171,6 +171,9 @@ class DanSpeechRecognizer(object):
             # the second batch in flight has its own model handle AND its own parser (frontend scratch, staging buffers)
             self._replica = (self.model.replica(), SpectrogramAudioParser(self.audio_config, device=self._device_index()))
         handles = [self.model, self._replica[0] if self._replica else self.model]
+        for h in handles:
+            if hasattr(h, "set_inflight"):
+                h.set_inflight(2)
         parsers = [self.audio_parser, self._replica[1] if self._replica else self.audio_parser]
         streams = [torch.cuda.current_stream(self._device_index()), self._side_stream("second batch")]
         waiting, turn = None, 0
@@ -185,6 +188,8 @@ class DanSpeechRecognizer(object):
             waiting = job if job is not None else "empty"
         if waiting is not None:
             yield self._finish_batch(waiting, show_all) if waiting != "empty" else []
+        if hasattr(self.model, "set_inflight"):
+            self.model.set_inflight(1)
 
     def transcribe_device(self, pcm, n_samples, show_all=False):
         """Clips that already sit back to back in GPU memory (int16 / float32 / float64, longest first), e.g. a

@@ -87,6 +87,7 @@ _PROTOS = {
     "dsmi_forward": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     "dsmi_forward_status": (C.c_int, [_vp]),
     "dsmi_recompute_count": (C.c_int, [_vp]),
+    "dsmi_model_set_inflight": (C.c_int, [_vp, C.c_int]),
     "dsmi_conv_stack": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
     "dsmi_rnn_layer": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
     "dsmi_greedy": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
@@ -237,6 +238,11 @@ class NativeModel:
 
     def recompute_count(self):
         return int(lib().dsmi_recompute_count(self._h))
+
+    def set_inflight(self, batches):
+        """How many batches the caller keeps in flight on this device (one handle + stream each): 2 selects the
+        throughput variant of the recurrent kernel."""
+        self._check(lib().dsmi_model_set_inflight(self._h, int(batches)))
 
     def conv_stack(self, feat, lens):
         import torch

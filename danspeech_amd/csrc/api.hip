@@ -158,6 +158,8 @@ extern "C" int dsmi_model_create(const dsmi_model_desc* d, int device, dsmi_mode
     m->Hs = m->geom.Kp;
     m->geom16 = make_rnn_geom_u(d->rnn_type, d->rnn_hidden_size, d->bidirectional ? 2 : 1, 16);
     m->have16 = d->rnn_hidden_size % 16 == 0;
+    m->geom32 = make_rnn_geom_u(d->rnn_type, d->rnn_hidden_size, d->bidirectional ? 2 : 1, 32);
+    m->have32 = rnn_persist32_eligible(m->geom32, 16, 1 << 20, nullptr);      // the shape fits the kernel at all
     m->rnn.resize(d->rnn_layers);
     {
         hipDeviceProp_t prop;
@@ -175,6 +177,8 @@ extern "C" int dsmi_model_create(const dsmi_model_desc* d, int device, dsmi_mode
             if (std::sscanf(ds, "%d:%d:%d", &m->drop_layer, &m->drop_wg, &m->drop_step) != 3) m->drop_layer = -1;
         const char* ln = std::getenv("DSMI_PERSIST_LANES");     // default 2: two batches in flight share the CUs; 1: whole-device kernels only
         m->lanes = (ln && std::atoi(ln) == 1) ? 1 : 2;
+        const char* pu = std::getenv("DSMI_PERSIST_UNITS");     // 32: the 32-unit kernel when two batches are in flight (measured slower: DESIGN.md 4)
+        m->persist_units = pu ? std::atoi(pu) : 0;
         const char* pw = std::getenv("DSMI_PERSIST_WAVES");     // 4 / 8 forces the workgroup size of rnn_persist16
         m->persist_waves = pw ? (std::atoi(pw) == 4 ? 4 : 8) : (m->lanes == 2 ? 4 : 8);
         {
@@ -313,6 +317,21 @@ extern "C" int dsmi_model_finalize(dsmi_model* m) {
             for (int dd = 0; dd < g.D; ++dd)
                 if ((rc = upload(m, pack_whh16(g16, wh[dd]->data.data()), &r.whh16_sp[dd]))) return rc;
         }
+        if (m->have32) {
+            const RnnGeom& g32 = m->geom32;
+            std::vector<float> w32((size_t)g32.Np * r.ldw, 0.f), b32(g32.Np, 0.f);
+            for (int col = 0; col < g32.Np; ++col) {
+                int dd;
+                const int src = rnn_src_row(g32, col, &dd);
+                if (src < 0) continue;
+                std::memcpy(&w32[(size_t)col * r.ldw], &wi[dd]->data[(size_t)src * I], sizeof(float) * I);
+                b32[col] = bi[dd]->data[src];
+            }
+            if ((rc = upload(m, pack_gemm_w_split(w32.data(), g32.Np, r.K, r.ldw), &r.wih32_sp))) return rc;
+            if ((rc = upload(m, b32, &r.bih32))) return rc;
+            for (int dd = 0; dd < g.D; ++dd)
+                if ((rc = upload(m, pack_whh32(g32, wh[dd]->data.data()), &r.whh32_sp[dd]))) return rc;
+        }
         if (l > 0) {  // model.py:403-404: BatchNorm1d(H) in front of layers >= 1
             std::vector<float> a, b;
             if (!bn_affine(m, "rnns." + std::to_string(l) + ".batch_norm.module", H, m->Hs, a, b)) return DSMI_ERR_NOT_READY;
@@ -392,7 +411,7 @@ extern "C" int dsmi_reserve(dsmi_model* m, int max_B, int max_T) {
         if ((rc = ws_alloc(m, &m->conv_buf_sp[i], n))) return rc;
     }
     const size_t rows = (size_t)To * max_B;
-    if ((rc = ws_alloc(m, &m->xp, rows * std::max(m->geom.Np, m->have16 ? m->geom16.Np : 0)))) return rc;
+    if ((rc = ws_alloc(m, &m->xp, rows * std::max(std::max(m->geom.Np, m->have16 ? m->geom16.Np : 0), m->have32 ? m->geom32.Np : 0)))) return rc;
     for (int i = 0; i < 2; ++i)
         for (int dd = 0; dd < 2; ++dd) {
             m->hbuf[i][dd] = nullptr;
@@ -418,7 +437,7 @@ extern "C" int dsmi_reserve(dsmi_model* m, int max_B, int max_T) {
         const size_t kt = (size_t)ceil_div(std::max(m->I0, m->Hs), 32);
         if ((rc = ws_alloc(m, &m->a_sp, mt * kt * 2 * 4096))) return rc;
     }
-    if (m->have16) {
+    if (m->have16 || m->have32) {
         const size_t n = rnn_persist16_state_halfs(m->geom16, max_B);
         if ((rc = ws_alloc(m, &m->hpack16, n))) return rc;
         HIP_OK(m, hipMemset(m->hpack16, 0, n * sizeof(uint16_t)));
@@ -514,12 +533,18 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
     const double GH = (double)m->geom.G * m->desc.rnn_hidden_size, Dd = m->geom.D;
     int pgroups = 0, waves = 8;
     bool use16 = m->rnn_mode == 1 && m->persist_gen == 2 && m->gemm_mode == 1 && m->have16 && gl.w_sp;
-    if (use16) {
+    // Two batches in flight (dsmi_model_set_inflight(m, 2)): the 32-unit kernel on the CUs of ONE lane, so that the two
+    // batches' recurrent layers run on disjoint halves of the chip.
+    const bool use32 = use16 && m->lanes == 2 && m->inflight >= 2 && m->have32 && m->persist_units == 32 &&
+                       rnn_persist32_eligible(m->geom32, B, m->n_cus / 2, &pgroups);
+    if (use16 && !use32) {
         // half-CU workgroups when two batches may be in flight (DSMI_PERSIST_LANES=2), else one workgroup per CU
         if (m->persist_waves == 4 && rnn_persist16_half_eligible(m->geom16, B, m->n_cus, &pgroups)) waves = 4;
         else use16 = rnn_persist16_eligible(m->geom16, B, m->n_cus, &pgroups);
     }
-    if (use16) {      // the second-generation kernel reads the x-projection in its own column order
+    if (use32) {
+        gl.w_sp = m->rnn[l].wih32_sp; gl.bias = m->rnn[l].bih32; gl.N = m->geom32.Np; gl.ldc = m->geom32.Np;
+    } else if (use16) {      // the second-generation kernel reads the x-projection in its own column order
         gl.w_sp = m->rnn[l].wih16_sp; gl.bias = m->rnn[l].bih16; gl.N = m->geom16.Np; gl.ldc = m->geom16.Np;
     }
     gl.ev = timer_arm(m, gl.mode == GEMM_A_CONV ? KK_GEMM0 : KK_GEMM, true, 2.0 * Dd * GH * gl.K * sumlen,
@@ -527,8 +552,11 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
     launch_gemm(gl, s);
     if (use16) {
         RnnPersist16Launch pl;
-        pl.g = m->geom16;
-        for (int dd = 0; dd < 2; ++dd) { pl.whh16[dd] = m->rnn[l].whh16_sp[dd]; pl.bhh[dd] = m->rnn[l].bhh[dd]; pl.out[dd] = m->hbuf[dst][dd]; }
+        pl.g = use32 ? m->geom32 : m->geom16;
+        for (int dd = 0; dd < 2; ++dd) {
+            pl.whh16[dd] = use32 ? m->rnn[l].whh32_sp[dd] : m->rnn[l].whh16_sp[dd];
+            pl.bhh[dd] = m->rnn[l].bhh[dd]; pl.out[dd] = m->hbuf[dst][dd];
+        }
         pl.xp = m->xp; pl.lens_dev = m->lens_dev; pl.hpack16 = m->hpack16; pl.counters = m->pcnt; pl.err = m->perr;
         pl.B = B; pl.T = To; pl.pgroups = pgroups; pl.waves = waves;
         pl.spin_limit = m->spin_limit;
@@ -541,9 +569,9 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
             PersistGate* gate = persist_gate(m->device);
             std::lock_guard<std::mutex> lk(gate->mu);       // wait -> launch -> record is atomic against other host threads
             static const bool force_lane = std::getenv("DSMI_PERSIST_FORCE_LANE") != nullptr;     // experiments only
-            const bool whole = !((waves == 4 || force_lane) && m->lanes == 2);     // a half-CU kernel takes one lane, anything else the device
+            const bool whole = !((waves == 4 || use32 || force_lane) && m->lanes == 2);     // a half-CU / half-chip kernel takes one lane, anything else the device
             gate_wait(gate, s, m->lane, whole);
-            ok = launch_rnn_persist16(pl, s);
+            ok = use32 ? launch_rnn_persist32(pl, s) : launch_rnn_persist16(pl, s);
             gate_record(gate, s, m->lane, whole);
         }
         if (ok) return;
@@ -854,6 +882,12 @@ extern "C" int dsmi_rnn_layer(dsmi_model* m, int layer, const float* x, const in
 }
 
 extern "C" int dsmi_recompute_count(const dsmi_model* m) { return m ? m->recomputed : DSMI_ERR_INVALID; }
+
+extern "C" int dsmi_model_set_inflight(dsmi_model* m, int batches) {
+    if (!m || batches < 1) return DSMI_ERR_INVALID;
+    m->inflight = batches;
+    return DSMI_OK;
+}
 
 extern "C" int dsmi_set_profiling(dsmi_model* m, int level) {
     if (!m) return DSMI_ERR_INVALID;

@@ -174,6 +174,12 @@ std::vector<uint16_t> pack_whh16(const RnnGeom& g16, const float* w_hh);
 size_t rnn_persist16_state_halfs(const RnnGeom& g16, int B);
 bool launch_rnn_persist16(const RnnPersist16Launch& p, hipStream_t s);
 
+// rnn_persist32.hip: throughput variant -- 32 units per workgroup, one workgroup per CU, a 32-clip batch on 100 CUs (cfgA);
+// takes a RnnPersist16Launch whose geometry is make_rnn_geom_u(kind, H, D, 32) and whose whh16 point at pack_whh32 images.
+bool rnn_persist32_eligible(const RnnGeom& g32, int B, int n_cus, int* pgroups_out);
+std::vector<uint16_t> pack_whh32(const RnnGeom& g32, const float* w_hh);
+bool launch_rnn_persist32(const RnnPersist16Launch& p, hipStream_t s);
+
 // head.hip
 //   lookahead: y[t][b][h] = clip(sum_k w[h][k] * x[t+k][b][h], 0, 20)
 void launch_lookahead(const float* x, const float* w, float* y, int T, int B, int H, int context, hipStream_t s);

@@ -18,6 +18,8 @@ struct RnnW {
     float* bhh[2] = {nullptr, nullptr};  // torch layout [G*H]
     // the same x-projection weights permuted for the 16-unit geometry of rnn_persist16.hip (H % 16 == 0 only)
     uint16_t* wih16_sp = nullptr; float* bih16 = nullptr; uint16_t* whh16_sp[2] = {nullptr, nullptr};
+    // ... and for the 32-unit geometry of rnn_persist32.hip (H % 32 == 0 only)
+    uint16_t* wih32_sp = nullptr; float* bih32 = nullptr; uint16_t* whh32_sp[2] = {nullptr, nullptr};
     float* bn_a = nullptr;  // [Hs] BatchNorm1d in front of layers >= 1
     float* bn_b = nullptr;
     int K = 0, ldw = 0;
@@ -50,6 +52,9 @@ struct dsmi_model {
     dsmi::RnnGeom geom{};
     dsmi::RnnGeom geom16{};       // U = 16 geometry of the second-generation persistent kernel
     bool have16 = false;          // geom16 weights were packed (H % 16 == 0)
+    dsmi::RnnGeom geom32{};       // U = 32 geometry of the throughput variant (rnn_persist32.hip)
+    bool have32 = false;          // geom32 weights were packed (H % 32 == 0, shape within the kernel's register budget)
+    int inflight = 1;             // dsmi_model_set_inflight: batches the caller keeps in flight on this device (2: throughput variant)
 
     // weights (device)
     ConvW conv[3];
@@ -86,6 +91,7 @@ struct dsmi_model {
     int recomputed = 0;            // forwards recomputed on the per-step path so far
     unsigned spin_limit = dsmi::kPersistSpinLimit;   // DSMI_DEBUG_SPIN_LIMIT
     int drop_layer = -1, drop_wg = -1, drop_step = -1;   // DSMI_DEBUG_DROP_SIGNAL=layer:workgroup:step (tests: force a timeout)
+    int persist_units = 0;         // DSMI_PERSIST_UNITS (16: never the 32-unit kernel)
     int persist_waves = 8;         // waves per workgroup of rnn_persist16 (4: half-CU workgroups)
     int lanes = 1, lane = 0;       // DSMI_PERSIST_LANES: persistent kernels of this handle take 1/lanes of the CUs, on this lane
     int persist_lock_fd = -1;      // this process holds the device's persistent-kernel lock file

@@ -155,6 +155,11 @@ class DeepSpeech(object):
         """Wait for the oldest ``enqueue`` and validate it (``dsmi_forward_status``)."""
         return self._native.status()
 
+    def set_inflight(self, batches):
+        """Tell the kernels how many batches the caller keeps in flight on this device (``dsmi_model_set_inflight``)."""
+        if self._native is not None:
+            self._native.set_inflight(batches)
+
     def replica(self):
         """A second handle on the same weights and device (own workspaces): a caller that keeps two batches in flight
         alternates between the model and its replica, so that the recurrent layers of the two batches share the CUs

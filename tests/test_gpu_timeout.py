@@ -187,16 +187,20 @@ def test_tiny_weights_and_saturating_gates(native, kind):
     m.close(); m1.close()
 
 
-@pytest.mark.parametrize("waves", ["4", "8"])
+@pytest.mark.parametrize("waves", ["4", "8", "units32"])
 def test_two_batches_in_flight_on_two_handles(native, waves):
     """Two handles, two streams, forwards enqueued back to back without waiting: with the half-CU workgroups (waves = 4)
     the persistent kernels of the two batches are co-resident on the same CUs (one gate lane each); with whole-CU
-    workgroups (waves = 8) the gate chains them.  Either way both batches must equal the oracle, repeatedly."""
+    workgroups (waves = 8) the gate chains them; with set_inflight(2) the 32-unit kernel puts each batch on its own half
+    of the chip.  Either way both batches must equal the oracle, repeatedly."""
     from oracle import torch_port as tp
     cfg = _cfg(800, 2)
     sd = syn.make_state_dict(2, "gru", 800, 2, seed=31, **syn.TALKATIVE)
-    with _env(DSMI_PERSIST_WAVES=waves):
+    with _env(DSMI_PERSIST_WAVES="4" if waves == "units32" else waves):
         models = [native.NativeModel(cfg, sd) for _ in range(2)]
+    if waves == "units32":
+        for m in models:
+            m.set_inflight(2)
     streams = [torch.cuda.Stream() for _ in range(2)]
     batches = [_batch(B=32, T=301, seed=40), _batch(B=20, T=257, seed=41)]
     refs = [tp.forward(sd, cfg, x, lens)[0] for x, lens in batches]
@@ -216,3 +220,27 @@ def test_two_batches_in_flight_on_two_handles(native, waves):
     for m in models:
         assert m.recompute_count() == 0
         m.close()
+
+
+@pytest.mark.parametrize("kind,H,B", [("gru", 800, 32), ("gru", 64, 40), ("lstm", 512, 16), ("rnn", 96, 70), ("gru", 896, 24)])
+def test_throughput_variant_32_units_equals_oracle(native, kind, H, B):
+    """rnn_persist32 (selected by set_inflight(2)) on its own: all cell types, one tile / several tiles per workgroup,
+    the seven-k-block shape (H = 896: one k-block of W_hh in LDS), ragged lengths."""
+    from oracle import torch_port as tp
+    cfg = _cfg(H, 2, kind=kind)
+    sd = syn.make_state_dict(2, kind, H, 2, seed=51, **syn.TALKATIVE)
+    m = native.NativeModel(cfg, sd)
+    m.set_inflight(2)
+    x, lens = _batch(B=B, T=201, seed=52)
+    p, ol = m.forward(_dev(x), lens)
+    ref, ol_ref = tp.forward(sd, cfg, x, lens)
+    assert np.array_equal(ol, ol_ref) and m.recompute_count() == 0
+    pn = p.cpu().numpy()
+    for b in range(B):
+        np.testing.assert_allclose(pn[b, :ol[b]], ref[b, :ol[b]], rtol=0, atol=1e-4)
+    # and the same batch through the default (latency) variant: same probabilities up to summation order
+    m.set_inflight(1)
+    p1, _ = m.forward(_dev(x), lens)
+    for b in range(B):
+        np.testing.assert_allclose(p1.cpu().numpy()[b, :ol[b]], pn[b, :ol[b]], rtol=0, atol=5e-5)
+    m.close()

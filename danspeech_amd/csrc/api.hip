@@ -177,10 +177,12 @@ extern "C" int dsmi_model_create(const dsmi_model_desc* d, int device, dsmi_mode
             if (std::sscanf(ds, "%d:%d:%d", &m->drop_layer, &m->drop_wg, &m->drop_step) != 3) m->drop_layer = -1;
         const char* ln = std::getenv("DSMI_PERSIST_LANES");     // default 2: two batches in flight share the CUs; 1: whole-device kernels only
         m->lanes = (ln && std::atoi(ln) == 1) ? 1 : 2;
+        const char* pd = std::getenv("DSMI_PERSIST_DUO");       // 0: never the paired-tile kernel
+        m->persist_duo = pd ? (std::atoi(pd) == 0 ? 0 : 1) : -1;       // -1: by the number of batches in flight
         const char* pu = std::getenv("DSMI_PERSIST_UNITS");     // 32: the 32-unit kernel when two batches are in flight (measured slower: DESIGN.md 4)
         m->persist_units = pu ? std::atoi(pu) : 0;
         const char* pw = std::getenv("DSMI_PERSIST_WAVES");     // 4 / 8 forces the workgroup size of rnn_persist16
-        m->persist_waves = pw ? (std::atoi(pw) == 4 ? 4 : 8) : (m->lanes == 2 ? 4 : 8);
+        m->persist_waves = pw ? (std::atoi(pw) == 4 ? 4 : 8) : 0;       // 0: by the number of batches in flight
         {
             PersistGate* g = persist_gate(device);
             std::lock_guard<std::mutex> lk(g->mu);
@@ -537,9 +539,21 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
     // batches' recurrent layers run on disjoint halves of the chip.
     const bool use32 = use16 && m->lanes == 2 && m->inflight >= 2 && m->have32 && m->persist_units == 32 &&
                        rnn_persist32_eligible(m->geom32, B, m->n_cus / 2, &pgroups);
-    if (use16 && !use32) {
-        // half-CU workgroups when two batches may be in flight (DSMI_PERSIST_LANES=2), else one workgroup per CU
-        if (m->persist_waves == 4 && rnn_persist16_half_eligible(m->geom16, B, m->n_cus, &pgroups)) waves = 4;
+    // Which 16-unit kernel.  The caller says how many batches it keeps in flight (dsmi_model_set_inflight):
+    //   1 -> whole-CU workgroups on the whole device: the shortest step for a lone batch (2.7 us for cfgA at B = 32);
+    //   2 -> the paired-tile pipeline on ONE gate lane's CUs when the batch fits there (B = 17..32 for cfgA: 100 CUs), so that
+    //        the second batch's recurrent layer runs on the other half of the chip; failing that, half-CU workgroups (one lane,
+    //        the two batches share every CU); failing that, whole-CU workgroups (both lanes: the two batches take turns).
+    // DSMI_PERSIST_DUO / DSMI_PERSIST_WAVES force a variant (tests, experiments).
+    bool duo = false, duo_lane = false;
+    const bool want_duo = m->persist_duo >= 0 ? m->persist_duo == 1 : m->inflight >= 2;
+    const int want_waves = m->persist_waves ? m->persist_waves : (m->inflight >= 2 ? 4 : 8);
+    if (use16 && !use32 && want_duo) {
+        duo_lane = m->lanes == 2 && rnn_persist_duo_eligible(m->geom16, B, m->n_cus / 2);
+        duo = duo_lane || rnn_persist_duo_eligible(m->geom16, B, m->n_cus);
+    }
+    if (use16 && !use32 && !duo) {
+        if (want_waves == 4 && m->lanes == 2 && rnn_persist16_half_eligible(m->geom16, B, m->n_cus, &pgroups)) waves = 4;
         else use16 = rnn_persist16_eligible(m->geom16, B, m->n_cus, &pgroups);
     }
     if (use32) {
@@ -569,9 +583,10 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
             PersistGate* gate = persist_gate(m->device);
             std::lock_guard<std::mutex> lk(gate->mu);       // wait -> launch -> record is atomic against other host threads
             static const bool force_lane = std::getenv("DSMI_PERSIST_FORCE_LANE") != nullptr;     // experiments only
-            const bool whole = !((waves == 4 || use32 || force_lane) && m->lanes == 2);     // a half-CU / half-chip kernel takes one lane, anything else the device
+            // a half-CU / half-chip kernel takes one lane, anything else the device
+            const bool whole = !(((waves == 4 && !duo) || duo_lane || use32 || force_lane) && m->lanes == 2);
             gate_wait(gate, s, m->lane, whole);
-            ok = use32 ? launch_rnn_persist32(pl, s) : launch_rnn_persist16(pl, s);
+            ok = use32 ? launch_rnn_persist32(pl, s) : (duo ? launch_rnn_persist_duo(pl, s) : launch_rnn_persist16(pl, s));
             gate_record(gate, s, m->lane, whole);
         }
         if (ok) return;
@@ -978,6 +993,31 @@ extern "C" int dsmi_debug_persist_stamps(dsmi_model* m, int layer, int B, int To
     if ((rc = dsmi_reserve(m, B, Tin))) return rc;
     HIP_OK(m, hipSetDevice(m->device));
     int pgroups = 0;
+    const bool duo = std::getenv("DSMI_STAMP_DUO") && m->have16 && rnn_persist_duo_eligible(m->geom16, B, m->n_cus);
+    if (duo) {          // the paired-tile kernel: stamps[workgroup][8 waves][8] = time in slots 0..3 and at the barrier behind each
+        const int64_t needd = (int64_t)m->geom16.D * ceil_div(ceil_div(B, 16), 2) * m->geom16.nwg * 8 * 8;
+        if (n_words < needd) return fail(m, DSMI_ERR_INVALID, "stamp buffer too small");
+        unsigned long long* dbg;
+        HIP_OK(m, hipMalloc((void**)&dbg, sizeof(unsigned long long) * needd));
+        HIP_OK(m, hipMemset(dbg, 0, sizeof(unsigned long long) * needd));
+        std::vector<int32_t> lens(B, To);
+        HIP_OK(m, hipMemcpy(m->lens_dev, lens.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice));
+        HIP_OK(m, hipMemset(m->xp, 0, sizeof(float) * (size_t)To * B * m->geom16.Np));
+        RnnPersist16Launch pl;
+        pl.g = m->geom16;
+        for (int dd = 0; dd < 2; ++dd) { pl.whh16[dd] = m->rnn[layer].whh16_sp[dd]; pl.bhh[dd] = m->rnn[layer].bhh[dd]; pl.out[dd] = m->hbuf[0][dd]; }
+        pl.xp = m->xp; pl.lens_dev = m->lens_dev; pl.hpack16 = m->hpack16; pl.counters = m->pcnt; pl.err = m->perr;
+        pl.B = B; pl.T = To;
+        for (int rep = 0; rep < 2; ++rep) {
+            HIP_OK(m, hipMemset(m->pcnt, 0, sizeof(unsigned) * (size_t)m->geom.D * ceil_div(B, 16) * To * kPersist16CntWords));
+            pl.dbg = rep ? dbg : nullptr;
+            launch_rnn_persist_duo(pl, nullptr);
+            HIP_OK(m, hipDeviceSynchronize());
+        }
+        HIP_OK(m, hipMemcpy(stamps_host, dbg, sizeof(unsigned long long) * needd, hipMemcpyDeviceToHost));
+        (void)hipFree(dbg);
+        return (int)(needd / 64);
+    }
     const bool use16 = m->persist_gen == 2 && m->have16 && rnn_persist16_eligible(m->geom16, B, m->n_cus, &pgroups) &&
                        ceil_div(B, 16) <= pgroups;        // one tile per workgroup: the plain single-tile path is what is stamped
     const int64_t need = use16 ? (int64_t)m->geom16.D * pgroups * m->geom16.nwg * 8 * 8 : (int64_t)m->geom.D * m->geom.nwg * 8 * 8;

@@ -180,6 +180,11 @@ bool rnn_persist32_eligible(const RnnGeom& g32, int B, int n_cus, int* pgroups_o
 std::vector<uint16_t> pack_whh32(const RnnGeom& g32, const float* w_hh);
 bool launch_rnn_persist32(const RnnPersist16Launch& p, hipStream_t s);
 
+// rnn_persist_duo.hip: one workgroup carries the two 16-clip tiles of a batch in a fixed four-slot pipeline (a 32-clip
+// batch of cfgA on 100 CUs); same packed weights, x-projection order and state layout as rnn_persist16.hip.
+bool rnn_persist_duo_eligible(const RnnGeom& g16, int B, int n_cus);
+bool launch_rnn_persist_duo(const RnnPersist16Launch& p, hipStream_t s);
+
 // head.hip
 //   lookahead: y[t][b][h] = clip(sum_k w[h][k] * x[t+k][b][h], 0, 20)
 void launch_lookahead(const float* x, const float* w, float* y, int T, int B, int H, int context, hipStream_t s);

@@ -200,6 +200,9 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void rnn_persist16_kern
                         hv[i][pl] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(
                             hrs, hbase + (unsigned)(kb * 2 + pl) * 1024u, 0, 16));
                 }
+                // every state load is issued, in k order, before the first MFMA: without this the compiler sinks the loads of
+                // the first k-block into its conditional block, behind all the others, and the first MFMA waits for every load
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < NKW; ++i) {
                     if (kb0 + i < kb1) {

@@ -187,7 +187,7 @@ def test_tiny_weights_and_saturating_gates(native, kind):
     m.close(); m1.close()
 
 
-@pytest.mark.parametrize("waves", ["4", "8", "units32"])
+@pytest.mark.parametrize("waves", ["duo", "4", "8", "units32"])
 def test_two_batches_in_flight_on_two_handles(native, waves):
     """Two handles, two streams, forwards enqueued back to back without waiting: with the half-CU workgroups (waves = 4)
     the persistent kernels of the two batches are co-resident on the same CUs (one gate lane each); with whole-CU
@@ -196,7 +196,10 @@ def test_two_batches_in_flight_on_two_handles(native, waves):
     from oracle import torch_port as tp
     cfg = _cfg(800, 2)
     sd = syn.make_state_dict(2, "gru", 800, 2, seed=31, **syn.TALKATIVE)
-    with _env(DSMI_PERSIST_WAVES="4" if waves == "units32" else waves):
+    env = dict(DSMI_PERSIST_DUO="1") if waves == "duo" else dict(DSMI_PERSIST_DUO="0", DSMI_PERSIST_WAVES="4" if waves == "units32" else waves)
+    if waves == "units32":
+        env["DSMI_PERSIST_UNITS"] = "32"
+    with _env(**env):
         models = [native.NativeModel(cfg, sd) for _ in range(2)]
     if waves == "units32":
         for m in models:
@@ -229,7 +232,8 @@ def test_throughput_variant_32_units_equals_oracle(native, kind, H, B):
     from oracle import torch_port as tp
     cfg = _cfg(H, 2, kind=kind)
     sd = syn.make_state_dict(2, kind, H, 2, seed=51, **syn.TALKATIVE)
-    m = native.NativeModel(cfg, sd)
+    with _env(DSMI_PERSIST_UNITS="32"):
+        m = native.NativeModel(cfg, sd)
     m.set_inflight(2)
     x, lens = _batch(B=B, T=201, seed=52)
     p, ol = m.forward(_dev(x), lens)
@@ -243,4 +247,46 @@ def test_throughput_variant_32_units_equals_oracle(native, kind, H, B):
     p1, _ = m.forward(_dev(x), lens)
     for b in range(B):
         np.testing.assert_allclose(p1.cpu().numpy()[b, :ol[b]], pn[b, :ol[b]], rtol=0, atol=5e-5)
+    m.close()
+
+
+@pytest.mark.parametrize("kind,H,B", [("gru", 800, 32), ("gru", 64, 17), ("lstm", 512, 48), ("rnn", 96, 64), ("gru", 896, 40), ("lstm", 64, 32)])
+def test_paired_tile_kernel_equals_oracle_and_the_single_tile_kernels(native, kind, H, B):
+    """rnn_persist_duo (the default for 17+ clips when the shape fits): all cell types, one pair / two pairs of tiles, an odd
+    tile count (the last half B idle), a partial last tile, the seven-k-block shape, ragged lengths -- against the oracle
+    and against the same batch through rnn_persist16 (DSMI_PERSIST_DUO=0)."""
+    from oracle import torch_port as tp
+    cfg = _cfg(H, 2, kind=kind)
+    sd = syn.make_state_dict(2, kind, H, 2, seed=61, **syn.TALKATIVE)
+    x, lens = _batch(B=B, T=181, seed=62)
+    ref, ol_ref = tp.forward(sd, cfg, x, lens)
+    outs = []
+    for duo in ("1", "0"):
+        with _env(DSMI_PERSIST_DUO=duo):
+            m = native.NativeModel(cfg, sd)
+        p, ol = m.forward(_dev(x), lens)
+        assert np.array_equal(ol, ol_ref) and m.recompute_count() == 0
+        outs.append(p.cpu().numpy())
+        m.close()
+    for b in range(B):
+        np.testing.assert_allclose(outs[0][b, :ol_ref[b]], ref[b, :ol_ref[b]], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(outs[0][b, :ol_ref[b]], outs[1][b, :ol_ref[b]], rtol=0, atol=5e-5)
+
+
+def test_paired_tile_kernel_timeout_is_recomputed(native):
+    from oracle import torch_port as tp
+    cfg = _cfg(64, 2)
+    sd = syn.make_state_dict(2, "gru", 64, 2, seed=63, **syn.TALKATIVE)
+    x, lens = _batch(B=24, T=161, seed=64)
+    ref, _ = tp.forward(sd, cfg, x, lens)
+    with _env(DSMI_DEBUG_DROP_SIGNAL="1:2:9", DSMI_DEBUG_SPIN_LIMIT="3000", DSMI_PERSIST_DUO="1"):
+        m = native.NativeModel(cfg, sd)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        p, ol = m.forward(_dev(x), lens, check=False)
+        assert m.status() is True
+    assert m.recompute_count() == 1
+    pn = p.cpu().numpy()
+    for b in range(24):
+        np.testing.assert_allclose(pn[b, :ol[b]], ref[b, :ol[b]], rtol=0, atol=1e-4)
     m.close()

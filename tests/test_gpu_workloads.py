@@ -45,8 +45,9 @@ def _ragged_clips(B, lo, hi, seed, first=None):
     return [syn.make_clip(100 * seed + i, int(k)) for i, k in enumerate(n)]
 
 
-def _gpu_pipeline(native, cfg, sd, clips):
+def _gpu_pipeline(native, cfg, sd, clips, inflight=1):
     m = native.NativeModel(cfg, sd)
+    m.set_inflight(inflight)          # 1: whole-device kernels for a lone batch; 2: what bench.py and recognize_batches run
     fe = native.NativeFrontend()
     n = np.array([len(c) for c in clips], dtype=np.int64)
     pcm = torch.from_numpy(np.concatenate(clips)).cuda()
@@ -86,13 +87,15 @@ def _check_greedy(native, probs, out_lens, p_ref, ol_ref, err, min_tokens):
     return lens
 
 
-def test_config2_cfgA_batch32_ragged_greedy(native):
-    """The benchmarked geometry itself."""
+@pytest.mark.parametrize("inflight", [2, 1])
+def test_config2_cfgA_batch32_ragged_greedy(native, inflight):
+    """The benchmarked geometry itself: with two batches in flight (the benchmark's default) the paired-tile kernel on 100 CUs,
+    with one the whole-CU kernel on 200."""
     from oracle import torch_port as tp
     cfg = _cfg(800, 5)
     sd = syn.make_state_dict(2, "gru", 800, 5, seed=0, **syn.TALKATIVE)
     clips = _ragged_clips(32, 64000, 160000, seed=1)
-    m, fe, feat, frames, probs, out_lens = _gpu_pipeline(native, cfg, sd, clips)
+    m, fe, feat, frames, probs, out_lens = _gpu_pipeline(native, cfg, sd, clips, inflight)
     x_ref, fr_ref = tp.spectrogram_batch(clips)
     assert np.array_equal(frames, fr_ref) and int(frames.max()) == 1001
     np.testing.assert_allclose(feat.cpu().numpy(), x_ref, rtol=0, atol=2e-5)

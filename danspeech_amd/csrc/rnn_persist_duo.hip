@@ -25,7 +25,6 @@
 // when most of the hand-off latency has passed.
 #include "common.h"
 #include <cstring>
-#include <cstdlib>
 
 namespace dsmi {
 
@@ -51,7 +50,6 @@ struct DuoArgs {
     int ntiles, D;
     unsigned spin_limit;
     int drop_wg, drop_step;
-    int dbg_mode;              // diagnostics build only: 1 = skip the MFMAs, 2 = skip the state loads (timing experiments)
     unsigned long long* dbg;   // diagnostics build only: per wave, time in each of its four slots [0..3] and at the barrier behind it [4..7]
 };
 
@@ -153,16 +151,13 @@ __global__ __launch_bounds__(DNT, 2) void rnn_persist_duo_kernel(DuoArgs p) {
                     for (int i = 0; i < NKW; ++i) {
                         const int kb = min(kb0 + i, max(kb1 - 1, kb0));
 #pragma unroll
-                        for (int pl = 0; pl < 2; ++pl) {
-                            if (STAMP && p.dbg_mode == 2) hv[i][pl] = wv[0][0][pl];
-                            else hv[i][pl] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                        for (int pl = 0; pl < 2; ++pl)
+                            hv[i][pl] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(
                                 hrs, hbase + (unsigned)(kb * 2 + pl) * 1024u, 0, 16));
-                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);     // every state load is issued, in k order, before the first MFMA
 #pragma unroll
                     for (int i = 0; i < NKW; ++i) {
-                        if (STAMP && p.dbg_mode == 1) { acc[0][0] += (float)hv[i][0][0] + (float)hv[i][1][3]; continue; }
                         if (kb0 + i < kb1) {
                             f16x8 wa[NG][2];
 #pragma unroll
@@ -334,7 +329,6 @@ bool launch_rnn_persist_duo(const RnnPersist16Launch& p, hipStream_t s) {
     a.B = p.B; a.T = p.T; a.H = p.g.H; a.Hs = p.g.Kp; a.Np = p.g.Np; a.nwg = p.g.nwg; a.nkb = ceil_div(p.g.H, 32);
     a.ntiles = ceil_div(p.B, DB); a.D = p.g.D;
     a.spin_limit = p.spin_limit; a.drop_wg = p.drop_wg; a.drop_step = p.drop_step; a.dbg = p.dbg;
-    a.dbg_mode = std::getenv("DSMI_STAMP_MODE") ? std::atoi(std::getenv("DSMI_STAMP_MODE")) : 0;
     switch (p.g.kind) {
         case DSMI_RNN_GRU: return launch_duo<DSMI_RNN_GRU>(a, s, p.ev);
         case DSMI_RNN_LSTM: return launch_duo<DSMI_RNN_LSTM>(a, s, p.ev);

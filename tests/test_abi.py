@@ -34,7 +34,9 @@ def test_create_rejects_bad_conv_layers_without_gpu():
     from danspeech_amd import _native
     L = _native.lib()
     d = _native.ModelDesc(conv_layers=0, rnn_type=0, rnn_hidden_size=8, rnn_layers=1, bidirectional=1, context=20,
-                          n_labels=33, sample_rate=16000, window_size=0.02, window_stride=0.01, window=0, normalize=1)
+                          n_labels=33, sample_rate=16000, window_size=0.02)
+    assert [f[0] for f in _native.ModelDesc._fields_] == ["conv_layers", "rnn_type", "rnn_hidden_size", "rnn_layers", "bidirectional",
+                                                          "context", "n_labels", "sample_rate", "window_size"]      # = dsmi_model_desc
     h = ctypes.c_void_p()
     assert L.dsmi_model_create(ctypes.byref(d), 0, ctypes.byref(h)) == _native.DSMI_ERR_CONV
     assert b"0 convolutional layers" in L.dsmi_last_error(None)

@@ -2,13 +2,13 @@
 # Counter passes for the bench workload (run on the GPU box, from the repo root):
 #   bash tools/pmc_collect.sh r02
 # One rocprofv3 invocation per counter group (TCC slots: FETCH_SIZE and WRITE_SIZE do not fit one pass;
-# --pmc is never combined with trace domains other than the kernel trace), one batch in flight so that
-# every dispatch runs alone.  Raw CSVs land under gpurun_out/<tag>_pmc_<group>/; tools/pmc_report.py turns
+# --pmc is never combined with trace domains other than the kernel trace); the counter passes serialise the
+# dispatches, so every kernel -- the default two-in-flight variants included -- is counted running alone.  Raw CSVs land under gpurun_out/<tag>_pmc_<group>/; tools/pmc_report.py turns
 # them into profiles/<tag>_pmc_summary.md and profiles/pmc_traffic.json.
 set -u
 TAG=${1:-r02}
 export TMPDIR=/tmp
-CMD="python3 bench.py --steps 2 --warmup 1 --pipeline 1 --no-cpu-baseline --no-public-surface --no-kernel-sampling"
+CMD="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-public-surface --no-kernel-sampling"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_trace -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-public-surface --no-kernel-sampling > gpurun_out/${TAG}_trace.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_trace_p1 -- python3 bench.py --steps 6 --warmup 2 --pipeline 1 --no-cpu-baseline --no-public-surface --no-kernel-sampling > gpurun_out/${TAG}_trace_p1.log 2>&1
 for G in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES" "GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_MFMA"; do

@@ -36,7 +36,7 @@ def main():
                 if k:
                     vals[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     out = {}
-    print("# %s: rocprofv3 --pmc, mean per dispatch (bench.py --pipeline 1, cfgA, 32 x 10 s)\n" % tag)
+    print("# %s: rocprofv3 --pmc, mean per dispatch (bench.py defaults: cfgA, 32 x 10 s, two batches in flight -- dispatches serialised by the counter passes)\n" % tag)
     counters = sorted({c for k in vals for c in vals[k]})
     print("| kernel | " + " | ".join(counters) + " |")
     print("|---|" + "---|" * len(counters))

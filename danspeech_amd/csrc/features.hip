@@ -12,6 +12,8 @@
 #include "common.h"
 
 #include <cmath>
+#include <cstring>
+#include <algorithm>
 
 using namespace dsmi;
 
@@ -25,7 +27,36 @@ struct dsmi_frontend {
     double* win = nullptr;   // [n_fft]
     int64_t* offs = nullptr; // device: per-clip sample offset, n_samples [2][cap], then float64 partial statistics [cap][NSL][2]
     int cap = 0;
+    // pinned staging of the per-batch offsets / lengths (an async copy must not read pageable memory that is gone or
+    // overwritten when the copy engine gets to it): a ring of slots, each reused only after its copy has completed
+    static constexpr int kStage = 4;
+    int64_t* stage = nullptr; int stage_cap = 0, stage_next = 0;
+    hipEvent_t stage_ev[kStage] = {nullptr, nullptr, nullptr, nullptr}; bool stage_used[kStage] = {false, false, false, false};
 };
+
+// host[0..n) -> dev[0..n) on stream s through the frontend's pinned ring
+static bool fe_stage_copy(dsmi_frontend* f, int64_t* dev, const int64_t* host, int n, hipStream_t s) {
+    if (n > f->stage_cap) {
+        if (hipDeviceSynchronize() != hipSuccess) return false;
+        if (f->stage) (void)hipHostFree(f->stage);
+        f->stage = nullptr;
+        const int cap = std::max(n, 256);
+        if (hipHostMalloc((void**)&f->stage, sizeof(int64_t) * (size_t)cap * dsmi_frontend::kStage, hipHostMallocDefault) != hipSuccess) return false;
+        f->stage_cap = cap;
+        for (int i = 0; i < dsmi_frontend::kStage; ++i) {
+            if (!f->stage_ev[i] && hipEventCreateWithFlags(&f->stage_ev[i], hipEventDisableTiming) != hipSuccess) return false;
+            f->stage_used[i] = false;
+        }
+    }
+    const int slot = f->stage_next++ % dsmi_frontend::kStage;
+    if (f->stage_used[slot] && hipEventSynchronize(f->stage_ev[slot]) != hipSuccess) return false;
+    int64_t* h = f->stage + (size_t)slot * f->stage_cap;
+    std::memcpy(h, host, sizeof(int64_t) * n);
+    if (hipMemcpyAsync(dev, h, sizeof(int64_t) * n, hipMemcpyHostToDevice, s) != hipSuccess) return false;
+    if (hipEventRecord(f->stage_ev[slot], s) != hipSuccess) return false;
+    f->stage_used[slot] = true;
+    return true;
+}
 
 static thread_local std::string g_fe_error;
 
@@ -271,9 +302,8 @@ extern "C" int dsmi_features_stream(dsmi_frontend* f, const void* pcm, int dtype
         f->cap = 2;
     }
     const int64_t host[2] = {0, n_samples};
-    if (hipMemcpyAsync(f->offs, &host[0], sizeof(int64_t), hipMemcpyHostToDevice, s) != hipSuccess ||
-        hipMemcpyAsync(f->offs + f->cap, &host[1], sizeof(int64_t), hipMemcpyHostToDevice, s) != hipSuccess)
-        return bad(DSMI_ERR_HIP, "hipMemcpyAsync failed");
+    if (!fe_stage_copy(f, f->offs, &host[0], 1, s) || !fe_stage_copy(f, f->offs + f->cap, &host[1], 1, s))
+        return bad(DSMI_ERR_HIP, "staging the chunk's offset / length failed");
     const size_t lds = sizeof(double) * ((size_t)2 * f->n_fft + (size_t)f->n_fft * FT);
     hipLaunchKernelGGL(stft_logmag_kernel, dim3(ceil_div(nfr, FT), 1), dim3(256), lds, s, pcm, dtype, f->offs, f->offs + f->cap,
                        f->tw, f->win, f->n_fft, f->hop, f->n_freq, PAD_NONE, feat, t_stride);
@@ -403,6 +433,8 @@ extern "C" void dsmi_frontend_destroy(dsmi_frontend* f) {
     if (f->tw) (void)hipFree(f->tw);
     if (f->win) (void)hipFree(f->win);
     if (f->offs) (void)hipFree(f->offs);
+    if (f->stage) (void)hipHostFree(f->stage);
+    for (hipEvent_t e : f->stage_ev) if (e) (void)hipEventDestroy(e);
     delete f;
 }
 
@@ -438,9 +470,8 @@ extern "C" int dsmi_features(dsmi_frontend* m, const void* pcm, int dtype, const
         if (hipMalloc((void**)&f->offs, sizeof(int64_t) * (2 + 2 * NSL) * B) != hipSuccess) return bad(DSMI_ERR_NOMEM, "hipMalloc failed");
         f->cap = B;
     }
-    if (hipMemcpyAsync(f->offs, host.data(), sizeof(int64_t) * B, hipMemcpyHostToDevice, s) != hipSuccess ||
-        hipMemcpyAsync(f->offs + f->cap, host.data() + B, sizeof(int64_t) * B, hipMemcpyHostToDevice, s) != hipSuccess)
-        return bad(DSMI_ERR_HIP, "hipMemcpyAsync failed");
+    if (!fe_stage_copy(f, f->offs, host.data(), B, s) || !fe_stage_copy(f, f->offs + f->cap, host.data() + B, B, s))
+        return bad(DSMI_ERR_HIP, "staging the clips' offsets / lengths failed");
     const size_t lds = sizeof(double) * ((size_t)2 * m->n_fft + (size_t)m->n_fft * FT);
     EvPair ev;
     DSMI_LAUNCH(stft_logmag_kernel, dim3(ceil_div(maxfr, FT), B), dim3(256), lds, s, ev, pcm, dtype, f->offs, f->offs + f->cap,

@@ -237,6 +237,11 @@ def main():
                         frac=round(ach / peak, 4), traffic=(PMC_TRAFFIC.get(dom) or {}).get("bytes_per_launch"),
                         peak_note=("fp16 dense MFMA peak 2500 TFLOP/s / 3 products per fp32-grade multiply (executed fp16 rate = 3 x achieved)"
                                    if split else "fp32 MFMA peak"),
+                        # with P batches in flight P launches of the recurrent kernel run at a time, each on its own lane of CUs:
+                        # `achieved` / `frac` are per launch (the contract's definition); the rate the chip sustains while they
+                        # run is `concurrent_launches` times that
+                        concurrent_launches=(min(P, 2) if dom == "rnn_layer_persistent" else 1),
+                        frac_all_concurrent_launches=round(ach / peak * (min(P, 2) if dom == "rnn_layer_persistent" else 1), 4),
                         avg_launch_us=round(s["avg_us"], 3), launches_per_step=s["launches"] // args.steps,
                         flops_per_launch=s["flops_per_launch"],
                         kernel_time_share={k: round(v / sum(tot.values()), 4) for k, v in sorted(tot.items())})

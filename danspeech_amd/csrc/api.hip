@@ -171,6 +171,8 @@ extern "C" int dsmi_model_create(const dsmi_model_desc* d, int device, dsmi_mode
         m->gemm_mode = (gm && std::string(gm) == "f32") ? 0 : 1;
         const char* cm = std::getenv("DSMI_CONV_MODE");       // "f32" forces the fp32-MFMA conv for all layers
         m->conv_mode = (cm && std::string(cm) == "f32") ? 0 : 1;
+        const char* c1 = std::getenv("DSMI_CONV1_MODE");      // "f32" keeps the first conv layer on the fp32 MFMA (conv.hip)
+        m->conv1_split = !(c1 && std::string(c1) == "f32");
         // test hooks for the hand-off timeout path (tests/test_gpu_timeout.py)
         if (const char* sl = std::getenv("DSMI_DEBUG_SPIN_LIMIT")) m->spin_limit = (unsigned)std::max(1L, std::atol(sl));
         if (const char* ds = std::getenv("DSMI_DEBUG_DROP_SIGNAL"))
@@ -260,9 +262,11 @@ extern "C" int dsmi_model_finalize(dsmi_model* m) {
         if (!w || !b || !bn_affine(m, "conv.seq_module." + std::to_string(3 * l + 1), s.co, s.co, a, bb)) return DSMI_ERR_NOT_READY;
         int rc;
         if ((rc = upload(m, pack_conv_weights(w->data.data(), l), &m->conv[l].wp))) return rc;
+        for (float v : w->data) if (!(std::fabs(v) < kF16Safe)) m->conv_mode = 0;    // split-fp16 operand range
         if (l > 0) {
-            for (float v : w->data) if (!(std::fabs(v) < kF16Safe)) m->conv_mode = 0;    // split-fp16 operand range
             if ((rc = upload(m, pack_conv_w_split(w->data.data(), s.co), &m->conv[l].wp_sp))) return rc;
+        } else {
+            if ((rc = upload(m, pack_conv1_w_split(w->data.data()), &m->conv[l].wp_sp))) return rc;
         }
         if ((rc = upload(m, b->data, &m->conv[l].bias))) return rc;
         if ((rc = upload(m, a, &m->conv[l].bn_a))) return rc;
@@ -519,7 +523,9 @@ static int run_conv(dsmi_model* m, const float* feat, int B, int T, int To, int 
             c.ti = ti; c.to = To; c.xs = xs; c.ys = ys; c.layer = l;
             c.y_sp = next_split ? m->conv_buf_sp[l] : nullptr;
             c.ev = timer_arm(m, KK_CONV1 + l, true, fl, by);
-            launch_conv(c, s);
+            // layer 0 on the split-fp16 MFMA (features are z-normalised log magnitudes: far inside fp16's range)
+            if (l == 0 && m->conv_mode == 1 && m->conv1_split) launch_conv1_split(c, m->conv[0].wp_sp, s);
+            else launch_conv(c, s);
             x = c.y; x_sp = c.y_sp;
         }
         ti = To; xs = ys;

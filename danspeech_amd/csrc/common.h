@@ -70,6 +70,11 @@ std::vector<uint16_t> pack_conv_w_split(const float* w, int co_total);
 // Host-side weight packer: w [co][ci][kf][kt] -> kernel layout. Returns packed floats.
 std::vector<float> pack_conv_weights(const float* w, int layer);
 
+// conv1_split.hip: the first conv layer (1 input channel) on the fp16 MFMA with two-term split operands; takes the same
+// launch description as launch_conv (layer 0) plus the pack_conv1_w_split image of the weights.
+std::vector<uint16_t> pack_conv1_w_split(const float* w);
+void launch_conv1_split(const ConvLaunch& p, const uint16_t* wp_sp, hipStream_t s);
+
 // gemm.hip: C[m][n] = sum_k A[m][k] * W[n][k] + bias[n]   (fp32 MFMA 32x32x2)
 enum GemmAMode {
     GEMM_A_ROWMAJOR = 0,   // A [M][K] row-major

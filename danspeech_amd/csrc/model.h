@@ -101,6 +101,7 @@ struct dsmi_model {
     int32_t* lens_stage = nullptr; int stage_cap = 0, stage_next = 0;
     hipEvent_t stage_ev[kStage] = {nullptr, nullptr, nullptr, nullptr}; bool stage_used[kStage] = {false, false, false, false};
     int n_cus = 0;
+    bool conv1_split = true;      // first conv layer on the split-fp16 MFMA (conv1_split.hip); DSMI_CONV1_MODE=f32: conv.hip
     int conv_mode = 1;            // 1: split-fp16 conv for the 32-input-channel layers, 0: fp32 MFMA conv
     int gemm_mode = 1;            // 1: split-fp16 GEMM, 0: fp32 MFMA GEMM
     int rnn_mode = 1;             // 1: persistent layer kernel when eligible, 0: one launch per step

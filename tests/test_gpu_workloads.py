@@ -64,22 +64,24 @@ def _margins(p, ol):
 
 
 def _check_greedy(native, probs, out_lens, p_ref, ol_ref, err, min_tokens):
-    """Transcripts and offsets identical to the oracle's for every clip whose top-2 margin is well above the
-    measured probability error (all of them, in practice); the weights must make that a real check."""
+    """Transcripts and offsets identical to the oracle's.  A clip may differ only if the oracle's own top-2 margin somewhere
+    in it is within 4 x the measured probability error (an argmax that close is decided by fp32 summation order, in the
+    reference too); at least 90 % of the clips must be identical outright, and the weights must make that a real check."""
     from oracle import decoder as od
     gd = native.NativeDecoder(LABELS, blank_index=0)
     dec = gd.greedy(probs, out_lens)
     s_ref, o_ref = od.greedy_decode(p_ref, ol_ref, LABELS, 0)
     mar = _margins(p_ref, ol_ref)
-    safe = mar > 20 * max(err, 1e-7)
-    assert safe.mean() >= 0.9, "top-2 margins too small for a bit-exact transcript check: %s" % np.sort(mar)[:4]
-    lens = []
+    lens, same = [], 0
     for b in range(len(dec)):
         got = "".join(LABELS[i] for i in dec[b][0])
         lens.append(len(got))
-        if safe[b]:
-            assert got == s_ref[b][0], (b, got, s_ref[b][0])
-            assert np.array_equal(dec[b][1], o_ref[b][0]), b
+        if got == s_ref[b][0] and np.array_equal(dec[b][1], o_ref[b][0]):
+            same += 1
+        else:
+            assert mar[b] <= 4 * max(err, 1e-7), (b, got, s_ref[b][0], mar[b], err)
+    assert same >= 0.9 * len(dec), (same, len(dec))
+    print("greedy transcripts identical: %d/%d (smallest top-2 margins %s, max err %.2g)" % (same, len(dec), np.sort(mar)[:3], err))
     assert min(lens) >= min_tokens, lens
     text = "".join("".join(LABELS[i] for i in d[0]) for d in dec)
     assert " " in text and len(set(text)) >= 10

@@ -24,6 +24,7 @@
 // advance in lockstep anti-phase chip-wide.  A signal leaves ~0.45 us into a drain slot and its poll starts ~0.5 us later,
 // when most of the hand-off latency has passed.
 #include "common.h"
+#include <cstdlib>
 #include <cstring>
 
 namespace dsmi {
@@ -56,7 +57,11 @@ struct DuoArgs {
 __device__ __forceinline__ float dsigmoid(float v) { return __frcp_rn(1.f + __expf(-v)); }
 __device__ __forceinline__ float dtanh(float v) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * v)); }
 
-template <int KIND, int NKW, bool STAMP = false>
+// TAIL: the k-blocks do not divide by the half's four waves (H = 800: 25).  Instead of one wave carrying a whole extra block
+// (9 more MFMAs and its W_hh fragments in LDS, the slot as long as that wave), every wave takes nkb / 4 full blocks and the
+// 1-3 blocks left over are dealt out gate by gate: wave vh takes gate vh % NG of block 4 * (nkb / 4) + vh / NG -- three more
+// MFMAs and 8 more registers, no LDS operand.  Offered when that is at most one (block, gate) item per wave.
+template <int KIND, int NKW, bool STAMP = false, bool TAIL = false>
 __global__ __launch_bounds__(DNT, 2) void rnn_persist_duo_kernel(DuoArgs p) {
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     constexpr int NG = KIND == DSMI_RNN_GRU ? 3 : (KIND == DSMI_RNN_LSTM ? 4 : 1);
@@ -81,8 +86,16 @@ __global__ __launch_bounds__(DNT, 2) void rnn_persist_duo_kernel(DuoArgs p) {
     if (tid < 32) sync[tid] = 0;
 
     // ---- resident operand: this wave's k-blocks of the split W_hh, all gates (both halves hold the same image)
-    const int kb0 = (vh * p.nkb) / 4, kb1 = ((vh + 1) * p.nkb) / 4;
+    const int kq = p.nkb >> 2;
+    const int kb0 = TAIL ? vh * kq : (vh * p.nkb) / 4, kb1 = TAIL ? kb0 + kq : ((vh + 1) * p.nkb) / 4;
+    const int xkb = 4 * kq + vh / NG, xgate = vh % NG;               // TAIL: this wave's left-over (block, gate)
+    const bool has_x = TAIL && vh < NG * (p.nkb & 3);
     f16x8 wv[NKR][NG][2];
+    // TAIL: that item's W_hh fragments [0..1] and, with six full blocks, the low planes of the sixth [2 + gate] live in LDS
+    // and are read (by the lane that wrote them) once earlier blocks have released registers: held from the start they push
+    // the kernel past 256 registers and the compiler parks a W_hh fragment in scratch, behind the state loads.
+    constexpr bool LO5 = TAIL && NKW == 6;
+    u32x4* wxl = wlds + (size_t)v * (2 + NG) * 64 + lane;
     u32x4* wl = wlds + (size_t)v * (NKW - NKR) * NG * 2 * 64 + lane;
     {
         const u32x4* wp = reinterpret_cast<const u32x4*>(p.whh[d]) + ((size_t)w * p.nkb) * (NG * 2 * 64) + lane;
@@ -94,10 +107,14 @@ __global__ __launch_bounds__(DNT, 2) void rnn_persist_duo_kernel(DuoArgs p) {
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl) {
                     const u32x4 frag = wp[(((size_t)kb * NG + g) * 2 + pl) * 64];
-                    if (i < NKR) wv[i < NKR ? i : 0][g][pl] = __builtin_bit_cast(f16x8, frag);
+                    if (LO5 && i == 5 && pl == 1) wxl[(2 + g) * 64] = frag;
+                    else if (i < NKR) wv[i < NKR ? i : 0][g][pl] = __builtin_bit_cast(f16x8, frag);
                     else wl[(((i - NKR) * NG + g) * 2 + pl) * 64] = frag;       // read back by this same lane only
                 }
         }
+        if (has_x)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) wxl[pl * 64] = wp[(((size_t)xkb * NG + xgate) * 2 + pl) * 64];
     }
     const size_t hp_par = (size_t)p.D * p.ntiles * p.nkb * 2048;     // bytes per parity
     const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.hpack, 0, (int)(2 * hp_par), 0x00020000);
@@ -155,16 +172,26 @@ __global__ __launch_bounds__(DNT, 2) void rnn_persist_duo_kernel(DuoArgs p) {
                             hv[i][pl] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(
                                 hrs, hbase + (unsigned)(kb * 2 + pl) * 1024u, 0, 16));
                     }
+                    f16x8 hx_[2] = {};
+                    if (has_x)
+#pragma unroll
+                        for (int pl = 0; pl < 2; ++pl)
+                            hx_[pl] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                                hrs, hbase + (unsigned)(xkb * 2 + pl) * 1024u, 0, 16));
                     __builtin_amdgcn_sched_barrier(0);     // every state load is issued, in k order, before the first MFMA
+                    f16x8 wlo5[NG];
 #pragma unroll
                     for (int i = 0; i < NKW; ++i) {
+                        if (LO5 && i == 3)
+#pragma unroll
+                            for (int g = 0; g < NG; ++g) wlo5[g] = __builtin_bit_cast(f16x8, wxl[(2 + g) * 64]);
                         if (kb0 + i < kb1) {
                             f16x8 wa[NG][2];
 #pragma unroll
                             for (int g = 0; g < NG; ++g)
 #pragma unroll
                                 for (int pl = 0; pl < 2; ++pl)
-                                    wa[g][pl] = i < NKR ? wv[i < NKR ? i : 0][g][pl]
+                                    wa[g][pl] = (LO5 && i == 5 && pl == 1) ? wlo5[g] : i < NKR ? wv[i < NKR ? i : 0][g][pl]
                                                         : __builtin_bit_cast(f16x8, wl[(((i - NKR) * NG + g) * 2 + pl) * 64]);
 #pragma unroll
                             for (int g = 0; g < NG; ++g) acl[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[g][1], hv[i][0], acl[g], 0, 0, 0);
@@ -176,6 +203,20 @@ __global__ __launch_bounds__(DNT, 2) void rnn_persist_duo_kernel(DuoArgs p) {
                         // keep the k-blocks in load order: the scheduler otherwise starts with the LDS-resident block, whose
                         // state operand was requested LAST, and the first MFMA then waits for every load
                         __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (has_x) {
+                        // operand read here, into registers the finished blocks have released (the kernel sits at the 256-register
+                        // limit: held from the start, these eight spill a W_hh fragment into scratch, behind the state loads)
+                        f16x8 wx[2];
+#pragma unroll
+                        for (int pl = 0; pl < 2; ++pl) wx[pl] = __builtin_bit_cast(f16x8, wxl[pl * 64]);
+#pragma unroll
+                        for (int g = 0; g < NG; ++g)
+                            if (g == xgate) {
+                                acl[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wx[1], hx_[0], acl[g], 0, 0, 0);
+                                acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wx[0], hx_[0], acc[g], 0, 0, 0);
+                                acl[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wx[0], hx_[1], acl[g], 0, 0, 0);
+                            }
                     }
                 }
 #pragma unroll
@@ -281,6 +322,9 @@ __global__ __launch_bounds__(DNT, 2) void rnn_persist_duo_kernel(DuoArgs p) {
 template <int KIND>
 bool launch_duo(const DuoArgs& a, hipStream_t s, const EvPair& ev) {
     const int nkw = ceil_div(a.nkb, 4);
+    constexpr int NGk = KIND == DSMI_RNN_GRU ? 3 : (KIND == DSMI_RNN_LSTM ? 4 : 1);
+    const int kq = a.nkb / 4, kr = a.nkb % 4;
+    const bool tail = kr > 0 && NGk * kr <= 4 && kq >= 1 && kq <= (KIND == DSMI_RNN_LSTM ? 4 : 6) && !getenv("DSMI_DUO_NOTAIL");
     const dim3 grid(a.nwg, a.D * ((a.ntiles + 1) / 2), 1), block(DNT);
     if (a.dbg) {
         if (KIND != DSMI_RNN_GRU || nkw != 7) return false;
@@ -288,6 +332,19 @@ bool launch_duo(const DuoArgs& a, hipStream_t s, const EvPair& ev) {
         hipLaunchKernelGGL((rnn_persist_duo_kernel<DSMI_RNN_GRU, 7, true>), grid, block, D_LDS, s, a);
         return true;
     }
+#define LAUNCH_T(N)                                                                                                  \
+    do {                                                                                                             \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rnn_persist_duo_kernel<KIND, N, false, true>),        \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)D_LDS);                            \
+        DSMI_LAUNCH((rnn_persist_duo_kernel<KIND, N, false, true>), grid, block, D_LDS, s, ev, a);                    \
+    } while (0)
+    if (tail) {
+        if (kq <= 2) LAUNCH_T(2);
+        else if (kq <= 4) LAUNCH_T(4);
+        else if constexpr (KIND != DSMI_RNN_LSTM) LAUNCH_T(6);
+        return true;
+    }
+#undef LAUNCH_T
 #define LAUNCH_D(N)                                                                                                  \
     do {                                                                                                             \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rnn_persist_duo_kernel<KIND, N>),                     \

@@ -18,11 +18,13 @@ WINDOWS = {"hamming": 0, "hann": 1, "blackman": 2, "bartlett": 3}
 PCM_DTYPES = {np.dtype(np.int16): 0, np.dtype(np.float32): 1, np.dtype(np.float64): 2}
 PAD_MODES = {"reflect": 0, "constant": 1}
 
+DSMI_ERR_INVALID = -1
 DSMI_ERR_CONV = -2
 DSMI_ERR_NOT_READY = -3
 DSMI_ERR_UNSORTED = -4
 DSMI_ERR_CAPACITY = -8
 DSMI_ERR_TIMEOUT = -9
+DSMI_ERR_COMM = -10
 DSMI_RECOMPUTED = 1
 
 
@@ -105,6 +107,25 @@ _PROTOS = {
     "dsmi_lm_word_index": (C.c_int, [_vp, C.c_char_p]),
     "dsmi_lm_lookup": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "dsmi_lm_cond_log10": (C.c_double, [_vp, _vp, C.c_int]),
+    "dsmi_model_info": (C.c_int, [_vp, C.POINTER(ModelDesc), C.POINTER(C.c_int)]),
+    "dsmi_frontend_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "dsmi_decoder_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "dsmi_decoder_label": (C.c_char_p, [_vp, C.c_int]),
+    "dsmi_session_create": (C.c_int, [_vp, _vp, _vp, C.POINTER(_vp)]),
+    "dsmi_session_destroy": (None, [_vp]),
+    "dsmi_session_last_error": (C.c_char_p, [_vp]),
+    "dsmi_recognize_batch": (C.c_int, [_vp, C.POINTER(_vp), _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _vp, C.c_int, _vp, _vp]),
+    "dsmi_recognize_enqueue": (C.c_int, [_vp, C.POINTER(_vp), _vp, C.c_int, C.c_int]),
+    "dsmi_recognize_enqueue_device": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int]),
+    "dsmi_recognize_collect": (C.c_int, [_vp, C.c_int, C.c_int, C.c_double, _vp, C.c_int, _vp, _vp]),
+    "dsmi_plan_shards": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
+    "dsmi_comm_unique_id": (C.c_int, [_vp]),
+    "dsmi_comm_init": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "dsmi_comm_destroy": (None, [_vp]),
+    "dsmi_comm_last_error": (C.c_char_p, [_vp]),
+    "dsmi_comm_scatter": (C.c_int, [_vp, C.c_int, C.POINTER(_vp), _vp, C.c_int, C.c_int, C.POINTER(_vp), _vp, _vp, C.c_int,
+                                    C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), _vp]),
+    "dsmi_comm_gather_text": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp]),
 }
 
 
@@ -564,3 +585,139 @@ class NativeLM:
     def cond_log10(self, ids):
         a = np.ascontiguousarray(ids, dtype=np.int32)
         return float(lib().dsmi_lm_cond_log10(self._h, _np_ptr(a), len(a)))
+
+
+_PCM_CODE = {np.dtype(np.int16): 0, np.dtype(np.float32): 1, np.dtype(np.float64): 2}
+
+
+def plan_shards(n_samples, world):
+    """dsmi_plan_shards: (rank_of, slot_of) int32 arrays."""
+    n = np.ascontiguousarray(n_samples, dtype=np.int64)
+    rank_of = np.zeros(len(n), dtype=np.int32)
+    slot_of = np.zeros(len(n), dtype=np.int32)
+    rc = lib().dsmi_plan_shards(_np_ptr(n) if len(n) else None, len(n), int(world),
+                                _np_ptr(rank_of) if len(n) else None, _np_ptr(slot_of) if len(n) else None)
+    if rc != 0:
+        raise DsmiError(rc, "dsmi_plan_shards")
+    return rank_of, slot_of
+
+
+class NativeSession:
+    """dsmi_session_*: the fused recognise call a host without the Python layer uses (tests drive it through ctypes).
+    ``frontend`` / ``model`` / ``decoder``: NativeFrontend / NativeModel / NativeDecoder; they must outlive the session."""
+
+    def __init__(self, frontend, model, decoder):
+        self._keep = (frontend, model, decoder)
+        h = _vp()
+        rc = lib().dsmi_session_create(frontend._h, model._h, decoder._h, C.byref(h))
+        if rc != 0:
+            raise DsmiError(rc, (lib().dsmi_session_last_error(None) or b"").decode())
+        self._h = h
+
+    def close(self):
+        if self._h:
+            lib().dsmi_session_destroy(self._h)
+            self._h = None
+
+    def _err(self, rc):
+        return DsmiError(rc, (lib().dsmi_session_last_error(self._h) or b"").decode())
+
+    def enqueue(self, clips):
+        clips = [np.ascontiguousarray(c) for c in clips]
+        kinds = {c.dtype for c in clips}
+        if len(kinds) != 1 or next(iter(kinds)) not in _PCM_CODE:
+            raise ValueError("clips of one sample type: int16, float32 or float64")
+        n = np.array([len(c) for c in clips], dtype=np.int64)
+        ptrs = (_vp * len(clips))(*[c.ctypes.data for c in clips])
+        rc = lib().dsmi_recognize_enqueue(self._h, ptrs, _np_ptr(n), _PCM_CODE[clips[0].dtype], len(clips))
+        if rc != 0:
+            raise self._err(rc)
+        self._count = len(clips)
+
+    def enqueue_device(self, pcm_dev, n_samples, dtype_code):
+        n = np.ascontiguousarray(n_samples, dtype=np.int64)
+        ptr = pcm_dev.data_ptr() if hasattr(pcm_dev, "data_ptr") else int(pcm_dev)
+        rc = lib().dsmi_recognize_enqueue_device(self._h, ptr, _np_ptr(n), int(dtype_code), len(n))
+        if rc != 0:
+            raise self._err(rc)
+        self._count = len(n)
+        self._keep_pcm = pcm_dev
+
+    def collect(self, beam_width=0, cutoff_top_n=40, cutoff_prob=1.0, text_stride=4096, raw=False):
+        B = self._count
+        text = np.zeros((B, text_stride), dtype=np.uint8)
+        nbytes = np.zeros(B, dtype=np.int32)
+        scores = np.zeros(B, dtype=np.float32)
+        rc = lib().dsmi_recognize_collect(self._h, int(beam_width), int(cutoff_top_n), float(cutoff_prob), text.ctypes.data, text_stride,
+                                          _np_ptr(nbytes), _np_ptr(scores))
+        if rc < 0:
+            raise self._err(rc)
+        self.last_status = rc
+        if raw:
+            return text, nbytes, scores
+        return [bytes(text[b]).split(b"\0", 1)[0].decode("utf-8") for b in range(B)], nbytes, scores
+
+    def recognize_batch(self, clips, **kw):
+        self.enqueue(clips)
+        return self.collect(**kw)
+
+
+class NativeComm:
+    """dsmi_comm_*: scatter / gather over RCCL for hosts without torch.distributed."""
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_ubyte * 128)()
+        rc = lib().dsmi_comm_unique_id(buf)
+        if rc != 0:
+            raise DsmiError(rc, (lib().dsmi_comm_last_error(None) or b"").decode())
+        return bytes(buf)
+
+    def __init__(self, unique_id, rank, world, device):
+        h = _vp()
+        buf = (C.c_ubyte * 128).from_buffer_copy(unique_id)
+        rc = lib().dsmi_comm_init(buf, int(rank), int(world), int(device), C.byref(h))
+        if rc != 0:
+            raise DsmiError(rc, (lib().dsmi_comm_last_error(None) or b"").decode())
+        self._h, self.rank, self.world, self.device = h, rank, world, device
+
+    def close(self):
+        if self._h:
+            lib().dsmi_comm_destroy(self._h)
+            self._h = None
+
+    def _err(self, rc):
+        return DsmiError(rc, (lib().dsmi_comm_last_error(self._h) or b"").decode())
+
+    def scatter(self, clips, root=0, cap=4096):
+        """-> (device address of the shard, n_samples int64[count], positions int32[count], sample-type code, total)."""
+        ptrs, n, code, count = None, None, 0, 0
+        if self.rank == root:
+            clips = [np.ascontiguousarray(c) for c in clips]
+            code = _PCM_CODE[clips[0].dtype] if clips else 0
+            n = np.array([len(c) for c in clips], dtype=np.int64)
+            ptrs = (_vp * max(len(clips), 1))(*[c.ctypes.data for c in clips])
+            count = len(clips)
+        dev = _vp()
+        sn = np.zeros(cap, dtype=np.int64)
+        si = np.zeros(cap, dtype=np.int32)
+        cnt, dt, tot = C.c_int(), C.c_int(), C.c_int()
+        rc = lib().dsmi_comm_scatter(self._h, root, ptrs, _np_ptr(n) if n is not None and len(n) else None, code, count, C.byref(dev),
+                                     _np_ptr(sn), _np_ptr(si), cap, C.byref(cnt), C.byref(dt), C.byref(tot), _stream(self.device))
+        if rc != 0:
+            raise self._err(rc)
+        return dev.value, sn[:cnt.value].copy(), si[:cnt.value].copy(), dt.value, tot.value
+
+    def gather_text(self, text, positions, total, root=0):
+        """text: uint8 [count][stride] (NativeSession.collect(raw=True)); -> list of str on the root, None elsewhere."""
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        stride = text.shape[1]
+        pos = np.ascontiguousarray(positions, dtype=np.int32)
+        out = np.zeros((max(total, 1), stride), dtype=np.uint8)
+        rc = lib().dsmi_comm_gather_text(self._h, root, text.ctypes.data if len(pos) else None, stride, _np_ptr(pos) if len(pos) else None,
+                                         len(pos), total, out.ctypes.data, _stream(self.device))
+        if rc != 0:
+            raise self._err(rc)
+        if self.rank != root:
+            return None
+        return [bytes(out[i]).split(b"\0", 1)[0].decode("utf-8") for i in range(total)]

@@ -201,6 +201,13 @@ extern "C" int dsmi_model_create(const dsmi_model_desc* d, int device, dsmi_mode
 
 extern "C" const char* dsmi_last_error(const dsmi_model* m) { return m ? m->err.c_str() : g_create_error.c_str(); }
 
+extern "C" int dsmi_model_info(const dsmi_model* m, dsmi_model_desc* desc, int* device) {
+    if (!m) return DSMI_ERR_INVALID;
+    if (desc) *desc = m->desc;
+    if (device) *device = m->device;
+    return DSMI_OK;
+}
+
 extern "C" int dsmi_model_load_tensor(dsmi_model* m, const char* name, const float* data, const int64_t* shape, int ndim) {
     if (!m || !name || !data || ndim < 0 || ndim > 4) return m ? fail(m, DSMI_ERR_INVALID, "bad tensor argument") : DSMI_ERR_INVALID;
     if (m->finalized) return fail(m, DSMI_ERR_INVALID, "model already finalized");

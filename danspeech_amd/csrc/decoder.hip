@@ -537,6 +537,18 @@ extern "C" void dsmi_decoder_destroy(dsmi_decoder* d) {
 
 extern "C" const char* dsmi_decoder_last_error(const dsmi_decoder* d) { return d ? d->err.c_str() : g_dec_error.c_str(); }
 
+extern "C" int dsmi_decoder_info(const dsmi_decoder* d, int* n_labels, int* blank_index, int* device) {
+    if (!d) return DSMI_ERR_INVALID;
+    if (n_labels) *n_labels = (int)d->labels.size();
+    if (blank_index) *blank_index = d->blank;
+    if (device) *device = d->device;
+    return DSMI_OK;
+}
+
+extern "C" const char* dsmi_decoder_label(const dsmi_decoder* d, int index) {
+    return d && index >= 0 && index < (int)d->labels.size() ? d->labels[(size_t)index].c_str() : nullptr;
+}
+
 extern "C" int dsmi_decoder_set_lm(dsmi_decoder* d, const char* path, double alpha, double beta) {
     if (!d) return DSMI_ERR_INVALID;
     DEC_HIP(d, hipSetDevice(d->device));

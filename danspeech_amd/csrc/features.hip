@@ -440,6 +440,14 @@ extern "C" void dsmi_frontend_destroy(dsmi_frontend* f) {
 
 extern "C" const char* dsmi_frontend_last_error(const dsmi_frontend* f) { return f ? f->err.c_str() : g_fe_error.c_str(); }
 
+extern "C" int dsmi_frontend_info(const dsmi_frontend* f, int* n_freq, int* hop, int* device) {
+    if (!f) return DSMI_ERR_INVALID;
+    if (n_freq) *n_freq = f->n_freq;
+    if (hop) *hop = f->hop;
+    if (device) *device = f->device;
+    return DSMI_OK;
+}
+
 extern "C" int dsmi_features(dsmi_frontend* m, const void* pcm, int dtype, const int64_t* n_samples, int B, float* feat,
                              int t_stride, int32_t* frames, void* stream) {
     if (!m) return DSMI_ERR_INVALID;

@@ -47,6 +47,7 @@ typedef enum {
     DSMI_ERR_IO = -7,          /* LM file unreadable / malformed                     */
     DSMI_ERR_CAPACITY = -8,    /* batch/time exceeds dsmi_reserve()                  */
     DSMI_ERR_TIMEOUT = -9,     /* a persistent recurrent kernel's hand-off wait timed out and the batch could not be recomputed */
+    DSMI_ERR_COMM = -10,       /* RCCL unavailable or an exchange failed (dsmi_comm_*)                                           */
     DSMI_RECOMPUTED = 1        /* dsmi_forward_status: the batch was recomputed on the per-step path; results valid now */
 } dsmi_status;
 
@@ -266,6 +267,67 @@ int dsmi_lm_info(const dsmi_lm* lm, int* order, int64_t* vocab_size, int* kind);
 int dsmi_lm_word_index(const dsmi_lm* lm, const char* word_utf8);
 int dsmi_lm_lookup(const dsmi_lm* lm, const int32_t* ids, int n, float* log10_prob, float* log10_backoff);
 double dsmi_lm_cond_log10(const dsmi_lm* lm, const int32_t* ids, int n);
+
+/* ---- What a handle was built with (a host that received handles from elsewhere, and dsmi_session_create). */
+int dsmi_model_info(const dsmi_model* m, dsmi_model_desc* desc, int* device);
+int dsmi_frontend_info(const dsmi_frontend* f, int* n_freq, int* hop, int* device);
+int dsmi_decoder_info(const dsmi_decoder* d, int* n_labels, int* blank_index, int* device);
+const char* dsmi_decoder_label(const dsmi_decoder* d, int index);          /* labels[index] as UTF-8, NULL out of range */
+
+/* ---- Recognizer.recognize (Recognizer.py:158-189) -> DanSpeechRecognizer.transcribe (DanSpeechRecognizer.py:191-231)
+ * over a batch of recordings, as ONE call for hosts without the Python layer: stage + upload the clips, spectrograms,
+ * network, decoder, label strings, results in the caller's order -- the sequence of dsmi_features, dsmi_forward,
+ * dsmi_forward_status, dsmi_greedy / dsmi_beam calls danspeech_amd/DanSpeechRecognizer.py issues.  A session binds one
+ * frontend, one model and one decoder of the same device and owns the buffers between the stages and a stream; the
+ * handles must outlive it.  One batch per session at a time; a host that keeps two batches in flight uses two sessions
+ * (each with its own model and frontend handle, dsmi_model_set_inflight(2) on both) and alternates
+ * dsmi_recognize_enqueue / dsmi_recognize_collect between them.
+ *   clips_host[b]      clip b's samples in host memory, n_samples_host[b] of them (frames for DSMI_PCM_STEREO), any order
+ *   beam_width         0: greedy (a recogniser without language model, DanSpeechRecognizer.py:94); > 0: beam search with
+ *                      the decoder's dsmi_decoder_set_lm settings, best beam returned
+ *   text_utf8          [B][text_stride]: clip b's transcript, NUL-terminated; one longer than text_stride - 1 bytes is cut
+ *                      at a label boundary and text_bytes_host[b] (optional) holds its full length
+ *   scores_host        optional [B]: the best beam's score (0 for greedy)
+ * Returns DSMI_OK, DSMI_RECOMPUTED (results valid, see dsmi_forward_status) or < 0. */
+typedef struct dsmi_session dsmi_session;
+int dsmi_session_create(dsmi_frontend* f, dsmi_model* m, dsmi_decoder* d, dsmi_session** out);
+void dsmi_session_destroy(dsmi_session* s);
+const char* dsmi_session_last_error(const dsmi_session* s);
+int dsmi_recognize_batch(dsmi_session* s, const void* const* clips_host, const int64_t* n_samples_host, int pcm_dtype, int B,
+                         int beam_width, int cutoff_top_n, double cutoff_prob,
+                         char* text_utf8, int text_stride, int32_t* text_bytes_host, float* scores_host);
+/* The two halves: everything up to the probabilities, asynchronous; then wait + decode + strings. */
+int dsmi_recognize_enqueue(dsmi_session* s, const void* const* clips_host, const int64_t* n_samples_host, int pcm_dtype, int B);
+/* Clips already back to back in device memory, LONGEST FIRST (DSMI_ERR_UNSORTED otherwise) -- a shard as
+ * dsmi_comm_scatter delivers it: no host staging.  pcm_dev must stay valid until the collect; results are in that order. */
+int dsmi_recognize_enqueue_device(dsmi_session* s, const void* pcm_dev, const int64_t* n_samples_host, int pcm_dtype, int B);
+int dsmi_recognize_collect(dsmi_session* s, int beam_width, int cutoff_top_n, double cutoff_prob,
+                           char* text_utf8, int text_stride, int32_t* text_bytes_host, float* scores_host);
+
+/* ---- Utterance-level data parallelism, one process (or host thread) per GPU, for hosts without torch.distributed
+ * (the Python layer: danspeech_amd/parallel.py).  The reference has no distributed code; clips are independent
+ * on this path, weights are replicated, and the only exchanges are the input scatter and the result gather: grouped
+ * ncclSend / ncclRecv between the root and the other ranks over RCCL, which is bound at run time (dlopen; DSMI_RCCL_LIBRARY
+ * overrides the library name) so that libdsmi.so has no load-time dependency on it.
+ * dsmi_plan_shards (host only): clips sorted by length, descending and stable, dealt round-robin -- clip i goes to rank
+ * rank_of[i] as that rank's slot_of[i]-th clip, so every shard is longest first with a similar length mix.
+ * dsmi_comm_unique_id: rank 0 creates the 128-byte id and ships it to the other ranks by the host's own means.
+ * dsmi_comm_scatter: the root passes its clips (the other ranks NULL / 0); every rank receives *shard_count clips back to
+ * back in device memory at *shard_pcm_dev (library-owned, valid until the next scatter), their lengths and their
+ * positions in the root's list (at most shard_cap), the sample type and the batch's total clip count.
+ * dsmi_comm_gather_text: every rank passes its shard's transcripts [shard_count][text_stride] with those positions; the
+ * root's all_text [total_count][text_stride] receives them in the root's order.  Both synchronise `stream`. */
+typedef struct dsmi_comm dsmi_comm;
+int dsmi_plan_shards(const int64_t* n_samples, int n, int world, int32_t* rank_of, int32_t* slot_of);
+int dsmi_comm_unique_id(void* id128);
+int dsmi_comm_init(const void* id128, int rank, int world, int device, dsmi_comm** out);
+void dsmi_comm_destroy(dsmi_comm* c);
+const char* dsmi_comm_last_error(const dsmi_comm* c);
+int dsmi_comm_scatter(dsmi_comm* c, int root, const void* const* clips_host, const int64_t* n_samples_host, int pcm_dtype, int n,
+                      const void** shard_pcm_dev, int64_t* shard_n_samples, int32_t* shard_index, int shard_cap,
+                      int* shard_count, int* shard_dtype, int* total_count, void* stream);
+int dsmi_comm_gather_text(dsmi_comm* c, int root, const char* text, int text_stride, const int32_t* shard_index, int shard_count,
+                          int total_count, char* all_text, void* stream);
 
 #ifdef __cplusplus
 }

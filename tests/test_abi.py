@@ -50,3 +50,16 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_native, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_native.NativeLibraryMissing):
         _native.lib()
+
+
+def test_header_is_plain_c(tmp_path):
+    """The boundary is a C ABI: include/dsmi.h must compile as C99 on its own (no C++ or HIP types in the signatures)."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    src = tmp_path / "h.c"
+    src.write_text('#include "dsmi.h"\nint main(void) { dsmi_model_desc d; (void)d; return DSMI_OK; }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), "-fsyntax-only", str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

@@ -150,3 +150,28 @@ def test_c_host_example_equals_python_surface(tmp_path):
     assert r.returncode == 0, r.stderr
     want = rec.recognize(load_audio(wav))
     assert len(want) >= 10 and r.stdout.splitlines() == [want, want]
+
+
+def test_comm_two_ranks_over_mock_transport(tmp_path):
+    """The N > 1 loops of comm.hip (plan, slice offsets, grouped sends / receives, gather rows, fewer clips than ranks) with
+    TWO rank processes on this box's single GPU.  RCCL refuses two ranks on one device, so the transport is
+    tests/mock_rccl.c -- same entry points, messages as files -- loaded through DSMI_RCCL_LIBRARY; everything above it
+    (device buffers, staging, the session's device-resident path) is the product code."""
+    import os
+    import shutil
+    import subprocess
+    import sys
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    here = os.path.dirname(os.path.abspath(__file__))
+    mock = str(tmp_path / "libmock_rccl.so")
+    subprocess.run(["gcc", "-shared", "-fPIC", "-O1", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", os.path.join(here, "mock_rccl.c"), "-o", mock,
+                    "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    work = tmp_path / "work"
+    work.mkdir()
+    env = dict(os.environ, DSMI_RCCL_LIBRARY=mock, MOCK_RCCL_DIR=str(work))
+    procs = [subprocess.Popen([sys.executable, os.path.join(here, "_comm_rank.py"), str(r), "2", str(work)], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert (work / "ok").exists()

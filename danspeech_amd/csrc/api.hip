@@ -69,21 +69,23 @@ static void timer_resolve(dsmi_model* m) {
 //    the device's PCI bus id, so HIP_VISIBLE_DEVICES remapping does not matter); a process that cannot get it runs
 //    its recurrent layers on the per-step path.  DSMI_PERSIST_SHARED=1 skips the lock (one process per GPU is
 //    guaranteed by the caller).
-//  * DSMI_PERSIST_LANES=2 splits the device into two halves: a persistent kernel whose grid fits half of the CUs
-//    takes ONE lane (handle-affine), so the recurrent layers of two batches in flight (two handles on two streams)
-//    run side by side; a kernel that needs more takes every lane.
-constexpr int kMaxLanes = 2;
-struct PersistGate { std::mutex mu; hipEvent_t ev[kMaxLanes] = {nullptr, nullptr}; int lock_fd = -1; bool lock_tried = false; int next_lane = 0; };
+//  * The device is four gate slots of a quarter of the CUs each (DSMI_PERSIST_LANES=1: one).  A persistent kernel whose grid
+//    fits a quarter takes ONE slot (handle-affine: four batches in flight on four handles and streams run their recurrent
+//    layers side by side), one that fits half takes a PAIR of slots (two batches in flight), anything else all four.
+constexpr int kMaxLanes = 4;
+struct PersistGate { std::mutex mu; hipEvent_t ev[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr}; int lock_fd = -1; bool lock_tried = false; int next_lane = 0; };
 
-// Under g->mu: make stream `s` wait for the lanes this launch needs ...
-static void gate_wait(PersistGate* g, hipStream_t s, int lane, bool all) {
-    for (int i = 0; i < kMaxLanes; ++i)
-        if ((all || i == lane) && g->ev[i]) (void)hipStreamWaitEvent(s, g->ev[i], 0);
+// slots a launch of `width` (1, 2 or kMaxLanes) takes for a handle whose home slot is `lane`: [first, first + width)
+static int gate_first(int lane, int width) { return width >= kMaxLanes ? 0 : (width == 2 ? 2 * (lane & 1) : (lane & (kMaxLanes - 1))); }
+// Under g->mu: make stream `s` wait for the slots this launch needs ...
+static void gate_wait(PersistGate* g, hipStream_t s, int lane, int width) {
+    for (int i = gate_first(lane, width); i < gate_first(lane, width) + width && i < kMaxLanes; ++i)
+        if (g->ev[i]) (void)hipStreamWaitEvent(s, g->ev[i], 0);
 }
 // ... and publish the launch on them.
-static void gate_record(PersistGate* g, hipStream_t s, int lane, bool all) {
-    for (int i = 0; i < kMaxLanes; ++i)
-        if ((all || i == lane) && g->ev[i]) (void)hipEventRecord(g->ev[i], s);
+static void gate_record(PersistGate* g, hipStream_t s, int lane, int width) {
+    for (int i = gate_first(lane, width); i < gate_first(lane, width) + width && i < kMaxLanes; ++i)
+        if (g->ev[i]) (void)hipEventRecord(g->ev[i], s);
 }
 static PersistGate* persist_gate(int device) {
     static std::mutex mu;
@@ -178,9 +180,11 @@ extern "C" int dsmi_model_create(const dsmi_model_desc* d, int device, dsmi_mode
         if (const char* ds = std::getenv("DSMI_DEBUG_DROP_SIGNAL"))
             if (std::sscanf(ds, "%d:%d:%d", &m->drop_layer, &m->drop_wg, &m->drop_step) != 3) m->drop_layer = -1;
         const char* ln = std::getenv("DSMI_PERSIST_LANES");     // default 2: two batches in flight share the CUs; 1: whole-device kernels only
-        m->lanes = (ln && std::atoi(ln) == 1) ? 1 : 2;
+        m->lanes = (ln && std::atoi(ln) == 1) ? 1 : 2;          // 1: whole-device persistent kernels only
         const char* pd = std::getenv("DSMI_PERSIST_DUO");       // 0: never the paired-tile kernel
         m->persist_duo = pd ? (std::atoi(pd) == 0 ? 0 : 1) : -1;       // -1: by the number of batches in flight
+        const char* pq = std::getenv("DSMI_PERSIST_QUAD");
+        m->persist_quad = pq ? (std::atoi(pq) == 0 ? 0 : 1) : -1;
         const char* pu = std::getenv("DSMI_PERSIST_UNITS");     // 32: the 32-unit kernel when two batches are in flight (measured slower: DESIGN.md 4)
         m->persist_units = pu ? std::atoi(pu) : 0;
         const char* pw = std::getenv("DSMI_PERSIST_WAVES");     // 4 / 8 forces the workgroup size of rnn_persist16
@@ -558,14 +562,18 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
     //        the second batch's recurrent layer runs on the other half of the chip; failing that, half-CU workgroups (one lane,
     //        the two batches share every CU); failing that, whole-CU workgroups (both lanes: the two batches take turns).
     // DSMI_PERSIST_DUO / DSMI_PERSIST_WAVES force a variant (tests, experiments).
-    bool duo = false, duo_lane = false;
-    const bool want_duo = m->persist_duo >= 0 ? m->persist_duo == 1 : m->inflight >= 2;
+    // DSMI_PERSIST_QUAD=1 (experiments; measured slower): the four-chain kernel -- both directions of two tiles
+    // per workgroup -- on ONE gate slot, a quarter of the chip (cfgA at B = 17..32: 50 CUs).
+    bool duo = false, duo_lane = false, quad = false;
+    const bool want_quad = m->persist_quad == 1;
+    if (use16 && !use32 && want_quad && m->lanes == 2) quad = rnn_persist_quad_eligible(m->geom16, B, m->n_cus / kMaxLanes);
+    const bool want_duo = !quad && (m->persist_duo >= 0 ? m->persist_duo == 1 : m->inflight >= 2);
     const int want_waves = m->persist_waves ? m->persist_waves : (m->inflight >= 2 ? 4 : 8);
     if (use16 && !use32 && want_duo) {
         duo_lane = m->lanes == 2 && rnn_persist_duo_eligible(m->geom16, B, m->n_cus / 2);
         duo = duo_lane || rnn_persist_duo_eligible(m->geom16, B, m->n_cus);
     }
-    if (use16 && !use32 && !duo) {
+    if (use16 && !use32 && !duo && !quad) {
         if (want_waves == 4 && m->lanes == 2 && rnn_persist16_half_eligible(m->geom16, B, m->n_cus, &pgroups)) waves = 4;
         else use16 = rnn_persist16_eligible(m->geom16, B, m->n_cus, &pgroups);
     }
@@ -596,11 +604,12 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
             PersistGate* gate = persist_gate(m->device);
             std::lock_guard<std::mutex> lk(gate->mu);       // wait -> launch -> record is atomic against other host threads
             static const bool force_lane = std::getenv("DSMI_PERSIST_FORCE_LANE") != nullptr;     // experiments only
-            // a half-CU / half-chip kernel takes one lane, anything else the device
-            const bool whole = !(((waves == 4 && !duo) || duo_lane || use32 || force_lane) && m->lanes == 2);
-            gate_wait(gate, s, m->lane, whole);
-            ok = use32 ? launch_rnn_persist32(pl, s) : (duo ? launch_rnn_persist_duo(pl, s) : launch_rnn_persist16(pl, s));
-            gate_record(gate, s, m->lane, whole);
+            // a quarter-chip kernel takes one slot, a half-CU / half-chip kernel a pair, anything else the device
+            const int width = m->lanes != 2 ? kMaxLanes : (quad ? 1 : (((waves == 4 && !duo) || duo_lane || use32 || force_lane) ? 2 : kMaxLanes));
+            gate_wait(gate, s, m->lane, width);
+            ok = use32 ? launch_rnn_persist32(pl, s)
+                       : (quad ? launch_rnn_persist_quad(pl, s) : (duo ? launch_rnn_persist_duo(pl, s) : launch_rnn_persist16(pl, s)));
+            gate_record(gate, s, m->lane, width);
         }
         if (ok) return;
         // (not reachable for eligible shapes; the x-projection is in the other column order, so redo it)
@@ -621,7 +630,7 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
         const int ny = m->geom.nwg * m->geom.D <= m->n_cus ? m->geom.D : 1;
         PersistGate* gate = persist_gate(m->device);
         std::lock_guard<std::mutex> lk(gate->mu);
-        gate_wait(gate, s, 0, true);                   // the first-generation kernel is sized for the whole device
+        gate_wait(gate, s, 0, kMaxLanes);              // the first-generation kernel is sized for the whole device
         bool ok = true;
         for (int d0 = 0; d0 < m->geom.D && ok; d0 += ny) {
             const double part = (double)ny;
@@ -630,7 +639,7 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
                               4.0 * part * (GH * m->desc.rnn_hidden_size + (double)To * B * (GH + 2.0 * m->desc.rnn_hidden_size)));
             ok = launch_rnn_persist(pl, s);
         }
-        gate_record(gate, s, 0, true);
+        gate_record(gate, s, 0, kMaxLanes);
         if (ok) return;
     }
     RnnStepLaunch st;

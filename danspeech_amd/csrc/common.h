@@ -188,6 +188,8 @@ bool launch_rnn_persist32(const RnnPersist16Launch& p, hipStream_t s);
 // rnn_persist_duo.hip: one workgroup carries the two 16-clip tiles of a batch in a fixed four-slot pipeline (a 32-clip
 // batch of cfgA on 100 CUs); same packed weights, x-projection order and state layout as rnn_persist16.hip.
 bool rnn_persist_duo_eligible(const RnnGeom& g16, int B, int n_cus);
+bool rnn_persist_quad_eligible(const RnnGeom& g16, int B, int n_cus);
+bool launch_rnn_persist_quad(const RnnPersist16Launch& p, hipStream_t s);
 bool launch_rnn_persist_duo(const RnnPersist16Launch& p, hipStream_t s);
 
 // head.hip

@@ -91,6 +91,7 @@ struct dsmi_model {
     int recomputed = 0;            // forwards recomputed on the per-step path so far
     unsigned spin_limit = dsmi::kPersistSpinLimit;   // DSMI_DEBUG_SPIN_LIMIT
     int drop_layer = -1, drop_wg = -1, drop_step = -1;   // DSMI_DEBUG_DROP_SIGNAL=layer:workgroup:step (tests: force a timeout)
+    int persist_quad = -1;         // DSMI_PERSIST_QUAD=1: the four-chain kernel (rnn_persist_quad.hip) where the shape allows it; opt-in, measured slower
     int persist_duo = -1;          // DSMI_PERSIST_DUO=1/0: always / never the paired-tile kernel (rnn_persist_duo.hip); -1: when two batches are in flight
     int persist_units = 0;         // DSMI_PERSIST_UNITS (16: never the 32-unit kernel)
     int persist_waves = 0;         // DSMI_PERSIST_WAVES=4/8 forces half-CU / whole-CU workgroups of rnn_persist16; 0: by the batches in flight

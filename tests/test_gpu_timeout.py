@@ -273,6 +273,25 @@ def test_paired_tile_kernel_equals_oracle_and_the_single_tile_kernels(native, ki
         np.testing.assert_allclose(outs[0][b, :ol_ref[b]], outs[1][b, :ol_ref[b]], rtol=0, atol=5e-5)
 
 
+@pytest.mark.parametrize("kind,H,B", [("gru", 800, 32), ("gru", 64, 17), ("lstm", 512, 48), ("rnn", 96, 64), ("gru", 896, 40)])
+def test_four_chain_kernel_equals_oracle(native, kind, H, B):
+    """rnn_persist_quad (opt-in, DSMI_PERSIST_QUAD=1): both directions of two tiles per workgroup -- all cell types, one
+    and two tile pairs, an odd tile count, a partial last tile, the left-over-block and the seven-k-block shapes."""
+    from oracle import torch_port as tp
+    cfg = _cfg(H, 2, kind=kind)
+    sd = syn.make_state_dict(2, kind, H, 2, seed=71, **syn.TALKATIVE)
+    x, lens = _batch(B=B, T=181, seed=72)
+    ref, ol_ref = tp.forward(sd, cfg, x, lens)
+    with _env(DSMI_PERSIST_QUAD="1"):
+        m = native.NativeModel(cfg, sd)
+    p, ol = m.forward(_dev(x), lens)
+    assert np.array_equal(ol, ol_ref) and m.recompute_count() == 0
+    pn = p.cpu().numpy()
+    for b in range(B):
+        np.testing.assert_allclose(pn[b, :ol_ref[b]], ref[b, :ol_ref[b]], rtol=0, atol=1e-4)
+    m.close()
+
+
 def test_paired_tile_kernel_timeout_is_recomputed(native):
     from oracle import torch_port as tp
     cfg = _cfg(64, 2)

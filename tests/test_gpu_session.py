@@ -138,7 +138,14 @@ def test_c_host_example_equals_python_surface(tmp_path):
     if not shutil.which("gcc"):
         pytest.skip("no gcc")
     wav = os.path.join(root, "tests", "golden", "u0013002.wav")
-    rec, sd = _engine(H=96, L=2, seed=16)
+    # only one PROCESS per GPU runs persistent kernels (the child would get the per-step path, this process the persistent
+    # one): put both on the per-step path so that the two transcripts come from the same arithmetic
+    os.environ["DSMI_RNN_MODE"] = "steps"
+    try:
+        rec, sd = _engine(H=96, L=2, seed=16)
+        want = rec.recognize(load_audio(wav))
+    finally:
+        del os.environ["DSMI_RNN_MODE"]
     eng = rec.danspeech_recognizer
     pack = str(tmp_path / "m.dsmiw")
     export_weights.write_pack(pack, sd, eng.model._cfg(), eng.labels, eng.audio_config)
@@ -146,9 +153,8 @@ def test_c_host_example_equals_python_surface(tmp_path):
     libdir = os.path.dirname(_native.LIB_PATH)
     subprocess.run(["gcc", "-std=c99", "-O2", "-Wall", "-Werror", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "host_recognize.c"),
                     "-o", exe, "-L", libdir, "-ldsmi", "-Wl,-rpath," + libdir], check=True)
-    r = subprocess.run([exe, pack, wav, wav], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([exe, pack, wav, wav], capture_output=True, text=True, timeout=600, env=dict(os.environ, DSMI_RNN_MODE="steps"))
     assert r.returncode == 0, r.stderr
-    want = rec.recognize(load_audio(wav))
     assert len(want) >= 10 and r.stdout.splitlines() == [want, want]
 
 
@@ -169,7 +175,9 @@ def test_comm_two_ranks_over_mock_transport(tmp_path):
                     "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"], check=True)
     work = tmp_path / "work"
     work.mkdir()
-    env = dict(os.environ, DSMI_RCCL_LIBRARY=mock, MOCK_RCCL_DIR=str(work))
+    # (one process per GPU gets the persistent kernels: both ranks on the per-step path, so that every transcript comes
+    # from the same arithmetic whichever rank computed it)
+    env = dict(os.environ, DSMI_RCCL_LIBRARY=mock, MOCK_RCCL_DIR=str(work), DSMI_RNN_MODE="steps")
     procs = [subprocess.Popen([sys.executable, os.path.join(here, "_comm_rank.py"), str(r), "2", str(work)], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=900)[0] for p in procs]

@@ -194,3 +194,28 @@ def make_arpa(path, order=3, n_words=5000, seed=11, ngrams_per_order=20000,
                     f.write("%.6f\t%s\n" % (lp, words))
         f.write("\n\\end\\\n")
     return vocab
+
+
+def gated_signal(plan, seed):
+    """int16 signal for the long-form segmentation tests: ``plan`` = [[n_samples, rms], ...], each stretch white noise of
+    that RMS (speech-like energy where rms is well above the script's threshold of 600, silence where it is well below)."""
+    rng = np.random.default_rng(seed)
+    parts = [np.clip(np.round(rng.standard_normal(int(n)) * float(rms)), -32768, 32767).astype(np.int16) for n, rms in plan]
+    return np.concatenate(parts)
+
+
+_C = 1024   # the simulated stream's chunk (example_scripts/video_transcribe_simulation.py:71)
+# (name, plan, seed, --offset seconds): phrases of several lengths, pauses around the 9-chunk closing rule, blips around the
+# 4-chunk keeping rule, speech in the very first chunks, speech running into the end, boundaries off the chunk grid,
+# energies hovering around the threshold, an offset start
+SEGMENT_CASES = [
+    ("phrases", [[12 * _C, 60], [20 * _C, 3000], [10 * _C, 60], [9 * _C, 3000], [9 * _C, 60], [7 * _C, 2500], [30 * _C, 60],
+                 [4 * _C, 3000], [12 * _C, 60], [5 * _C, 3000], [12 * _C, 60], [6 * _C, 3000], [11 * _C, 60]], 101, 0),
+    ("starts_speaking", [[15 * _C, 2000], [14 * _C, 50], [_C, 50], [8 * _C, 2600], [10 * _C, 50], [20 * _C, 2600]], 102, 0),
+    ("second_chunk", [[_C, 50], [9 * _C, 2000], [25 * _C, 50]], 103, 0),
+    ("off_grid", [[7 * _C + 311, 80], [13 * _C + 97, 2800], [9 * _C + 512, 80], [6 * _C + 1000, 2800], [10 * _C + 3, 80],
+                  [5 * _C + 700, 2800], [15 * _C + 5, 80]], 104, 0),
+    ("around_threshold", [[6 * _C, 560], [6 * _C, 640], [3 * _C, 590], [8 * _C, 610], [12 * _C, 580], [7 * _C, 620], [2 * _C, 600],
+                          [9 * _C, 601], [14 * _C, 599], [10 * _C, 1200], [20 * _C, 300]], 105, 0),
+    ("offset_start", [[20 * _C, 3000], [12 * _C, 60], [18 * _C, 3000], [14 * _C, 60], [9 * _C, 3000], [20 * _C, 60]], 106, 1),
+]

@@ -6,10 +6,11 @@ threshold (two chunks of lead-in when available) and closes after more than
 ceil(pause_threshold / chunk_seconds) quiet chunks; it is kept when it held more than
 ceil(phrase_threshold / chunk_seconds) chunks besides that pause.
 
-Pinning status: the script is a command-line example (argparse + a Recognizer with downloaded
-models) and cannot be imported; there is no reference test for it.  This restatement keeps the
-script's own expressions (including numpy's summation for the energy), so "parity unpinned"
-applies only in the sense that no recorded output of the script exists to compare with.
+Pinning status: PINNED to the reference itself.  The script is a command-line example whose gate lives in its
+``__main__`` block and cannot be imported as a function, so tools/gen_golden_segments.py EXECUTES the script
+(runpy, in the build container) on seeded WAV files with a recording stand-in for ``Recognizer`` and stores the
+sample ranges it hands to ``recognize()``: tests/golden/g9_segments.json.  tests/test_oracle_segmentation.py holds
+this restatement to those ranges; tests/test_gpu_recognizer.py holds ``dsmi_segment`` to them directly.
 """
 import numpy as np
 

@@ -230,6 +230,29 @@ def test_segmentation_equals_the_script_restatement(step):
     fe.close()
 
 
+def test_segmentation_equals_the_reference_script_golden():
+    """G9 (tests/golden/g9_segments.json): the sample ranges the reference's own example script handed to recognize() on
+    seeded signals (tools/gen_golden_segments.py ran the script itself) -- dsmi_segment on the int16 samples must give
+    exactly those, including the overlapping lead-in, phrases at the very start and the offset start."""
+    import hashlib
+    import json
+    from danspeech_amd import _native
+    fe = _native.NativeFrontend()
+    cases = json.load(open(os.path.join(HERE, "golden", "g9_segments.json"), encoding="utf-8"))["cases"]
+    total = 0
+    for c in cases:
+        pcm = syn.gated_signal(c["plan"], c["seed"])
+        assert hashlib.sha256(pcm.tobytes()).hexdigest() == c["sha256"]
+        pcm = pcm[c["offset_seconds"] * 16000:]
+        got = fe.segment(torch.from_numpy(pcm.copy()).cuda())                  # the script's defaults: 600, 1024, 0.55 s, 0.2 s
+        assert [[int(a), int(b)] for a, b in got] == c["segments"], c["name"]
+        got64 = fe.segment(torch.from_numpy(pcm.astype(np.float64)).cuda())     # as recognize_long passes load_audio's array
+        assert np.array_equal(got64, got)
+        total += len(got)
+    assert total >= 12
+    fe.close()
+
+
 def test_recognize_long_equals_per_phrase_recognize():
     from danspeech_amd import Recognizer
     from oracle import segmentation as oseg

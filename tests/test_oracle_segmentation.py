@@ -38,3 +38,27 @@ def test_short_pause_does_not_split_and_open_phrase_at_the_end_is_dropped():
     assert oseg.segment(_audio(25, range(18, 25)))[0] == []          # still speaking when the audio ends
     # the loop runs while iterator + step < len(audio): a recording of exactly k*step samples has k-1 hops
     assert len(oseg.segment(np.zeros(10 * STEP))[1]) == 9
+
+
+def _golden_cases():
+    import hashlib
+    import json
+    import os
+    from danspeech_amd import synthetic as syn
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g9_segments.json")
+    for c in json.load(open(path, encoding="utf-8"))["cases"]:
+        pcm = syn.gated_signal(c["plan"], c["seed"])
+        assert hashlib.sha256(pcm.tobytes()).hexdigest() == c["sha256"], "the seeded signal is not the one the fixture was made from"
+        yield c, pcm.astype(np.float64)[c["offset_seconds"] * 16000:]          # what the script's loop sees after load_audio + offset
+
+
+def test_restatement_equals_the_reference_script_itself():
+    """G9: tools/gen_golden_segments.py executed example_scripts/video_transcribe_simulation.py (the script's own loop,
+    a recording Recognizer in place of the real one) on these seeded signals; the slices it handed to recognize() are the
+    fixture.  Pins oracle/segmentation.py to the reference's behaviour, not just to its text."""
+    n = 0
+    for c, audio in _golden_cases():
+        segs, _ = oseg.segment(audio)
+        assert [list(s) for s in segs] == c["segments"], c["name"]
+        n += len(segs)
+    assert n >= 12

@@ -35,3 +35,21 @@ def test_short_and_odd_lengths():
 def test_window_matches_scipy():
     import scipy.signal.windows as W
     np.testing.assert_allclose(of.hamming_sym(320), W.hamming(320), rtol=0, atol=1e-15)
+
+
+def test_scipy_stft_agreement():
+    """A second independent STFT (scipy.signal.stft, its 'even' boundary extension = numpy/librosa 'reflect' padding,
+    'zeros' = librosa >= 0.10's constant padding), un-scaled by the window sum."""
+    import scipy.signal as ss
+    win = of.hamming_sym(320)
+    for n in (160000, 66944, 4000):
+        y = syn.make_clip(5, n)
+        for pad_mode, boundary in (("reflect", "even"), ("constant", "zeros")):
+            _, _, Z = ss.stft(y, fs=16000, window=win, nperseg=320, noverlap=160, nfft=320, boundary=boundary, padded=False,
+                              return_onesided=True)
+            Z = Z[:, :1 + n // 160] * win.sum()
+            s = np.log1p(np.abs(Z.astype(np.complex64))).astype(np.float32)
+            s = (s - s.mean()) / s.std(ddof=1)
+            got = of.spectrogram(y, pad_mode=pad_mode)
+            assert got.shape == s.shape
+            np.testing.assert_allclose(got, s, rtol=0, atol=3e-5)

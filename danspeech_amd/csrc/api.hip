@@ -1014,6 +1014,12 @@ extern "C" int dsmi_debug_persist_stamps(dsmi_model* m, int layer, int B, int To
     int rc;
     if ((rc = dsmi_reserve(m, B, Tin))) return rc;
     HIP_OK(m, hipSetDevice(m->device));
+    // diagnostics launch persistent kernels too: same rules as the product path -- one process per GPU, and the per-device gate
+    // held from here to the end (every launch below is followed by a device synchronise before the lock is released)
+    if (!persist_process_lock(m->device)) return fail(m, DSMI_ERR_INVALID, "another process holds this GPU's persistent-kernel lock");
+    PersistGate* stamp_gate = persist_gate(m->device);
+    std::lock_guard<std::mutex> stamp_lk(stamp_gate->mu);
+    HIP_OK(m, hipDeviceSynchronize());
     int pgroups = 0;
     const bool duo = std::getenv("DSMI_STAMP_DUO") && m->have16 && rnn_persist_duo_eligible(m->geom16, B, m->n_cus);
     if (duo) {          // the paired-tile kernel: stamps[workgroup][8 waves][8] = time in slots 0..3 and at the barrier behind each

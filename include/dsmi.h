@@ -185,9 +185,10 @@ int dsmi_forward(dsmi_model* m, const float* feat_dev, const int32_t* lens_host,
  * makes the next dsmi_forward fail with DSMI_ERR_TIMEOUT (its results were invalid and may have been consumed). */
 int dsmi_forward_status(dsmi_model* m);
 /* Tells the handle how many batches the caller keeps in flight on this device (each on its own handle and stream).
- * 1 (default): kernels chosen for the latency of one batch.  2: the recurrent layers use the throughput variant (32 hidden
- * units per workgroup, a 32-clip batch on 100 CUs) where the shape allows it, so that the two batches' recurrent layers run
- * side by side on disjoint halves of the chip.  Results are the same either way (within the parity bound). */
+ * 1 (default): kernels chosen for the latency of one batch (one 16-clip tile per workgroup, the whole device).  2: the
+ * recurrent layers use the paired-tile variant (a workgroup carries both tiles of a 17..32-clip batch: 100 CUs for
+ * BASELINE's 5 x BiGRU 800) where the shape allows it, so that the two batches' recurrent layers run side by side on
+ * disjoint halves of the chip.  Results are the same either way (within the parity bound). */
 int dsmi_model_set_inflight(dsmi_model* m, int batches);
 /* Number of batches / layers this handle had to recompute after a hand-off timeout (0 in normal operation). */
 int dsmi_recompute_count(const dsmi_model* m);

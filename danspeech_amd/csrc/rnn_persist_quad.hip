@@ -159,8 +159,12 @@ __global__ __launch_bounds__(QNT, 2) void rnn_persist_quad_kernel(QuadArgs p) {
     f16x8 hv[NKW][2];
     f16x8 hxv[2] = {};
     int ndrain = 0, npoll = 0;                                       // LDS tickets handed out so far (per half)
+    // The barrier that ends an interval must not drain the vector-memory queue (the state request of the next interval and
+    // the x-projection operands are meant to be in flight across it): __syncthreads() carries a release fence that hipcc
+    // lowers to s_waitcnt vmcnt(0) in front of s_barrier; only the LDS traffic has to be ordered here.
+    auto interval_barrier = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     __syncthreads();
-    if (hx == 1) __syncthreads();                                    // half B runs one interval behind
+    if (hx == 1) interval_barrier();                                 // half B runs one interval behind
 
     // ---- M(c, s)
     auto phase_m = [&](auto cc, int s) __attribute__((always_inline)) {
@@ -235,7 +239,7 @@ __global__ __launch_bounds__(QNT, 2) void rnn_persist_quad_kernel(QuadArgs p) {
 #pragma unroll
             for (int g = 0; g < NG; ++g) xg[c ^ 1][g] = xr[g * QU];
         }
-        __syncthreads();
+        interval_barrier();
     };
 
     // ---- C(c, s)
@@ -318,7 +322,7 @@ __global__ __launch_bounds__(QNT, 2) void rnn_persist_quad_kernel(QuadArgs p) {
             __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, h1), hrs, off, 0, 16);
             __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, h2), hrs, off + 1024u, 0, 16);
         }
-        __syncthreads();
+        interval_barrier();
     };
 
     for (int s = 0; s < p.T; ++s) {
@@ -327,7 +331,7 @@ __global__ __launch_bounds__(QNT, 2) void rnn_persist_quad_kernel(QuadArgs p) {
         phase_m(std::integral_constant<int, 1>{}, s);
         phase_c(std::integral_constant<int, 1>{}, s);
     }
-    if (hx == 0) __syncthreads();                                    // half A's share of the barrier half B still owes
+    if (hx == 0) interval_barrier();                                 // half A's share of the barrier half B still owes
 }
 
 template <int KIND>

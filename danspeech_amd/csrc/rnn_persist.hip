@@ -33,6 +33,7 @@
 // requests > 80 KiB of LDS so that at most one workgroup fits a CU) and otherwise falls back
 // to the per-step path.
 #include "common.h"
+#include "rnn_cell.h"
 #include <cstring>
 
 namespace dsmi {
@@ -66,8 +67,6 @@ struct PersistArgs {
 // branchy expf / tanhf: the cell sits on the critical path of every step (-0.3 us of 4.56 per step).  Absolute
 // error ~1e-7 on outputs in [-1, 1] -- tanh(x) = 1 - 2 / (1 + e^2x) loses RELATIVE accuracy near 0 but h is consumed
 // at absolute scale -- measured end to end: same parity margins as libm (tests/test_gpu_parity.py).
-__device__ __forceinline__ float psigmoid(float v) { return __frcp_rn(1.f + __expf(-v)); }
-__device__ __forceinline__ float ptanh(float v) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * v)); }
 
 #define PSTAMP(k)                                                                         \
     do {                                                                                  \
@@ -224,23 +223,7 @@ __global__ __launch_bounds__(PNT) void rnn_persist_kernel(PersistArgs p) {
                     for (int k = 0; k < PNW; ++k) sum += red[(k * 32 + row) * RP + ebl];
                     hg[g] = sum + bh[g];
                 }
-                if (KIND == DSMI_RNN_GRU) {
-                    const float r = psigmoid(xg[0] + hg[0]);
-                    const float zz = psigmoid(xg[1] + hg[1]);
-                    const float n = ptanh(xg[2] + r * hg[2]);
-                    hn = (1.f - zz) * n + zz * hprev_own;
-                } else if (KIND == DSMI_RNN_LSTM) {
-                    const float ig = psigmoid(xg[0] + hg[0]);
-                    const float fg = psigmoid(xg[1] + hg[1]);
-                    const float gg = ptanh(xg[2] + hg[2]);
-                    const float og = psigmoid(xg[3] + hg[3]);
-                    const float cn = fg * cprev_own + ig * gg;
-                    hn = og * ptanh(cn);
-                    if (t < mylen) cprev_own = cn;
-                } else {
-                    hn = ptanh(xg[0] + hg[0]);
-                }
-                if (t >= mylen) hn = 0.f;         // pad_packed_sequence zero; the reverse chain stays at 0 until len-1
+                hn = rnn_cell<KIND>(xg, hg, hprev_own, cprev_own, t < mylen);
                 hprev_own = hn;
                 if (MULTI) { st_h[z * PU * 32 + tid] = hn; if (KIND == DSMI_RNN_LSTM) st_c[z * PU * 32 + tid] = cprev_own; }
                 p.out[d][((size_t)t * p.B + eb) * p.Hs + eunit] = hn;

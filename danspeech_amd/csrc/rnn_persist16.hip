@@ -19,6 +19,7 @@
 //   state, per parity and chain: [kb][plane 2][kg 4][clip j 16][8 fp16]   (one 1-KiB MFMA B operand per (kb, plane))
 //   x-projection: geometry U = 16 (make_rnn_geom_u), one workgroup's G x 16 gate columns contiguous.
 #include "common.h"
+#include "rnn_cell.h"
 #include <cstring>
 
 namespace dsmi {
@@ -63,8 +64,6 @@ struct P16Args {
         }                                                                                 \
     } while (0)
 
-__device__ __forceinline__ float qsigmoid(float v) { return __frcp_rn(1.f + __expf(-v)); }
-__device__ __forceinline__ float qtanh(float v) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * v)); }
 
 // KIND: cell type; NKW: compile-time bound of the 32-wide k-blocks one wave owns; NWV: waves per workgroup.
 // NWV = 8: one workgroup per CU (two waves per SIMD, <= 256 registers each).
@@ -245,23 +244,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void rnn_persist16_kern
                         for (int k = 0; k < NWV; ++k) sum += red[((k * 4 + g) * 16 + cu) * QRP + cj];
                         hg[g] = sum + bh[g];
                     }
-                    if (KIND == DSMI_RNN_GRU) {
-                        const float r = qsigmoid(xg[0] + hg[0]);
-                        const float zz = qsigmoid(xg[1] + hg[1]);
-                        const float n = qtanh(xg[2] + r * hg[2]);
-                        hn = (1.f - zz) * n + zz * hprev_own;
-                    } else if (KIND == DSMI_RNN_LSTM) {
-                        const float ig = qsigmoid(xg[0] + hg[0]);
-                        const float fg = qsigmoid(xg[1] + hg[1]);
-                        const float gg = qtanh(xg[2] + hg[2]);
-                        const float og = qsigmoid(xg[3] + hg[3]);
-                        const float cn = fg * cprev_own + ig * gg;
-                        hn = og * qtanh(cn);
-                        if (t < mylen) cprev_own = cn;
-                    } else {
-                        hn = qtanh(xg[0] + hg[0]);
-                    }
-                    if (t >= mylen) hn = 0.f;         // pad_packed_sequence zero; the reverse chain stays at 0 until len-1
+                    hn = rnn_cell<KIND>(xg, hg, hprev_own, cprev_own, t < mylen);
                     hprev_own = hn;
                     if (multi) { st_h[z * 256 + tid] = hn; if (KIND == DSMI_RNN_LSTM) st_c[z * 256 + tid] = cprev_own; }
                     p.out[d][((size_t)t * p.B + eb) * p.Hs + cunit] = hn;
@@ -462,23 +445,7 @@ __global__ __launch_bounds__(QNT) void rnn_persist16_pipe_kernel(P16Args p) {
                     for (int k = 0; k < QNW; ++k) sum += red[((k * 4 + g) * 16 + cu) * QRP + cj];
                     hg[g] = sum + bh[g];
                 }
-                if (KIND == DSMI_RNN_GRU) {
-                    const float r = qsigmoid(xg[0] + hg[0]);
-                    const float zz = qsigmoid(xg[1] + hg[1]);
-                    const float n = qtanh(xg[2] + r * hg[2]);
-                    hn = (1.f - zz) * n + zz * hprev_own;
-                } else if (KIND == DSMI_RNN_LSTM) {
-                    const float ig = qsigmoid(xg[0] + hg[0]);
-                    const float fg = qsigmoid(xg[1] + hg[1]);
-                    const float gg = qtanh(xg[2] + hg[2]);
-                    const float og = qsigmoid(xg[3] + hg[3]);
-                    const float cn = fg * cprev_own + ig * gg;
-                    hn = og * qtanh(cn);
-                    if (t < mylen) cprev_own = cn;
-                } else {
-                    hn = qtanh(xg[0] + hg[0]);
-                }
-                if (t >= mylen) hn = 0.f;
+                hn = rnn_cell<KIND>(xg, hg, hprev_own, cprev_own, t < mylen);
                 st_h[z * 256 + tid] = hn;
                 if (KIND == DSMI_RNN_LSTM) st_c[z * 256 + tid] = cprev_own;
                 p.out[d][((size_t)t * p.B + eb) * p.Hs + cunit] = hn;

@@ -18,6 +18,7 @@
 // 100 CUs.  Alone it is slower per step than the 16-unit kernel (twice the MFMAs behind one state load), so it is used
 // when the handle has been told that two batches are in flight (dsmi_model_set_inflight).
 #include "common.h"
+#include "rnn_cell.h"
 #include <cstring>
 
 namespace dsmi {
@@ -46,31 +47,6 @@ struct P32Args {
     unsigned spin_limit;
     int drop_wg, drop_step;
 };
-
-__device__ __forceinline__ float rsigmoid(float v) { return __frcp_rn(1.f + __expf(-v)); }
-__device__ __forceinline__ float rtanh(float v) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * v)); }
-
-template <int KIND>
-__device__ __forceinline__ float cell(const float* xg, const float* hg, float hprev, float& cprev, bool live) {
-    float hn;
-    if (KIND == DSMI_RNN_GRU) {
-        const float r = rsigmoid(xg[0] + hg[0]);
-        const float zz = rsigmoid(xg[1] + hg[1]);
-        const float n = rtanh(xg[2] + r * hg[2]);
-        hn = (1.f - zz) * n + zz * hprev;
-    } else if (KIND == DSMI_RNN_LSTM) {
-        const float ig = rsigmoid(xg[0] + hg[0]);
-        const float fg = rsigmoid(xg[1] + hg[1]);
-        const float gg = rtanh(xg[2] + hg[2]);
-        const float og = rsigmoid(xg[3] + hg[3]);
-        const float cn = fg * cprev + ig * gg;
-        hn = og * rtanh(cn);
-        if (live) cprev = cn;
-    } else {
-        hn = rtanh(xg[0] + hg[0]);
-    }
-    return live ? hn : 0.f;            // pad_packed_sequence zero; the reverse chain stays at 0 until len-1
-}
 
 template <int KIND, int NKW>
 __global__ __launch_bounds__(RNT, 1) void rnn_persist32_kernel(P32Args p) {
@@ -254,7 +230,7 @@ __global__ __launch_bounds__(RNT, 1) void rnn_persist32_kernel(P32Args p) {
                         for (int k = 0; k < RNW; ++k) sum += red[((k * 8 + g * 2 + r) * 16 + cu) * RRP + cj];
                         hg[g] = sum + bh[r][g];
                     }
-                    hn = cell<KIND>(xg[r], hg, hprev[r], cprev[r], t < mylen);
+                    hn = rnn_cell<KIND>(xg[r], hg, hprev[r], cprev[r], t < mylen);
                     hprev[r] = hn;
                     if (multi) { st_h[z * 512 + r * 256 + tid] = hn; if (KIND == DSMI_RNN_LSTM) st_c[z * 512 + r * 256 + tid] = cprev[r]; }
                     p.out[d][((size_t)t * p.B + eb) * p.Hs + cunit[r]] = hn;

@@ -24,6 +24,7 @@
 // advance in lockstep anti-phase chip-wide.  A signal leaves ~0.45 us into a drain slot and its poll starts ~0.5 us later,
 // when most of the hand-off latency has passed.
 #include "common.h"
+#include "rnn_cell.h"
 #include <cstdlib>
 #include <cstring>
 
@@ -54,8 +55,6 @@ struct DuoArgs {
     unsigned long long* dbg;   // diagnostics build only: per wave, time in each of its four slots [0..3] and at the barrier behind it [4..7]
 };
 
-__device__ __forceinline__ float dsigmoid(float v) { return __frcp_rn(1.f + __expf(-v)); }
-__device__ __forceinline__ float dtanh(float v) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * v)); }
 
 // TAIL: the k-blocks do not divide by the half's four waves (H = 800: 25).  Instead of one wave carrying a whole extra block
 // (9 more MFMAs and its W_hh fragments in LDS, the slot as long as that wave), every wave takes nkb / 4 full blocks and the
@@ -236,23 +235,7 @@ __global__ __launch_bounds__(DNT, 2) void rnn_persist_duo_kernel(DuoArgs p) {
                         for (int q = 0; q < 4; ++q) sum += red[((q * 4 + g) * 16 + cu) * DRP + cj];
                         hg[g] = sum + bh[g];
                     }
-                    if (KIND == DSMI_RNN_GRU) {
-                        const float r = dsigmoid(xg[0] + hg[0]);
-                        const float zz = dsigmoid(xg[1] + hg[1]);
-                        const float n = dtanh(xg[2] + r * hg[2]);
-                        hn = (1.f - zz) * n + zz * hprev_own;
-                    } else if (KIND == DSMI_RNN_LSTM) {
-                        const float ig = dsigmoid(xg[0] + hg[0]);
-                        const float fg = dsigmoid(xg[1] + hg[1]);
-                        const float gg = dtanh(xg[2] + hg[2]);
-                        const float og = dsigmoid(xg[3] + hg[3]);
-                        const float cn = fg * cprev_own + ig * gg;
-                        hn = og * dtanh(cn);
-                        if (t < mylen) cprev_own = cn;
-                    } else {
-                        hn = dtanh(xg[0] + hg[0]);
-                    }
-                    if (t >= mylen) hn = 0.f;         // pad_packed_sequence zero; the reverse chain stays at 0 until len-1
+                    hn = rnn_cell<KIND>(xg, hg, hprev_own, cprev_own, t < mylen);
                     hprev_own = hn;
                     p.out[d][((size_t)t * p.B + eb) * p.Hs + cunit] = hn;
                 } else if (cj < nb && cunit < p.Hs) {

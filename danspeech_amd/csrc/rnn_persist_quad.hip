@@ -33,6 +33,7 @@
 // A workgroup barrier ends every interval: all CUs run the same phase pattern, which is what keeps 50-workgroup chains
 // from running at the sum of everybody's busy parts (rnn_persist_duo.hip, header).
 #include "common.h"
+#include "rnn_cell.h"
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -63,8 +64,6 @@ struct QuadArgs {
     int drop_wg, drop_step;
 };
 
-__device__ __forceinline__ float qsigmoid(float v) { return __frcp_rn(1.f + __expf(-v)); }
-__device__ __forceinline__ float qtanh(float v) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * v)); }
 
 // TAIL: see rnn_persist_duo.hip -- the k-blocks left over by the four-way split are dealt out gate by gate.
 template <int KIND, int NKW, bool TAIL>
@@ -295,23 +294,7 @@ __global__ __launch_bounds__(QNT, 2) void rnn_persist_quad_kernel(QuadArgs p) {
                     for (int q = 0; q < 4; ++q) sum += red[((q * 4 + g) * 16 + cu) * QRP + cj];
                     hg[g] = sum + bh[g];
                 }
-                if constexpr (KIND == DSMI_RNN_GRU) {
-                    const float r = qsigmoid(xg[c][0] + hg[0]);
-                    const float zz = qsigmoid(xg[c][1] + hg[1]);
-                    const float n = qtanh(xg[c][2] + r * hg[2]);
-                    hn = (1.f - zz) * n + zz * hprev[c];
-                } else if constexpr (KIND == DSMI_RNN_LSTM) {
-                    const float ig = qsigmoid(xg[c][0] + hg[0]);
-                    const float fg = qsigmoid(xg[c][1] + hg[1]);
-                    const float gg = qtanh(xg[c][2] + hg[2]);
-                    const float og = qsigmoid(xg[c][NG - 1] + hg[NG - 1]);
-                    const float cn = fg * cprev[c] + ig * gg;
-                    hn = og * qtanh(cn);
-                    if (t < mylen[c]) cprev[c] = cn;
-                } else {
-                    hn = qtanh(xg[c][0] + hg[0]);
-                }
-                if (t >= mylen[c]) hn = 0.f;          // pad_packed_sequence zero; the reverse chain stays at 0 until len-1
+                hn = rnn_cell<KIND>(xg[c], hg, hprev[c], cprev[c], t < mylen[c]);
                 hprev[c] = hn;
             }
             if (eact[c] || epad[c]) p.out[d][((size_t)t * p.B + eb[c]) * p.Hs + cunit] = hn;

@@ -374,6 +374,13 @@ extern "C" int dsmi_model_finalize(dsmi_model* m) {
     }
     m->tensors.clear();
     for (int i = 0; i < 8; ++i) HIP_OK(m, hipEventCreate(&m->ev[i]));
+    // every slot of the forward-status ring now, not on the first four forwards (a pinned allocation can take ~100 ms)
+    for (auto& f : m->fwd) {
+        if (f.done) continue;
+        HIP_OK(m, hipEventCreateWithFlags(&f.done, hipEventDisableTiming));
+        HIP_OK(m, hipHostMalloc((void**)&f.err_host, sizeof(unsigned), hipHostMallocDefault));
+        *f.err_host = 0;
+    }
     m->finalized = true;
     return DSMI_OK;
 }

@@ -257,7 +257,7 @@ __global__ __launch_bounds__(BT) void beam_kernel(BeamArgs a) {
             for (int idx = tid; idx < N; idx += BT) cnt += c_key[idx] != 0;
             cnt = wave_sum(cnt);
             if (lane == 0) wtot[wid] = cnt;
-            if (tid < 256) hist[tid] = 0;
+            for (int q = tid; q < 256; q += BT) hist[q] = 0;
             __syncthreads();
             if (tid == 0) {
                 int m = 0;
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(BT) void beam_kernel(BeamArgs a) {
                     const uint64_t k = c_key[idx];
                     if (k != 0 && (pass == 0 || (k >> (shift + 8)) == pre)) atomicAdd(&h[(unsigned)(k >> shift) & 255u], 1u);
                 }
-                if (tid >= 256 && tid < 512) hn[tid - 256] = 0;
+                for (int q = tid; q < 256; q += BT) hn[q] = 0;       // (the other histogram: nobody counts into it in this pass)
                 __syncthreads();
                 if (wid == 0) {
                     // lane l owns bins 4l .. 4l+3; suffix sums from the top bin down

@@ -93,7 +93,9 @@ __global__ __launch_bounds__(BT) void beam_kernel(BeamArgs a) {
     double* e_ext = e_rep + BW;
     uint64_t* c_key = reinterpret_cast<uint64_t*>(e_ext + BW);        // [NMAX] 0 = no candidate, else okey(logp)
     uint64_t* su = c_key + NMAX;                                      // [2] scalars (radix prefix)
-    int* e_node = reinterpret_cast<int*>(su + 2);                     // [2][BW]
+    uint64_t* wkmin = su + 2;                                         // [NWAVE] per-wave smallest / largest candidate key
+    uint64_t* wkmax = wkmin + NWAVE;
+    int* e_node = reinterpret_cast<int*>(wkmax + NWAVE);              // [2][BW]
     int* e_ch = e_node + 2 * BW;                                      // [2][BW]
     int* e_ds = e_ch + 2 * BW;                                        // [2][BW] dictionary state of the entry's node
     int* c_child = e_ds + 2 * BW;                                     // [NMAX]
@@ -110,6 +112,7 @@ __global__ __launch_bounds__(BT) void beam_kernel(BeamArgs a) {
 #define s_kk si[4]
 #define s_done si[5]
 #define s_nnew si[6]
+#define s_pass0 si[7]
 #define s_mincut sd[0]
 #define s_prefix su[0]
 
@@ -254,15 +257,27 @@ __global__ __launch_bounds__(BT) void beam_kernel(BeamArgs a) {
         // ---- 3. exact top-BW selection
         {
             int cnt = 0;
-            for (int idx = tid; idx < N; idx += BT) cnt += c_key[idx] != 0;
+            uint64_t kmin = ~0ull, kmax = 0;
+            for (int idx = tid; idx < N; idx += BT) {
+                const uint64_t k = c_key[idx];
+                if (k != 0) { ++cnt; kmin = k < kmin ? k : kmin; kmax = k > kmax ? k : kmax; }
+            }
             cnt = wave_sum(cnt);
-            if (lane == 0) wtot[wid] = cnt;
-            for (int q = tid; q < 256; q += BT) hist[q] = 0;
+            for (int o = 32; o > 0; o >>= 1) {
+                const uint64_t a0 = __shfl_xor(kmin, o, 64), a1 = __shfl_xor(kmax, o, 64);
+                kmin = a0 < kmin ? a0 : kmin; kmax = a1 > kmax ? a1 : kmax;
+            }
+            if (lane == 0) { wtot[wid] = cnt; wkmin[wid] = kmin; wkmax[wid] = kmax; }
+            for (int q = tid; q < 512; q += BT) hist[q] = 0;      // both histograms: the first pass may be an odd one
             __syncthreads();
             if (tid == 0) {
                 int m = 0;
-                for (int w = 0; w < NWAVE; ++w) m += wtot[w];
-                s_m = m; s_prefix = 0; s_kk = BW; s_done = 0;
+                uint64_t lo = ~0ull, hi = 0;
+                for (int w = 0; w < NWAVE; ++w) { m += wtot[w]; lo = wkmin[w] < lo ? wkmin[w] : lo; hi = wkmax[w] > hi ? wkmax[w] : hi; }
+                // the radix select starts at the first byte in which the candidates differ at all (scores of one frame share
+                // sign, exponent and often the leading mantissa bits: the passes over those bytes would select nothing)
+                const int skip = (m > 0 && lo != hi) ? __builtin_clzll(lo ^ hi) >> 3 : 0;
+                s_m = m; s_prefix = skip ? hi >> (64 - 8 * skip) : 0; s_kk = BW; s_done = 0; s_pass0 = skip;
             }
             __syncthreads();
         }
@@ -271,7 +286,7 @@ __global__ __launch_bounds__(BT) void beam_kernel(BeamArgs a) {
             for (int idx = tid; idx < N; idx += BT) c_surv[idx] = c_key[idx] != 0;
         } else {
             // radix select, 8 bits per pass from the top; stops as soon as the threshold bin is taken whole
-            int pass = 0;
+            int pass = s_pass0;
             for (; pass < 8; ++pass) {
                 const int shift = 56 - 8 * pass;
                 unsigned* h = hist + (pass & 1) * 256;
@@ -605,7 +620,7 @@ extern "C" int dsmi_beam(dsmi_decoder* d, const float* probs, const int32_t* siz
     const int C = (int)d->labels.size();
     if (!probs || !tokens || !tsteps || !lens || !scores || B < 1 || To < 1 || beam < 1) { d->err = "bad beam arguments"; return DSMI_ERR_INVALID; }
     const size_t NMAX = (size_t)beam * (C + 1);
-    const size_t lds = sizeof(double) * (128 + 2 + 6 * (size_t)beam + 3 * (size_t)beam) + sizeof(uint64_t) * (NMAX + 2) +
+    const size_t lds = sizeof(double) * (128 + 2 + 6 * (size_t)beam + 3 * (size_t)beam) + sizeof(uint64_t) * (NMAX + 2 + 2 * NWAVE) +
                        sizeof(int) * (6 * (size_t)beam + 2 * NMAX + (size_t)beam + 128) + sizeof(unsigned) * 512 +
                        sizeof(int) * (NWAVE + 1 + 8) + 64;
     if (lds > 160 * 1024 - 256) { d->err = "beam_width * (n_labels + 1) exceeds the on-chip candidate buffer"; return DSMI_ERR_CAPACITY; }

@@ -119,14 +119,20 @@ class BeamCTCDecoder(Decoder):
         tok, ts, ln, sc = dec.beam(probs, sz, beam_width=self.beam_width, cutoff_top_n=self.cutoff_top_n,
                                    cutoff_prob=self.cutoff_prob)
         self.last_scores = sc      # the reference drops ctcdecode's scores (decoder.py:140); kept for inspection
-        strings, offsets = [], []
-        ts_t = torch.from_numpy(ts)
-        for b in range(tok.shape[0]):
-            su, ou = [], []
-            for p in range(tok.shape[1]):
-                n = int(ln[b, p])
-                su.append(self._to_string(tok[b, p, :n]) if n > 0 else "")
-                ou.append(ts_t[b, p, :n])
-            strings.append(su)
-            offsets.append(ou)
+        # label strings and emission offsets of every beam, built in bulk: the valid prefixes of all beams are gathered
+        # once (a few hundred thousand ids instead of B x beam x T), turned into ONE string, and cut by length
+        B, W = tok.shape[0], tok.shape[1]
+        lmax = int(ln.max()) if ln.size else 0
+        valid = np.arange(lmax, dtype=np.int32)[None, None, :] < ln[:, :, None]
+        flat_len = ln.reshape(-1).tolist()
+        flat_ts = torch.split(torch.from_numpy(ts[:, :, :lmax][valid]), flat_len)
+        ids = tok[:, :, :lmax][valid]
+        cuts = np.concatenate(([0], np.cumsum(ln.reshape(-1), dtype=np.int64))).tolist()
+        if self._code_points is not None:
+            big = self._code_points[ids].tobytes().decode("utf-32-le")
+            flat_str = [big[cuts[k]:cuts[k + 1]] for k in range(B * W)]
+        else:
+            flat_str = ["".join(self.int_to_char[int(i)] for i in ids[cuts[k]:cuts[k + 1]]) for k in range(B * W)]
+        strings = [flat_str[b * W:(b + 1) * W] for b in range(B)]
+        offsets = [list(flat_ts[b * W:(b + 1) * W]) for b in range(B)]
         return strings, offsets

@@ -59,10 +59,11 @@ class _StreamingSession(object):
 
 class _BatchJob(object):
     """One batch between enqueue and decode."""
-    __slots__ = ("order", "probs", "sizes", "count", "model")
+    __slots__ = ("order", "probs", "sizes", "count", "model", "ticket")
 
     def __init__(self, order, probs, sizes, count, model):
         self.order, self.probs, self.sizes, self.count, self.model = order, probs, sizes, count, model
+        self.ticket = None                       # a beam search launched behind the forward (transcribe_batches)
 
 
 class DanSpeechRecognizer(object):
@@ -130,7 +131,7 @@ class DanSpeechRecognizer(object):
             self._side_streams[key] = torch.cuda.Stream(device=key[1])
         return self._side_streams[key]
 
-    def _enqueue_batch(self, recordings, model=None, parser=None):
+    def _enqueue_batch(self, recordings, model=None, parser=None, decode_slot=None):
         """Stage + upload + spectrograms + forward of one batch, all asynchronous.  Clips run longest first
         (pack_padded_sequence's order, reference model.py:117)."""
         import torch
@@ -138,15 +139,32 @@ class DanSpeechRecognizer(object):
         order = np.argsort([-len(r) for r in recordings], kind="stable")
         feats, frames = (parser or self.audio_parser).parse_batch([recordings[i] for i in order])
         probs, sizes = model.enqueue(feats, torch.from_numpy(frames.astype(np.int32)))
-        return _BatchJob(order, probs, sizes, len(recordings), model)
+        job = _BatchJob(order, probs, sizes, len(recordings), model)
+        if decode_slot is not None and hasattr(self.decoder, "decode_enqueue"):
+            # the beam search is a kernel: launched now, behind this forward, on a stream of its own, so that the host
+            # never waits for it while it could be feeding the next batch
+            side = self._side_stream("decode")           # one decode stream for both slots: see audio/parsers.py on hardware queues
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(self._device_index()))
+            side.wait_event(done)
+            probs.record_stream(side)
+            with torch.cuda.stream(side):
+                job.ticket = self.decoder.decode_enqueue(probs, sizes, slot=decode_slot)
+        return job
 
     def _finish_batch(self, job, show_all, warn=True):
         import torch
-        job.model.collect()                      # waits for the forward; a timed-out batch has been recomputed by now
+        recomputed = job.model.collect()         # waits for the forward; a timed-out batch has been recomputed by now
         side = self._side_stream("decode")
         job.probs.record_stream(side)
-        with torch.cuda.stream(side):
-            decoded, _ = self.decoder.decode(job.probs, job.sizes)
+        decoded = None
+        if getattr(job, "ticket", None) is not None:
+            decoded, _ = self.decoder.decode_collect(job.ticket)      # the search launched behind the forward ...
+            if recomputed:
+                decoded = None                                         # ... read the probabilities of a forward that had to be redone
+        if decoded is None:
+            with torch.cuda.stream(side):
+                decoded, _ = self.decoder.decode(job.probs, job.sizes)
         if warn and show_all and self.lm == "greedy":
             warnings.warn("You are trying to get all beams but no LM has been instantiated.", NoLmInstantiatedWarning)
         results = [None] * job.count
@@ -181,7 +199,7 @@ class DanSpeechRecognizer(object):
             job = None
             if len(recordings):
                 with torch.cuda.stream(streams[turn]):
-                    job = self._enqueue_batch(recordings, handles[turn], parsers[turn])
+                    job = self._enqueue_batch(recordings, handles[turn], parsers[turn], decode_slot=turn)
                 turn ^= 1
             if waiting is not None:
                 yield self._finish_batch(waiting, show_all) if waiting != "empty" else []

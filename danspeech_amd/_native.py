@@ -107,6 +107,8 @@ _PROTOS = {
     "dsmi_lm_word_index": (C.c_int, [_vp, C.c_char_p]),
     "dsmi_lm_lookup": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "dsmi_lm_cond_log10": (C.c_double, [_vp, _vp, C.c_int]),
+    "dsmi_beam_enqueue": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _vp]),
+    "dsmi_beam_collect": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "dsmi_model_info": (C.c_int, [_vp, C.POINTER(ModelDesc), C.POINTER(C.c_int)]),
     "dsmi_frontend_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "dsmi_decoder_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -533,15 +535,25 @@ class NativeDecoder:
 
     def beam(self, probs, sizes=None, beam_width=64, cutoff_top_n=40, cutoff_prob=1.0):
         """probs: CUDA [B,T,C] -> (tokens [B,beam,T], timesteps [B,beam,T], lens [B,beam], scores [B,beam])."""
+        self.beam_enqueue(probs, sizes, beam_width, cutoff_top_n, cutoff_prob)
+        return self.beam_collect()
+
+    def beam_enqueue(self, probs, sizes=None, beam_width=64, cutoff_top_n=40, cutoff_prob=1.0):
+        """Launch the search on the current stream and return at once; ``beam_collect`` waits and returns the arrays."""
         B, T = probs.shape[0], probs.shape[1]
+        sz = None if sizes is None else np.ascontiguousarray(sizes, dtype=np.int32)
+        self._check(lib().dsmi_beam_enqueue(self._h, probs.data_ptr(), None if sz is None else _np_ptr(sz), B, T, int(beam_width),
+                                            int(cutoff_top_n), float(cutoff_prob), _stream(self.device)))
+        self._beam_pending = (probs, B, T, int(beam_width))        # keeps the probabilities alive until the collect
+
+    def beam_collect(self):
+        _, B, T, beam_width = self._beam_pending
+        self._beam_pending = None
         tok = np.zeros((B, beam_width, T), dtype=np.int32)
         ts = np.zeros((B, beam_width, T), dtype=np.int32)
         ln = np.zeros((B, beam_width), dtype=np.int32)
         sc = np.zeros((B, beam_width), dtype=np.float32)
-        sz = None if sizes is None else np.ascontiguousarray(sizes, dtype=np.int32)
-        self._check(lib().dsmi_beam(self._h, probs.data_ptr(), None if sz is None else _np_ptr(sz), B, T, int(beam_width),
-                                    int(cutoff_top_n), float(cutoff_prob), _np_ptr(tok), _np_ptr(ts), _np_ptr(ln),
-                                    _np_ptr(sc), _stream(self.device)))
+        self._check(lib().dsmi_beam_collect(self._h, _np_ptr(tok), _np_ptr(ts), _np_ptr(ln), _np_ptr(sc)))
         return tok, ts, ln, sc
 
 

@@ -7,6 +7,20 @@ tensor stays on the device (the engine's ``.to(device)`` is then a no-op).
 import numpy as np
 
 
+
+_COPY_STREAMS = {}
+
+
+def _shared_copy_stream(device):
+    """ONE upload stream per device for every parser: HIP gives a process a handful of hardware queues (four by default)
+    and maps streams onto them round robin, so every further stream is a chance that two of the pipeline's streams --
+    a forward and the other batch's beam search, say -- share a queue and run one after the other."""
+    import torch
+    if device not in _COPY_STREAMS:
+        _COPY_STREAMS[device] = torch.cuda.Stream(device=device)
+    return _COPY_STREAMS[device]
+
+
 class AudioParser(object):
     def __init__(self, audio_config=None):
         self.audio_config = audio_config
@@ -50,7 +64,7 @@ class SpectrogramAudioParser(AudioParser):
         if getattr(self, "_slots", None) is None:
             self._slots = [dict(buf=None, done=None), dict(buf=None, done=None)]
             self._turn = 0
-            self._copy_stream = torch.cuda.Stream(device=self.device)
+            self._copy_stream = _shared_copy_stream(self.device)
         slot = self._slots[self._turn]
         self._turn ^= 1
         if slot["done"] is not None:

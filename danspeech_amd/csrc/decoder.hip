@@ -506,6 +506,13 @@ struct dsmi_decoder {
     // beam workspace
     size_t ws_bytes = 0;
     unsigned char* ws = nullptr;
+    // the beam search between dsmi_beam_enqueue and dsmi_beam_collect: geometry, pinned copies of its outputs, completion event
+    bool beam_pending = false;
+    int pb_B = 0, pb_To = 0, pb_beam = 0;
+    size_t pb_out = 0, pb_out_bytes = 0; hipStream_t pb_stream = nullptr;
+    int32_t* pin_sz = nullptr; size_t pin_sz_cap = 0;
+    unsigned char* pin = nullptr; size_t pin_bytes = 0;
+    hipEvent_t beam_done = nullptr;
 };
 
 static thread_local std::string g_dec_error;
@@ -542,6 +549,9 @@ static void free_lm(dsmi_decoder* d) {
 }
 
 extern "C" void dsmi_decoder_destroy(dsmi_decoder* d) {
+    if (d && d->pin) { (void)hipSetDevice(d->device); (void)hipDeviceSynchronize(); (void)hipHostFree(d->pin); d->pin = nullptr; }
+    if (d && d->beam_done) { (void)hipEventDestroy(d->beam_done); d->beam_done = nullptr; }
+    if (d && d->pin_sz) { (void)hipHostFree(d->pin_sz); d->pin_sz = nullptr; }
     if (!d) return;
     (void)hipSetDevice(d->device);
     (void)hipDeviceSynchronize();
@@ -614,11 +624,13 @@ extern "C" int dsmi_greedy(dsmi_decoder* d, const float* probs, const int32_t* s
     return DSMI_OK;
 }
 
-extern "C" int dsmi_beam(dsmi_decoder* d, const float* probs, const int32_t* sizes, int B, int To, int beam, int cutoff_top_n,
-                         double cutoff_prob, int32_t* tokens, int32_t* tsteps, int32_t* lens, float* scores, void* stream) {
+// Launches the beam search of a batch and the copies of its results into pinned host memory, all asynchronous on `stream`.
+extern "C" int dsmi_beam_enqueue(dsmi_decoder* d, const float* probs, const int32_t* sizes, int B, int To, int beam, int cutoff_top_n,
+                                 double cutoff_prob, void* stream) {
     if (!d) return DSMI_ERR_INVALID;
     const int C = (int)d->labels.size();
-    if (!probs || !tokens || !tsteps || !lens || !scores || B < 1 || To < 1 || beam < 1) { d->err = "bad beam arguments"; return DSMI_ERR_INVALID; }
+    if (!probs || B < 1 || To < 1 || beam < 1) { d->err = "bad beam arguments"; return DSMI_ERR_INVALID; }
+    if (d->beam_pending) { d->err = "the previous beam search has not been collected"; return DSMI_ERR_INVALID; }
     const size_t NMAX = (size_t)beam * (C + 1);
     const size_t lds = sizeof(double) * (128 + 2 + 6 * (size_t)beam + 3 * (size_t)beam) + sizeof(uint64_t) * (NMAX + 2 + 2 * NWAVE) +
                        sizeof(int) * (6 * (size_t)beam + 2 * NMAX + (size_t)beam + 128) + sizeof(unsigned) * 512 +
@@ -634,11 +646,14 @@ extern "C" int dsmi_beam(dsmi_decoder* d, const float* probs, const int32_t* siz
     size_t o_child = off; off += al((size_t)B * ncap * C * 4);
     size_t o_nn = off; off += al((size_t)B * 4);
     size_t o_sizes = off; off += al((size_t)B * 4);
+    // outputs, contiguous, in the order of the pinned image: tokens, steps, lens, counts, scores
+    const size_t o_out = off;
     size_t o_tok = off; off += al((size_t)B * beam * To * 4);
     size_t o_step = off; off += al((size_t)B * beam * To * 4);
     size_t o_len = off; off += al((size_t)B * beam * 4);
     size_t o_n = off; off += al((size_t)B * 4);
     size_t o_score = off; off += al((size_t)B * beam * 8);
+    const size_t out_bytes = off - o_out;
     if (off > d->ws_bytes) {
         DEC_HIP(d, hipDeviceSynchronize());
         if (d->ws) (void)hipFree(d->ws);
@@ -646,6 +661,14 @@ extern "C" int dsmi_beam(dsmi_decoder* d, const float* probs, const int32_t* siz
         DEC_HIP(d, hipMalloc((void**)&d->ws, off));
         d->ws_bytes = off;
     }
+    if (out_bytes > d->pin_bytes) {
+        DEC_HIP(d, hipDeviceSynchronize());
+        if (d->pin) (void)hipHostFree(d->pin);
+        d->pin = nullptr; d->pin_bytes = 0;
+        DEC_HIP(d, hipHostMalloc((void**)&d->pin, out_bytes + out_bytes / 4, hipHostMallocDefault));
+        d->pin_bytes = out_bytes + out_bytes / 4;
+    }
+    if (!d->beam_done) DEC_HIP(d, hipEventCreateWithFlags(&d->beam_done, hipEventDisableTiming));
     unsigned char* w = d->ws;
     BeamArgs a{};
     a.probs = probs; a.T = To; a.C = C; a.blank = d->blank; a.space = d->space; a.beam = beam;
@@ -658,26 +681,59 @@ extern "C" int dsmi_beam(dsmi_decoder* d, const float* probs, const int32_t* siz
     a.out_score = (double*)(w + o_score);
     a.sizes = nullptr;
     if (sizes) {
-        DEC_HIP(d, hipMemcpyAsync(w + o_sizes, sizes, sizeof(int32_t) * B, hipMemcpyHostToDevice, s));
+        // through pinned memory: an asynchronous copy from pageable memory makes the HOST wait for the stream to get there
+        // (i.e. for the forward this search was queued behind), and the caller's array need not outlive this call
+        if ((size_t)B > d->pin_sz_cap) {
+            if (d->pin_sz) { DEC_HIP(d, hipDeviceSynchronize()); (void)hipHostFree(d->pin_sz); d->pin_sz = nullptr; d->pin_sz_cap = 0; }
+            DEC_HIP(d, hipHostMalloc((void**)&d->pin_sz, sizeof(int32_t) * std::max(B, 256), hipHostMallocDefault));
+            d->pin_sz_cap = (size_t)std::max(B, 256);
+        }
+        std::memcpy(d->pin_sz, sizes, sizeof(int32_t) * B);
+        DEC_HIP(d, hipMemcpyAsync(w + o_sizes, d->pin_sz, sizeof(int32_t) * B, hipMemcpyHostToDevice, s));
         a.sizes = (const int32_t*)(w + o_sizes);
     }
     DEC_HIP(d, hipMemsetAsync(w + o_len, 0, (size_t)B * beam * 4, s));
     DEC_HIP(d, hipFuncSetAttribute(reinterpret_cast<const void*>(beam_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(beam_kernel, dim3(B), dim3(BT), lds, s, a);
-    std::vector<int32_t> h_len((size_t)B * beam), h_n(B);
-    std::vector<double> h_score((size_t)B * beam);
-    DEC_HIP(d, hipMemcpyAsync(h_len.data(), w + o_len, (size_t)B * beam * 4, hipMemcpyDeviceToHost, s));
-    DEC_HIP(d, hipMemcpyAsync(h_n.data(), w + o_n, (size_t)B * 4, hipMemcpyDeviceToHost, s));
-    DEC_HIP(d, hipMemcpyAsync(h_score.data(), w + o_score, (size_t)B * beam * 8, hipMemcpyDeviceToHost, s));
-    DEC_HIP(d, hipStreamSynchronize(s));
     DEC_HIP(d, hipGetLastError());
-    // transcripts are a fraction of T_out long: bring back only the columns that hold tokens
+    // Only the kernel is queued here.  A device-to-host copy queued behind it would sit in a DMA queue until the search is
+    // over, and with it whatever upload another stream has been given the same engine for -- the next batch's samples: its
+    // forward then starts only when this search has ended (measured: two batches in flight ran one after the other).
+    DEC_HIP(d, hipEventRecord(d->beam_done, s));
+    d->beam_pending = true; d->pb_B = B; d->pb_To = To; d->pb_beam = beam; d->pb_out = o_out; d->pb_out_bytes = out_bytes; d->pb_stream = s;
+    return DSMI_OK;
+}
+
+// Waits for the enqueued beam search and hands its results over (layouts of dsmi_beam).
+extern "C" int dsmi_beam_collect(dsmi_decoder* d, int32_t* tokens, int32_t* tsteps, int32_t* lens, float* scores) {
+    if (!d) return DSMI_ERR_INVALID;
+    if (!d->beam_pending) { d->err = "no beam search enqueued"; return DSMI_ERR_INVALID; }
+    if (!tokens || !tsteps || !lens || !scores) { d->err = "bad beam arguments"; return DSMI_ERR_INVALID; }
+    d->beam_pending = false;
+    DEC_HIP(d, hipSetDevice(d->device));
+    DEC_HIP(d, hipEventSynchronize(d->beam_done));
+    const int B = d->pb_B, To = d->pb_To, beam = d->pb_beam;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t tok_bytes = al((size_t)B * beam * To * 4);
+    // lengths, counts and scores first (they are behind the two token arrays in the image) ...
+    const unsigned char* dev = d->ws + d->pb_out;
+    DEC_HIP(d, hipMemcpy(d->pin + 2 * tok_bytes, dev + 2 * tok_bytes, d->pb_out_bytes - 2 * tok_bytes, hipMemcpyDeviceToHost));
+    const unsigned char* q0 = d->pin;
+    const int32_t* p_tok = reinterpret_cast<const int32_t*>(q0); q0 += tok_bytes;
+    const int32_t* p_step = reinterpret_cast<const int32_t*>(q0); q0 += tok_bytes;
+    const int32_t* h_len = reinterpret_cast<const int32_t*>(q0); q0 += al((size_t)B * beam * 4);
+    const int32_t* h_n = reinterpret_cast<const int32_t*>(q0); q0 += al((size_t)B * 4);
+    const double* h_score = reinterpret_cast<const double*>(q0);
+    // ... then, of the token arrays, only the columns that hold tokens: transcripts are a fraction of T_out long
     int maxlen = 0;
-    for (int32_t v : h_len) maxlen = std::max(maxlen, (int)v);
+    for (size_t i = 0; i < (size_t)B * beam; ++i) maxlen = std::max(maxlen, (int)h_len[i]);
     if (maxlen > 0) {
-        DEC_HIP(d, hipMemcpy2DAsync(tokens, (size_t)To * 4, w + o_tok, (size_t)To * 4, (size_t)maxlen * 4, (size_t)B * beam, hipMemcpyDeviceToHost, s));
-        DEC_HIP(d, hipMemcpy2DAsync(tsteps, (size_t)To * 4, w + o_step, (size_t)To * 4, (size_t)maxlen * 4, (size_t)B * beam, hipMemcpyDeviceToHost, s));
-        DEC_HIP(d, hipStreamSynchronize(s));
+        DEC_HIP(d, hipMemcpy2D(d->pin, (size_t)To * 4, dev, (size_t)To * 4, (size_t)maxlen * 4, (size_t)B * beam, hipMemcpyDeviceToHost));
+        DEC_HIP(d, hipMemcpy2D(d->pin + tok_bytes, (size_t)To * 4, dev + tok_bytes, (size_t)To * 4, (size_t)maxlen * 4, (size_t)B * beam, hipMemcpyDeviceToHost));
+    }
+    for (size_t r = 0; r < (size_t)B * beam && maxlen > 0; ++r) {
+        std::memcpy(tokens + r * To, p_tok + r * To, (size_t)maxlen * 4);
+        std::memcpy(tsteps + r * To, p_step + r * To, (size_t)maxlen * 4);
     }
     // ---- ctcdecode "approx_ctc": strip the word bonus and the LM weight; score = -approx
     for (int b = 0; b < B; ++b)
@@ -695,7 +751,7 @@ extern "C" int dsmi_beam(dsmi_decoder* d, const float* probs, const int32_t* siz
                     words.push_back(it == d->lm.word2id.end() ? -1 : it->second);
                     cur.clear();
                 };
-                const int32_t* tk = tokens + q * To;
+                const int32_t* tk = p_tok + q * To;
                 for (int k = 0; k < h_len[q]; ++k) { if (tk[k] == d->space) flush(); else cur += d->labels[tk[k]]; }
                 flush();
                 approx -= (double)h_len[q] * d->beta;
@@ -704,6 +760,15 @@ extern "C" int dsmi_beam(dsmi_decoder* d, const float* probs, const int32_t* siz
             scores[q] = (float)-approx;
         }
     return DSMI_OK;
+}
+
+extern "C" int dsmi_beam(dsmi_decoder* d, const float* probs, const int32_t* sizes, int B, int To, int beam, int cutoff_top_n,
+                         double cutoff_prob, int32_t* tokens, int32_t* tsteps, int32_t* lens, float* scores, void* stream) {
+    if (!d) return DSMI_ERR_INVALID;
+    if (!tokens || !tsteps || !lens || !scores) { d->err = "bad beam arguments"; return DSMI_ERR_INVALID; }
+    const int rc = dsmi_beam_enqueue(d, probs, sizes, B, To, beam, cutoff_top_n, cutoff_prob, stream);
+    if (rc) return rc;
+    return dsmi_beam_collect(d, tokens, tsteps, lens, scores);
 }
 
 

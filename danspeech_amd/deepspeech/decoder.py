@@ -40,15 +40,26 @@ class Decoder(object):
             return self._code_points[ids].tobytes().decode("utf-32-le")
         return "".join(self.int_to_char[int(i)] for i in ids)
 
-    def _dec(self, device_index):
+    def _dec(self, device_index, slot=0):
+        """The native handle; ``slot`` > 0: a further handle with its own workspaces, for a caller that keeps several
+        decodes in flight (one search per handle at a time)."""
         from .. import _native
         if self._native is None or self._native_device != device_index:
             if self._native is not None:
                 self._native.close()
+            for extra in getattr(self, "_native_slots", {}).values():
+                extra.close()
+            self._native_slots = {}
             self._native = _native.NativeDecoder(self.labels, blank_index=self.blank_index, device=device_index)
             self._native_device = device_index
             self._configure(self._native)
-        return self._native
+        if slot == 0:
+            return self._native
+        slots = self.__dict__.setdefault("_native_slots", {})
+        if slot not in slots:
+            slots[slot] = _native.NativeDecoder(self.labels, blank_index=self.blank_index, device=device_index)
+            self._configure(slots[slot])
+        return slots[slot]
 
     def _configure(self, native):
         pass
@@ -112,12 +123,21 @@ class BeamCTCDecoder(Decoder):
         native.set_lm(self.lm_path, self.alpha, self.beta)
 
     def decode(self, probs, sizes=None):
+        return self.decode_collect(self.decode_enqueue(probs, sizes))
+
+    def decode_enqueue(self, probs, sizes=None, slot=0):
+        """Launch the search on the current stream and return a ticket at once (the search is a kernel; ctcdecode's
+        thread pool has no counterpart).  ``decode_collect(ticket)`` waits and builds the strings."""
         import torch
         probs = self._on_gpu(probs)
-        dec = self._dec(probs.device.index or 0)
+        dec = self._dec(probs.device.index or 0, slot)
         sz = None if sizes is None else np.asarray(torch.as_tensor(sizes).cpu()).astype(np.int32)
-        tok, ts, ln, sc = dec.beam(probs, sz, beam_width=self.beam_width, cutoff_top_n=self.cutoff_top_n,
-                                   cutoff_prob=self.cutoff_prob)
+        dec.beam_enqueue(probs, sz, beam_width=self.beam_width, cutoff_top_n=self.cutoff_top_n, cutoff_prob=self.cutoff_prob)
+        return dec
+
+    def decode_collect(self, ticket):
+        import torch
+        tok, ts, ln, sc = ticket.beam_collect()
         self.last_scores = sc      # the reference drops ctcdecode's scores (decoder.py:140); kept for inspection
         # label strings and emission offsets of every beam, built in bulk: the valid prefixes of all beams are gathered
         # once (a few hundred thousand ids instead of B x beam x T), turned into ONE string, and cut by length

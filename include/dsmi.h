@@ -254,6 +254,13 @@ int dsmi_decoder_set_lm(dsmi_decoder* d, const char* lm_path, double alpha, doub
 int dsmi_beam(dsmi_decoder* d, const float* probs_dev, const int32_t* sizes_host, int B, int T_out,
               int beam_width, int cutoff_top_n, double cutoff_prob, int32_t* tokens_host,
               int32_t* tsteps_host, int32_t* lens_host, float* scores_host, void* stream);
+/* The two halves of dsmi_beam, for callers that keep the GPU busy meanwhile (ctcdecode decodes on a host thread pool while
+ * the caller waits; here the search itself is a kernel): dsmi_beam_enqueue launches the search and the copies of its results
+ * into pinned memory of the handle, asynchronously on `stream` (probs_dev must stay valid until the collect);
+ * dsmi_beam_collect waits for them and fills the arrays.  One search per decoder handle at a time. */
+int dsmi_beam_enqueue(dsmi_decoder* d, const float* probs_dev, const int32_t* sizes_host, int B, int T_out,
+                      int beam_width, int cutoff_top_n, double cutoff_prob, void* stream);
+int dsmi_beam_collect(dsmi_decoder* d, int32_t* tokens_host, int32_t* tsteps_host, int32_t* lens_host, float* scores_host);
 
 /* ---- Host-only view of a language model file (no GPU involved): what dsmi_decoder_set_lm would load.
  * kind: 0 ARPA text, 1 KenLM probing binary, 2 KenLM trie binary.  Word ids are the file's own (KenLM's WordIndex for

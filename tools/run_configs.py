@@ -35,12 +35,12 @@ def run(name, rec, B, seconds, reps=3):
         out = rec.recognize_batch(clips)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
-    for _ in rec.recognize_batches([clips] * 3):
+    for _ in rec.recognize_batches([clips] * 6):       # (the pipeline's own buffers: replica handles, decoder slots, allocator)
         pass
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     n = 0
-    for _ in rec.recognize_batches([clips] * (2 * reps + 2)):
+    for _ in rec.recognize_batches([clips] * (4 * reps + 2)):
         n += 1
     torch.cuda.synchronize()
     dp = (time.perf_counter() - t0) / n

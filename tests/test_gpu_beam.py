@@ -144,3 +144,29 @@ def test_lm_file_errors(native, tmp_path):
     with pytest.raises(native.DsmiError):
         dec.set_lm(str(bad), 1.0, 0.1)
     dec.close()
+
+
+def test_beam_enqueue_collect_halves(native):
+    """dsmi_beam_enqueue / dsmi_beam_collect: the split the pipelined recogniser uses (two decoder handles, two searches in
+    flight, results collected later) equals dsmi_beam; one search per handle at a time."""
+    rng = np.random.default_rng(5)
+    labels = syn.DANSPEECH_LABELS
+    pa, pb = _peaky_probs(rng, 3, 60, len(labels)), _peaky_probs(rng, 2, 45, len(labels))
+    da, db = native.NativeDecoder(labels, blank_index=0), native.NativeDecoder(labels, blank_index=0)
+    want_a, want_b = da.beam(_dev(pa), None, beam_width=16), db.beam(_dev(pb), None, beam_width=16)
+    xa, xb = _dev(pa), _dev(pb)
+    da.beam_enqueue(xa, None, beam_width=16)
+    db.beam_enqueue(xb, None, beam_width=16)
+    with pytest.raises(native.DsmiError) as e:
+        da.beam_enqueue(xa, None, beam_width=16)
+    assert "not been collected" in e.value.msg
+    got_b, got_a = db.beam_collect(), da.beam_collect()
+    for got, want in ((got_a, want_a), (got_b, want_b)):
+        for g, w in zip(got, want):
+            assert np.array_equal(g, w)
+    with pytest.raises(native.DsmiError):
+        lib = native.lib()
+        import ctypes
+        z = np.zeros(4, dtype=np.int32)
+        da._check(lib.dsmi_beam_collect(da._h, z.ctypes.data, z.ctypes.data, z.ctypes.data, z.ctypes.data))     # nothing enqueued
+    da.close(); db.close()

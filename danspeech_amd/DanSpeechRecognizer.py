@@ -193,6 +193,8 @@ class DanSpeechRecognizer(object):
             if hasattr(h, "set_inflight"):
                 h.set_inflight(2)
         parsers = [self.audio_parser, self._replica[1] if self._replica else self.audio_parser]
+        for ps in parsers:
+            ps.share_copy_stream = hasattr(self.decoder, "decode_enqueue")     # a search kernel on the decode stream: fewer streams
         streams = [torch.cuda.current_stream(self._device_index()), self._side_stream("second batch")]
         waiting, turn = None, 0
         for recordings in batches:

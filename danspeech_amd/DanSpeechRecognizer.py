@@ -22,7 +22,7 @@ import numpy as np
 
 from .deepspeech.decoder import GreedyDecoder, BeamCTCDecoder
 from .errors.recognizer_errors import ModelNotInitialized
-from .audio.parsers import SpectrogramAudioParser, InferenceSpectrogramAudioParser
+from .audio.parsers import SpectrogramAudioParser, InferenceSpectrogramAudioParser, DeviceClips
 
 
 class NoLmInstantiatedWarning(Warning):
@@ -59,11 +59,12 @@ class _StreamingSession(object):
 
 class _BatchJob(object):
     """One batch between enqueue and decode."""
-    __slots__ = ("order", "probs", "sizes", "count", "model", "ticket")
+    __slots__ = ("order", "probs", "sizes", "count", "model", "ticket", "slot")
 
     def __init__(self, order, probs, sizes, count, model):
         self.order, self.probs, self.sizes, self.count, self.model = order, probs, sizes, count, model
         self.ticket = None                       # a beam search launched behind the forward (transcribe_batches)
+        self.slot = 0                            # the decoder handle that search occupies
 
 
 class DanSpeechRecognizer(object):
@@ -136,8 +137,12 @@ class DanSpeechRecognizer(object):
         (pack_padded_sequence's order, reference model.py:117)."""
         import torch
         model = model or self.model
-        order = np.argsort([-len(r) for r in recordings], kind="stable")
-        feats, frames = (parser or self.audio_parser).parse_batch([recordings[i] for i in order])
+        if isinstance(recordings, DeviceClips):             # already on the device, longest first
+            order = np.arange(len(recordings))
+            feats, frames = (parser or self.audio_parser).parse_batch(recordings)
+        else:
+            order = np.argsort([-len(r) for r in recordings], kind="stable")
+            feats, frames = (parser or self.audio_parser).parse_batch([recordings[i] for i in order])
         probs, sizes = model.enqueue(feats, torch.from_numpy(frames.astype(np.int32)))
         job = _BatchJob(order, probs, sizes, len(recordings), model)
         if decode_slot is not None and hasattr(self.decoder, "decode_enqueue"):
@@ -148,6 +153,7 @@ class DanSpeechRecognizer(object):
             done.record(torch.cuda.current_stream(self._device_index()))
             side.wait_event(done)
             probs.record_stream(side)
+            job.slot = decode_slot
             with torch.cuda.stream(side):
                 job.ticket = self.decoder.decode_enqueue(probs, sizes, slot=decode_slot)
         return job
@@ -164,9 +170,16 @@ class DanSpeechRecognizer(object):
                 decoded = None                                         # ... read the probabilities of a forward that had to be redone
         if decoded is None:
             with torch.cuda.stream(side):
-                decoded, _ = self.decoder.decode(job.probs, job.sizes)
+                if hasattr(self.decoder, "decode_enqueue"):
+                    # on the job's OWN decoder handle: it is free again after the collect above, while handle 0 may hold the
+                    # search of the batch enqueued after this one
+                    decoded, _ = self.decoder.decode_collect(self.decoder.decode_enqueue(job.probs, job.sizes, slot=job.slot))
+                else:
+                    decoded, _ = self.decoder.decode(job.probs, job.sizes)
         if warn and show_all and self.lm == "greedy":
             warnings.warn("You are trying to get all beams but no LM has been instantiated.", NoLmInstantiatedWarning)
+        if getattr(self, "keep_last_output", False):
+            self.last_output = (job.probs, job.sizes)        # bench.py checks the timed batch's probabilities against the oracle
         results = [None] * job.count
         for pos, i in enumerate(job.order):
             results[i] = decoded[pos] if show_all else decoded[pos][0]
@@ -196,29 +209,53 @@ class DanSpeechRecognizer(object):
         for ps in parsers:
             ps.share_copy_stream = hasattr(self.decoder, "decode_enqueue")     # a search kernel on the decode stream: fewer streams
         streams = [torch.cuda.current_stream(self._device_index()), self._side_stream("second batch")]
-        waiting, turn = None, 0
-        for recordings in batches:
-            job = None
-            if len(recordings):
-                with torch.cuda.stream(streams[turn]):
-                    job = self._enqueue_batch(recordings, handles[turn], parsers[turn], decode_slot=turn)
-                turn ^= 1
+        waiting, turn, job, done = None, 0, None, None
+        try:
+            for recordings in batches:
+                job = None
+                if len(recordings):
+                    with torch.cuda.stream(streams[turn]):
+                        job = self._enqueue_batch(recordings, handles[turn], parsers[turn], decode_slot=turn)
+                    turn ^= 1
+                if waiting is not None:
+                    done, waiting = waiting, None
+                    res = self._finish_batch(done, show_all) if done != "empty" else []
+                    done = None
+                    yield res
+                waiting, job = (job if job is not None else "empty"), None
             if waiting is not None:
-                yield self._finish_batch(waiting, show_all) if waiting != "empty" else []
-            waiting = job if job is not None else "empty"
-        if waiting is not None:
-            yield self._finish_batch(waiting, show_all) if waiting != "empty" else []
-        if hasattr(self.model, "set_inflight"):
-            self.model.set_inflight(1)
+                done, waiting = waiting, None
+                res = self._finish_batch(done, show_all) if done != "empty" else []
+                done = None
+                yield res
+        finally:
+            # the caller stopped early, or a batch raised: whatever is still enqueued gives its forward and its beam-search
+            # ticket back, otherwise the decoder handle stays "not collected" and every later call on this engine fails
+            for left in (done, waiting, job):
+                if isinstance(left, _BatchJob):
+                    self._abandon(left)
+            for h in handles:
+                if hasattr(h, "set_inflight"):
+                    h.set_inflight(1)
 
-    def transcribe_device(self, pcm, n_samples, show_all=False):
+    def _abandon(self, job):
+        """Wait for an enqueued batch and drop its results."""
+        for release in (job.model.collect, (lambda: self.decoder.decode_collect(job.ticket)) if job.ticket is not None else None):
+            if release is not None:
+                try:
+                    release()
+                except Exception:      # the batch is being discarded: its own failure must not mask the caller's
+                    pass
+
+    def transcribe_device(self, pcm, n_samples, show_all=False, max_batch=None):
         """Clips that already sit back to back in GPU memory (int16 / float32 / float64, longest first), e.g. a
-        shard received over RCCL (``parallel.recognize_sharded``): no host staging at all."""
-        import torch
-        feats, frames = self.audio_parser._frontend().features(pcm, np.asarray(n_samples, dtype=np.int64))
-        probs, sizes = self.model(feats, torch.from_numpy(frames.astype(np.int32)))
-        decoded, _ = self.decoder.decode(probs, sizes)
-        return [d if show_all else d[0] for d in decoded]
+        shard received over RCCL (``parallel.recognize_sharded``): no host staging at all.  With ``max_batch`` the shard
+        runs as a pipelined sequence of batches of at most that many clips (``transcribe_batches``)."""
+        clips = DeviceClips(pcm, n_samples)
+        if not max_batch or len(clips) <= max_batch:
+            return self.transcribe_batch(clips, show_all=show_all) if len(clips) else []
+        parts = [clips.part(lo, min(lo + max_batch, len(clips))) for lo in range(0, len(clips), max_batch)]
+        return [r for res in self.transcribe_batches(parts, show_all=show_all) for r in res]
 
     def transcribe(self, recording, show_all=False):
         beams = self._finish_batch(self._enqueue_batch([recording]), True, warn=show_all)[0]

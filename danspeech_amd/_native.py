@@ -109,6 +109,7 @@ _PROTOS = {
     "dsmi_lm_cond_log10": (C.c_double, [_vp, _vp, C.c_int]),
     "dsmi_beam_enqueue": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _vp]),
     "dsmi_beam_collect": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "dsmi_decoder_beam_stats": (C.c_int, [_vp, _vp]),
     "dsmi_model_info": (C.c_int, [_vp, C.POINTER(ModelDesc), C.POINTER(C.c_int)]),
     "dsmi_frontend_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "dsmi_decoder_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -555,6 +556,12 @@ class NativeDecoder:
         sc = np.zeros((B, beam_width), dtype=np.float32)
         self._check(lib().dsmi_beam_collect(self._h, _np_ptr(tok), _np_ptr(ts), _np_ptr(ln), _np_ptr(sc)))
         return tok, ts, ln, sc
+
+    def beam_stats(self):
+        """Of the last collected search: {revivals, walk_hops, list_rankings, full_rankings} (dsmi_decoder_beam_stats)."""
+        c = np.zeros(4, dtype=np.int32)
+        self._check(lib().dsmi_decoder_beam_stats(self._h, _np_ptr(c)))
+        return dict(zip(("revivals", "walk_hops", "list_rankings", "full_rankings"), (int(v) for v in c)))
 
 
 class NativeLM:

@@ -23,6 +23,29 @@ def _shared_copy_stream(device):
     return _COPY_STREAMS[device]
 
 
+class DeviceClips(object):
+    """A batch whose clips already lie back to back in GPU memory, longest first: ``pcm`` = 1-D CUDA tensor (int16, float32
+    or float64 samples), ``n_samples`` = their lengths.  What an RCCL scatter delivers (``parallel.recognize_sharded``) and
+    what a caller that keeps its audio on the device passes to ``recognize_batch`` / ``recognize_batches`` instead of a
+    list of host arrays: no staging, no upload."""
+
+    def __init__(self, pcm, n_samples):
+        self.pcm = pcm
+        self.n_samples = np.asarray(n_samples, dtype=np.int64)
+        if self.n_samples.ndim != 1 or (np.diff(self.n_samples) > 0).any():
+            raise ValueError("DeviceClips: clips must be ordered longest first (pack_padded_sequence's order, reference model.py:117)")
+        if int(self.n_samples.sum()) != pcm.numel():
+            raise ValueError("DeviceClips: the lengths do not add up to the buffer")
+
+    def __len__(self):
+        return len(self.n_samples)
+
+    def part(self, lo, hi):
+        """Clips lo..hi-1 as a batch of their own (a view)."""
+        offs = np.concatenate(([0], np.cumsum(self.n_samples)))
+        return DeviceClips(self.pcm[int(offs[lo]):int(offs[hi])], self.n_samples[lo:hi])
+
+
 class AudioParser(object):
     def __init__(self, audio_config=None):
         self.audio_config = audio_config
@@ -79,6 +102,8 @@ class SpectrogramAudioParser(AudioParser):
         """list of 1-D arrays -> (features [B,1,F,Tmax] CUDA float32, frames int32[B]); batched extension.
         Asynchronous: the upload runs on a copy stream, the kernels on the current stream behind it."""
         import torch
+        if isinstance(recordings, DeviceClips):
+            return self._frontend().features(recordings.pcm, recordings.n_samples)
         recordings = [np.asarray(r) for r in recordings]
         kinds = {r.dtype for r in recordings}
         dtype = kinds.pop() if len(kinds) == 1 and next(iter(kinds)) in self._NATIVE_PCM else np.dtype(np.float64)

@@ -25,43 +25,67 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 using namespace dsmi;
 
 namespace {
 
-constexpr int BT = 1024;          // threads per utterance: the frame loop is latency-bound, so 16 waves hide it
-constexpr int NWAVE = BT / 64;
+constexpr int MAXBT = 1024;       // threads per utterance: a template parameter of the kernel (BT)
+constexpr double BIN_SPAN = 64.0; // the selection histogram has one bin per thread, over the 64 nats below the frame's score bound
+constexpr int LISTCAP = 256;      // members of the threshold bin that are ranked from a list (more: ranked against all keys)
 constexpr int MAXCTX = kMaxOrder - 1;
-constexpr int F_EXISTS = 1, F_DELETED = 2;
+constexpr int MAXC = 128;
 constexpr int MEMO_UNSET = 0x7fc00001;   // a NaN pattern no float computation produces
 
-// One prefix-trie node (64 bytes: one L2 line).  Children are found through a direct table
-// childtab[node][label] (-1: none), so a pair needs two dependent loads: the child id, then its record.
-struct __attribute__((aligned(64))) Node {
-    int parent, ch, tstep, dstate;
-    int nchild, flags, slot, memo;       // memo: bits of log10 P_lm(word ending here | ctx), or MEMO_UNSET
-    double lpc;
-    int ctx[MAXCTX];
-    int pad;
-};
-static_assert(sizeof(Node) == 64, "Node must be one 64-byte line");
+// One record of the node pool (HBM).  Written at creation, tstep / lpc updated in place by get_path_trie's "better emission
+// frame" rule; read only when a dormant prefix re-enters the beam (the walk in resolve()) and by the final path output.
+struct __attribute__((aligned(32))) NodeRec { int parent, ch, tstep, depth; double lpc; double pad; };
+static_assert(sizeof(NodeRec) == 32, "NodeRec is two 16-byte stores");
 
 struct BeamArgs {
     const float* probs; const int32_t* sizes; int T, C, blank, space, beam, cutoff_top_n; float cutoff_prob;
     int has_lm, order; double alpha, beta;
     LmView lm; const int32_t* trie_next; const int32_t* trie_word; int unk, bos;
     int ncap;                    // per-utterance node pool capacity
-    Node* nodes; int32_t* childtab; int32_t* nnodes;
+    NodeRec* nodes;
+    int32_t* dbg;                // optional [B][4]: dormant prefixes revived, walk hops, list rankings, full rankings
     // outputs
     int32_t *out_tok, *out_step, *out_len, *out_n; double* out_score;
 };
 
+// On-chip layout of one utterance's search, shared by the kernel and the launcher's size check.
+struct Carve {
+    size_t lp, sd, bprev, nbprev, score, uplpc, ownlpc, bcur, nbcur, ckey, lkey, su;          // 8-byte items
+    size_t node, ch, ds, depth, up, upch, upnode, memo, ctx, newslot, use, lidx, hist, wtot, wsurv, wfresh, si, pfp;   // 4-byte
+    size_t cell;                                                                                // 2-byte
+    size_t lmv;
+    size_t bytes;
+};
+__host__ __device__ inline Carve carve(int BW, int C, int BT) {
+    const int NBINS = BT, NWAVE = BT / 64;
+    Carve k; size_t o = 0;
+    const size_t NMAX = (size_t)BW * (C + 1);
+    auto take = [&](size_t n, size_t sz) { const size_t at = o; o += ((n * sz + 15) & ~(size_t)15); return at; };
+    k.lp = take(2 * MAXC, 8); k.sd = take(8, 8);
+    k.bprev = take(2 * BW, 8); k.nbprev = take(2 * BW, 8); k.score = take(2 * BW, 8); k.uplpc = take(2 * BW, 8); k.ownlpc = take(2 * BW, 8);
+    k.bcur = take(BW, 8); k.nbcur = take(BW, 8); k.ckey = take(NMAX, 8); k.lkey = take(LISTCAP, 8); k.su = take(4, 8);
+    k.node = take(2 * BW, 4); k.ch = take(2 * BW, 4); k.ds = take(2 * BW, 4); k.depth = take(2 * BW, 4); k.up = take(2 * BW, 4);
+    k.upch = take(2 * BW, 4); k.upnode = take(2 * BW, 4); k.memo = take(2 * BW, 4); k.ctx = take((size_t)2 * BW * MAXCTX, 4);
+    k.newslot = take(BW, 4); k.use = take(2 * MAXC, 4); k.lidx = take(LISTCAP, 4); k.hist = take(NBINS, 4);
+    k.wtot = take(NWAVE, 4); k.wsurv = take(NWAVE, 4); k.wfresh = take(NWAVE, 4); k.si = take(16, 4); k.pfp = take(2 * MAXC, 4);
+    k.cell = take((size_t)2 * (((size_t)BW * C + 1) & ~(size_t)1), 2);
+    k.lmv = take(1, sizeof(LmView));
+    k.bytes = o;
+    return k;
+}
+
 __device__ __forceinline__ double lse2(double x, double y) {
+    // log(exp(x - m) + exp(y - m)) + m with m = max: the larger term's exp is exactly 1
     if (x == -INFINITY) return y;
     if (y == -INFINITY) return x;
-    const double m = fmax(x, y);
-    return log(exp(x - m) + exp(y - m)) + m;
+    const double m = fmax(x, y), d = fmin(x, y) - m;
+    return log(1.0 + exp(d)) + m;
 }
 
 __device__ __forceinline__ uint64_t okey(double v) {   // order-preserving bits, > 0 for every double
@@ -72,395 +96,446 @@ __device__ __forceinline__ double unokey(uint64_t k) {
     const uint64_t u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
     return __longlong_as_double((long long)u);
 }
-
+template <int NBINS>
+__device__ __forceinline__ int score_bin(double U, double s) {     // monotone: a better score never lands in a later bin
+    const double q = (U - s) * (NBINS / BIN_SPAN);
+    if (!(q < (double)(NBINS - 1))) return NBINS - 1;              // also NaN (U - s with both infinite)
+    return q > 0.0 ? (int)q : 0;
+}
 __device__ __forceinline__ int wave_sum(int v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
 
+struct Tup { int up, upch, upnode; double uplpc; };
+
+// The scorer's n-gram look-ups stay out of line: three call sites, rarely taken, a long chain of dependent loads each.
+__device__ __noinline__ float lm_word_log10(const LmView* v, const int32_t* ctx, int n, int32_t w, int32_t unk) {
+    return lm_cond_log10(*v, ctx, n, w, unk);
+}
+
+// CTC prefix beam search of one utterance by one workgroup; the algorithm, array for array, is oracle/beam_flat.py
+// (tests/test_oracle_beam_flat.py holds that formulation to ctcdecode's pointer trie as restated in oracle/beam.py).
+// A frame is six barrier-separated phases, all on LDS; HBM sees fire-and-forget stores (new node records, timestep updates)
+// and, one frame ahead, the load of the next probability row:
+//   F1  every candidate in registers: thread idx < nb = beam entry idx (its blank / repeat terms, and -- pull form -- the
+//       extension it receives from its parent when that is a beam entry), the others = (entry, character) pairs; keys go
+//       into a 1024-bin histogram of (bound - score) at 1/16 nat;
+//   F2  prefix sums of the histogram, wave level; the last wave turns the prefetched row into log-probabilities;
+//   F3  the bin in which the beam_width-th best score lies, and how many of its members survive;
+//   F4  members of that bin ranked exactly (score desc, character asc, index asc) when not all of them survive; survivors
+//       numbered inside each wave;
+//   F5  new slot numbers; what left the beam, which dormant prefixes came back;
+//   F6  commit: the new beam entry by entry into the other buffer (edge tuples resolved through whatever left), node
+//       records to HBM, the child table of the new beam.
+template <int BT, int KMAX>
 __global__ __launch_bounds__(BT) void beam_kernel(BeamArgs a) {
+    constexpr int NWAVE = BT / 64, NBINS = BT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int C = a.C, BW = a.beam, NMAX = BW * (C + 1);
-    // ---- LDS carve
-    double* lp = reinterpret_cast<double*>(smem_raw);                 // [128]
-    double* sd = lp + 128;                                            // [2] scalars (min_cutoff)
-    double* e_bprev = sd + 2;                                         // entry arrays [2][BW] (double-buffered)
-    double* e_nbprev = e_bprev + 2 * BW;
-    double* e_score = e_nbprev + 2 * BW;
-    double* e_bcur = e_score + 2 * BW;                                // [BW]
-    double* e_rep = e_bcur + BW;
-    double* e_ext = e_rep + BW;
-    uint64_t* c_key = reinterpret_cast<uint64_t*>(e_ext + BW);        // [NMAX] 0 = no candidate, else okey(logp)
-    uint64_t* su = c_key + NMAX;                                      // [2] scalars (radix prefix)
-    uint64_t* wkmin = su + 2;                                         // [NWAVE] per-wave smallest / largest candidate key
-    uint64_t* wkmax = wkmin + NWAVE;
-    int* e_node = reinterpret_cast<int*>(wkmax + NWAVE);              // [2][BW]
-    int* e_ch = e_node + 2 * BW;                                      // [2][BW]
-    int* e_ds = e_ch + 2 * BW;                                        // [2][BW] dictionary state of the entry's node
-    int* c_child = e_ds + 2 * BW;                                     // [NMAX]
-    int* c_surv = c_child + NMAX;                                     // [NMAX]
-    int* newn = c_surv + NMAX;                                        // [BW] nodes created this frame
-    int* use = newn + BW;                                             // [128]
-    unsigned* hist = reinterpret_cast<unsigned*>(use + 128);          // [2][256]
-    int* wtot = reinterpret_cast<int*>(hist + 512);                   // [NWAVE + 1]
-    int* si = wtot + NWAVE + 1;                                       // [8] scalars
+    const int C = a.C, BW = a.beam;
+    const Carve kv = carve(BW, C, BT);
+    LmView* s_lm = reinterpret_cast<LmView*>(smem_raw + kv.lmv);
+    double* lp = reinterpret_cast<double*>(smem_raw + kv.lp);            // [2][MAXC] by frame parity
+    double* sd = reinterpret_cast<double*>(smem_raw + kv.sd);            // [0..1] ln p(blank), [2..3] max_c lp
+    double* e_bprev = reinterpret_cast<double*>(smem_raw + kv.bprev);    // entry arrays [2][BW]
+    double* e_nbprev = reinterpret_cast<double*>(smem_raw + kv.nbprev);
+    double* e_score = reinterpret_cast<double*>(smem_raw + kv.score);
+    double* e_uplpc = reinterpret_cast<double*>(smem_raw + kv.uplpc);
+    double* e_ownlpc = reinterpret_cast<double*>(smem_raw + kv.ownlpc);
+    double* e_bcur = reinterpret_cast<double*>(smem_raw + kv.bcur);      // [BW]
+    double* e_nbcur = reinterpret_cast<double*>(smem_raw + kv.nbcur);
+    uint64_t* c_key = reinterpret_cast<uint64_t*>(smem_raw + kv.ckey);   // [NMAX] 0 = no candidate, else okey(score)
+    uint64_t* l_key = reinterpret_cast<uint64_t*>(smem_raw + kv.lkey);   // [LISTCAP]
+    uint64_t* su = reinterpret_cast<uint64_t*>(smem_raw + kv.su);        // [0] smallest, [1] largest key of the beam
+    int* e_node = reinterpret_cast<int*>(smem_raw + kv.node);
+    int* e_ch = reinterpret_cast<int*>(smem_raw + kv.ch);
+    int* e_ds = reinterpret_cast<int*>(smem_raw + kv.ds);
+    int* e_depth = reinterpret_cast<int*>(smem_raw + kv.depth);
+    int* e_up = reinterpret_cast<int*>(smem_raw + kv.up);
+    int* e_upch = reinterpret_cast<int*>(smem_raw + kv.upch);
+    int* e_upnode = reinterpret_cast<int*>(smem_raw + kv.upnode);
+    int* e_memo = reinterpret_cast<int*>(smem_raw + kv.memo);
+    int* e_ctx = reinterpret_cast<int*>(smem_raw + kv.ctx);              // [2][BW][MAXCTX]
+    int* newslot = reinterpret_cast<int*>(smem_raw + kv.newslot);
+    int* usev = reinterpret_cast<int*>(smem_raw + kv.use);               // [2][MAXC]
+    int* l_idx = reinterpret_cast<int*>(smem_raw + kv.lidx);
+    unsigned* hist = reinterpret_cast<unsigned*>(smem_raw + kv.hist);
+    int* wtot = reinterpret_cast<int*>(smem_raw + kv.wtot);
+    int* wsurv = reinterpret_cast<int*>(smem_raw + kv.wsurv);
+    int* wfresh = reinterpret_cast<int*>(smem_raw + kv.wfresh);
+    int* si = reinterpret_cast<int*>(smem_raw + kv.si);
+    float* pfp = reinterpret_cast<float*>(smem_raw + kv.pfp);            // [MAXC] row being pruned, [MAXC] the same sorted
+    short* cell = reinterpret_cast<short*>(smem_raw + kv.cell);          // [2][CELLS]: (entry, label) -> an entry of that edge
+    const int CELLS = (BW * C + 1) & ~1;
 #define s_nb si[0]
-#define s_full si[1]
-#define s_m si[2]
-#define s_nuse si[3]
-#define s_kk si[4]
-#define s_done si[5]
-#define s_nnew si[6]
-#define s_pass0 si[7]
-#define s_mincut sd[0]
-#define s_prefix su[0]
+#define s_bstar si[1]
+#define s_r si[2]
+#define s_mb si[3]
+#define s_nlist si[4]
+#define s_nrev si[5]
+#define s_kmin su[0]
+#define s_kmax su[1]
 
-    // ---- per-utterance global state
-    Node* nodes = a.nodes + (size_t)b * a.ncap;
-    int32_t* childtab = a.childtab + (size_t)b * a.ncap * C;
-    int32_t* nnodes = a.nnodes + b;
+    NodeRec* nodes = a.nodes + (size_t)b * a.ncap;
     const int T = a.sizes ? min(a.sizes[b], a.T) : a.T;
     const float* pb = a.probs + (size_t)b * a.T * C;
     const int NCTX = a.order - 1;
+    const double betap = fmax(0.0, a.beta);
+    const bool prune = a.cutoff_prob < 1.0f || a.cutoff_top_n < C;
+    const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    int dbg_rev = 0, dbg_hops = 0, dbg_list = 0, dbg_full = 0;
 
-    if (tid < C) childtab[tid] = -1;
+    // The last wave turns row tt of the probabilities (held in p0, p1: labels lane and lane + 64; pbl = p(blank)) into the
+    // log-probabilities, the vocabulary mask and the two scalars of frame tt (decoder_utils get_pruned_log_probs).
+    auto make_row = [&](int tt, float p0, float p1, float pbl) {
+        const int par = tt & 1;
+        double mx = -INFINITY;
+        if (lane < C) { const double l = log((double)p0 + 1.17549435e-38); lp[par * MAXC + lane] = l; usev[par * MAXC + lane] = 1; mx = l; }
+        if (lane + 64 < C) { const double l = log((double)p1 + 1.17549435e-38); lp[par * MAXC + lane + 64] = l; usev[par * MAXC + lane + 64] = 1; mx = fmax(mx, l); }
+        for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+        if (lane == 0) { sd[par] = pbl > 0.f ? log((double)pbl) : -INFINITY; sd[2 + par] = mx; }
+        if (prune) {
+            // rank of every label by (probability desc, index asc); the cumulative sum runs in that order, in double, like the
+            // reference's loop, so that `cum >= cutoff_prob` falls on the same label
+            if (lane < C) pfp[lane] = p0;
+            if (lane + 64 < C) pfp[lane + 64] = p1;
+            __builtin_amdgcn_wave_barrier();
+            int rk[2] = {0, 0};
+            for (int h = 0; h < 2; ++h) {
+                const int c = lane + 64 * h;
+                if (c >= C) continue;
+                const float pc = pfp[c];
+                int r = 0;
+                for (int o = 0; o < C; ++o) { const float po = pfp[o]; r += (po > pc) || (po == pc && o < c); }
+                rk[h] = r;
+                pfp[MAXC + r] = pc;
+            }
+            __builtin_amdgcn_wave_barrier();
+            int len = C;
+            if (a.cutoff_prob < 1.0f) {
+                int mine = C;
+                for (int h = 0; h < 2; ++h) {
+                    const int c = lane + 64 * h;
+                    if (c >= C) continue;
+                    double cum = 0.0;
+                    for (int k = 0; k <= rk[h]; ++k) cum += (double)pfp[MAXC + k];
+                    if (cum >= (double)a.cutoff_prob || rk[h] + 1 >= a.cutoff_top_n) mine = min(mine, rk[h] + 1);
+                }
+                for (int o = 32; o > 0; o >>= 1) mine = min(mine, __shfl_xor(mine, o, 64));
+                len = mine;
+            } else len = a.cutoff_top_n;
+            for (int h = 0; h < 2; ++h) { const int c = lane + 64 * h; if (c < C) usev[par * MAXC + c] = rk[h] < len; }
+        }
+    };
+
+    // ---- start: the root is the whole beam
+    for (int q = tid; q < NBINS; q += BT) hist[q] = 0;
+    for (int q = tid; q < CELLS; q += BT) reinterpret_cast<int*>(cell)[q] = -1;       // both buffers (2 * CELLS shorts)
     if (tid == 0) {
-        Node r{};
-        r.parent = -1; r.ch = -1; r.tstep = 0; r.dstate = 0; r.nchild = 0; r.flags = F_EXISTS; r.slot = 0; r.memo = MEMO_UNSET;
-        r.lpc = -INFINITY;
-        for (int k = 0; k < MAXCTX; ++k) r.ctx[k] = a.bos;
+        NodeRec r; r.parent = -1; r.ch = -1; r.tstep = 0; r.depth = 0; r.lpc = -INFINITY; r.pad = 0.0;
         nodes[0] = r;
-        *nnodes = 1;
-        e_node[0] = 0; e_ch[0] = -1; e_ds[0] = 0; e_bprev[0] = 0.0; e_nbprev[0] = -INFINITY; e_score[0] = 0.0;
-        s_nb = 1;
+        e_node[0] = 0; e_ch[0] = -1; e_ds[0] = 0; e_depth[0] = 0; e_up[0] = -1; e_upch[0] = -1; e_upnode[0] = -1; e_memo[0] = MEMO_UNSET;
+        e_bprev[0] = 0.0; e_nbprev[0] = -INFINITY; e_score[0] = 0.0; e_uplpc[0] = -INFINITY; e_ownlpc[0] = -INFINITY;
+        for (int k = 0; k < MAXCTX; ++k) e_ctx[k] = a.bos;
+        s_nb = 1; s_kmin = okey(0.0); s_kmax = okey(0.0); s_nlist = 0; s_nrev = 0;
+        *s_lm = a.lm;
     }
-    float pnext = (tid < C && T > 0) ? pb[tid] : 0.f;     // next frame's row, fetched one frame ahead
+    if (wid == NWAVE - 1 && T > 0)
+        make_row(0, lane < C ? pb[lane] : 0.f, lane + 64 < C ? pb[lane + 64] : 0.f, pb[a.blank]);
     __syncthreads();
-    int cur = 0;
+    int cur = 0, nn = 1;
 
     for (int t = 0; t < T; ++t) {
+        const int nxt = cur ^ 1, par = t & 1;
         const int nb = s_nb;
-        double* bprev = e_bprev + cur * BW; double* nbprev = e_nbprev + cur * BW; double* score = e_score + cur * BW;
-        int* node = e_node + cur * BW; int* ech = e_ch + cur * BW; int* eds = e_ds + cur * BW;
-        const float* pr = pb + (size_t)t * C;
-        // ---- 1. log-probabilities and vocabulary pruning (decoder_utils get_pruned_log_probs)
-        if (tid < C) { lp[tid] = log((double)pnext + 1.17549435e-38); use[tid] = 1; }
-        if (tid < C && t + 1 < T) pnext = pr[C + tid];
-        for (int i = tid; i < nb; i += BT) { e_bcur[i] = -INFINITY; e_rep[i] = -INFINITY; e_ext[i] = -INFINITY; }
-        if (wid == 1) {
-            // ---- min_cutoff / full_beam (scorer only)
-            double mn = INFINITY;
-            if (a.has_lm) {
-                for (int i = lane; i < nb; i += 64) mn = fmin(mn, score[i]);
-                for (int o = 32; o > 0; o >>= 1) mn = fmin(mn, __shfl_xor(mn, o, 64));
-            }
-            if (lane == 0) {
-                s_full = 0; s_mincut = -INFINITY;
-                if (a.has_lm) {
-                    const float pbl = pr[a.blank];
-                    const double blp = pbl > 0.f ? log((double)pbl) : -INFINITY;
-                    s_mincut = mn + blp - fmax(0.0, a.beta);
-                    s_full = nb == BW;
-                }
-            }
+        const double* lpv = lp + par * MAXC; const int* use = usev + par * MAXC;
+        const double* bprev = e_bprev + cur * BW; const double* nbprev = e_nbprev + cur * BW; const double* score = e_score + cur * BW;
+        double* uplpc = e_uplpc + cur * BW; const double* ownlpc = e_ownlpc + cur * BW;
+        const int* node = e_node + cur * BW; const int* ech = e_ch + cur * BW; const int* eds = e_ds + cur * BW;
+        const int* depth = e_depth + cur * BW; const int* up = e_up + cur * BW; const int* upch = e_upch + cur * BW;
+        const int* upnode = e_upnode + cur * BW; int* memo = e_memo + cur * BW; const int* ctx = e_ctx + (size_t)cur * BW * MAXCTX;
+        short* cellc = cell + (size_t)cur * CELLS; short* celln = cell + (size_t)nxt * CELLS;
+        // next frame's row, on its way while this frame runs
+        float pn0 = 0.f, pn1 = 0.f, pnb = 0.f;
+        if (wid == NWAVE - 1 && t + 1 < T) {
+            const float* pr = pb + (size_t)(t + 1) * C;
+            if (lane < C) pn0 = pr[lane];
+            if (lane + 64 < C) pn1 = pr[lane + 64];
+            pnb = pr[a.blank];
         }
-        if (tid == 0) {
-            s_nuse = C;
-            if (a.cutoff_prob < 1.0f || a.cutoff_top_n < C) {
-                // selection by repeated maximum: C is small (<= 128)
-                bool used[128];
-                for (int c = 0; c < C; ++c) used[c] = false;
-                double cum = 0.0; int len = 0;
-                const int maxlen = a.cutoff_prob < 1.0f ? C : a.cutoff_top_n;
-                while (len < maxlen) {
-                    int best = -1; float bv = -1.f;
-                    for (int c = 0; c < C; ++c) if (!used[c] && pr[c] > bv) { bv = pr[c]; best = c; }
-                    if (best < 0) break;
-                    used[best] = true; ++len; cum += (double)bv;
-                    if (a.cutoff_prob < 1.0f && (cum >= (double)a.cutoff_prob || len >= a.cutoff_top_n)) break;
-                }
-                s_nuse = -len;     // negative: the mask below still has to be applied
-                for (int c = 0; c < C; ++c) c_surv[c] = used[c];
-            }
-        }
-        __syncthreads();
-        if (s_nuse < 0) {
-            if (tid < C) use[tid] = c_surv[tid];
-            __syncthreads();
-        }
-        const bool full = s_full != 0;
-        const double mincut = s_mincut;
+        const bool full = a.has_lm && nb == BW;
+        const double mincut = a.has_lm ? unokey(s_kmin) + sd[par] - betap : -INFINITY;
+        const double U = unokey(s_kmax) + sd[2 + par] + betap + 1.2;      // no score of this frame exceeds it (alpha >= 0)
+        const int NP = nb * C, N = nb + NP;
+        const float invC = 1.0f / (float)C;
 
-        // ---- 2. all (entry, character) pairs
-        const int NP = nb * C;
-        for (int idx = tid; idx < NP; idx += BT) {
-            const int i = idx / C, c = idx - i * C;
-            uint64_t key = 0; int cc = -2;
-            do {
-                if (!use[c]) break;
-                const double l = lp[c], sc = score[i];
-                if (full && l + sc < mincut) break;
-                if (c == a.blank) { e_bcur[i] = l + sc; break; }
-                const int lastc = ech[i];
-                if (c == lastc) e_rep[i] = l + nbprev[i];
-                const int pn = node[i];
-                const int ds = eds[i];
-                // independent loads first: child id, dictionary arc, memoised LM score of the parent
-                const int child = childtab[(size_t)pn * C + c];
-                const bool sp = a.has_lm && c == a.space;
-                int arc = 0, memo = 0;
-                if (a.has_lm) arc = c == a.space ? a.trie_word[ds] : a.trie_next[(size_t)ds * C + c];
-                if (sp) memo = nodes[pn].memo;
-                int cflags = F_DELETED, cslot = -1;
-                if (child >= 0) {
-                    Node* cn = nodes + child;
-                    cflags = cn->flags; cslot = cn->slot;
-                    if (!(cflags & F_DELETED) && cn->lpc < l) { cn->lpc = l; cn->tstep = t; }
-                }
-                const bool alive = !(cflags & F_DELETED);
-                if (!alive && a.has_lm && arc < 0) break;   // dictionary: a new child needs an arc (space: a word must end here)
-                double logp = -INFINITY;
-                if (c == lastc) { if (bprev[i] > -INFINITY) logp = l + bprev[i]; }
-                else logp = l + sc;
-                if (sp) {
-                    double lm = kOovScore;
-                    if (arc >= 0) {
-                        float l10;
-                        if (memo != MEMO_UNSET) l10 = __int_as_float(memo);
-                        else {
-                            l10 = lm_cond_log10(a.lm, nodes[pn].ctx, NCTX, arc, a.unk);
-                            nodes[pn].memo = __float_as_int(l10);
-                        }
-                        lm = (double)l10 / (double)kLog10E;
+        // the extension of prefix P by character c (not a repeat of its blank-terminated self): ctc_beam_search_decoder.cpp's
+        // log_p, with the scorer's word score on the space character
+        auto pair_logp = [&](int P, int c, int arcw) -> double {
+            const double l = lpv[c];
+            double logp = -INFINITY;
+            if (c == ech[P]) { if (bprev[P] > -INFINITY) logp = l + bprev[P]; }
+            else logp = l + score[P];
+            if (a.has_lm && c == a.space) {
+                double lm = kOovScore;
+                if (arcw >= 0) {
+                    float l10;
+                    const int mm = memo[P];
+                    if (mm != MEMO_UNSET) l10 = __int_as_float(mm);
+                    else {
+                        l10 = lm_word_log10(s_lm, ctx + (size_t)P * MAXCTX, NCTX, arcw, a.unk);
+                        memo[P] = __float_as_int(l10);
                     }
-                    logp += lm * a.alpha;
-                    logp += a.beta;
+                    lm = (double)l10 / (double)kLog10E;
                 }
-                if (alive && (cflags & F_EXISTS)) { e_ext[cslot] = logp; break; }
-                cc = alive ? child : (child >= 0 ? -3 - child : -1);   // <= -3: reuse deleted id
-                key = okey(logp);
-            } while (false);
-            c_key[idx] = key; c_child[idx] = cc;
-        }
-        __syncthreads();
-        // entries themselves
-        for (int i = tid; i < nb; i += BT) {
-            const double nbc = lse2(e_rep[i], e_ext[i]);
-            e_rep[i] = nbc;                         // now nb_cur
-            const double s = lse2(e_bcur[i], nbc);
-            c_child[NP + i] = node[i]; c_key[NP + i] = okey(s);
-        }
-        __syncthreads();
-        const int N = NP + nb;
+                logp += lm * a.alpha;
+                logp += a.beta;
+            }
+            return logp;
+        };
 
-        // ---- 3. exact top-BW selection
-        {
-            int cnt = 0;
-            uint64_t kmin = ~0ull, kmax = 0;
-            for (int idx = tid; idx < N; idx += BT) {
-                const uint64_t k = c_key[idx];
-                if (k != 0) { ++cnt; kmin = k < kmin ? k : kmin; kmax = k > kmax ? k : kmax; }
-            }
-            cnt = wave_sum(cnt);
-            for (int o = 32; o > 0; o >>= 1) {
-                const uint64_t a0 = __shfl_xor(kmin, o, 64), a1 = __shfl_xor(kmax, o, 64);
-                kmin = a0 < kmin ? a0 : kmin; kmax = a1 > kmax ? a1 : kmax;
-            }
-            if (lane == 0) { wtot[wid] = cnt; wkmin[wid] = kmin; wkmax[wid] = kmax; }
-            for (int q = tid; q < 512; q += BT) hist[q] = 0;      // both histograms: the first pass may be an odd one
-            __syncthreads();
-            if (tid == 0) {
-                int m = 0;
-                uint64_t lo = ~0ull, hi = 0;
-                for (int w = 0; w < NWAVE; ++w) { m += wtot[w]; lo = wkmin[w] < lo ? wkmin[w] : lo; hi = wkmax[w] > hi ? wkmax[w] : hi; }
-                // the radix select starts at the first byte in which the candidates differ at all (scores of one frame share
-                // sign, exponent and often the leading mantissa bits: the passes over those bytes would select nothing)
-                const int skip = (m > 0 && lo != hi) ? __builtin_clzll(lo ^ hi) >> 3 : 0;
-                s_m = m; s_prefix = skip ? hi >> (64 - 8 * skip) : 0; s_kk = BW; s_done = 0; s_pass0 = skip;
-            }
-            __syncthreads();
-        }
-        const int M = s_m;
-        if (M <= BW) {
-            for (int idx = tid; idx < N; idx += BT) c_surv[idx] = c_key[idx] != 0;
-        } else {
-            // radix select, 8 bits per pass from the top; stops as soon as the threshold bin is taken whole
-            int pass = s_pass0;
-            for (; pass < 8; ++pass) {
-                const int shift = 56 - 8 * pass;
-                unsigned* h = hist + (pass & 1) * 256;
-                unsigned* hn = hist + ((pass + 1) & 1) * 256;
-                const uint64_t pre = s_prefix;
-                for (int idx = tid; idx < N; idx += BT) {
-                    const uint64_t k = c_key[idx];
-                    if (k != 0 && (pass == 0 || (k >> (shift + 8)) == pre)) atomicAdd(&h[(unsigned)(k >> shift) & 255u], 1u);
-                }
-                for (int q = tid; q < 256; q += BT) hn[q] = 0;       // (the other histogram: nobody counts into it in this pass)
-                __syncthreads();
-                if (wid == 0) {
-                    // lane l owns bins 4l .. 4l+3; suffix sums from the top bin down
-                    const unsigned h0 = h[4 * lane], h1 = h[4 * lane + 1], h2 = h[4 * lane + 2], h3 = h[4 * lane + 3];
-                    const unsigned mine = h0 + h1 + h2 + h3;
-                    unsigned suf = mine;                         // inclusive suffix sum over lanes >= lane
-                    for (int o = 1; o < 64; o <<= 1) {
-                        const unsigned v = __shfl_down(suf, o, 64);
-                        if (lane + o < 64) suf += v;
-                    }
-                    const unsigned kk = (unsigned)s_kk;
-                    const unsigned long long bal = __ballot(suf >= kk);
-                    const int owner = 63 - __builtin_clzll(bal);   // highest lane whose suffix reaches kk
-                    if (lane == owner) {
-                        unsigned cum = suf - mine;               // keys in bins above this lane's
-                        int d; unsigned hd;
-                        if (cum + h3 >= kk) { d = 3; hd = h3; }
-                        else { cum += h3; if (cum + h2 >= kk) { d = 2; hd = h2; }
-                        else { cum += h2; if (cum + h1 >= kk) { d = 1; hd = h1; }
-                        else { cum += h1; d = 0; hd = h0; } } }
-                        s_kk = (int)(kk - cum);
-                        s_prefix = (pre << 8) | (unsigned)(4 * lane + d);
-                        s_done = hd == kk - cum;                 // the whole bin survives: no deeper pass needed
-                    }
-                }
-                __syncthreads();
-                if (s_done) break;
-            }
-            if (pass < 8) {
-                const int shift = 56 - 8 * pass;
-                const uint64_t thr = s_prefix;
-                for (int idx = tid; idx < N; idx += BT) {
-                    const uint64_t k = c_key[idx];
-                    c_surv[idx] = k != 0 && (k >> shift) >= thr;
-                }
-            } else {
-                const uint64_t thr = s_prefix;
-                const int need = (int)s_kk;          // how many of the keys equal to thr survive
-                // ties at the threshold: (character asc, candidate index asc)
-                for (int idx = tid; idx < N; idx += BT) {
-                    const uint64_t k = c_key[idx];
-                    int sv = k > thr;
-                    if (k == thr) {
-                        const int myc = idx < NP ? idx % C : ech[idx - NP];
-                        int rank = 0;
-                        for (int j = 0; j < N; ++j) {
-                            if (c_key[j] != thr || j == idx) continue;
-                            const int oc = j < NP ? j % C : ech[j - NP];
-                            rank += (oc < myc) || (oc == myc && j < idx);
+        // ---- F1: candidates
+        uint64_t key[KMAX]; int mark[KMAX], arcv[KMAX], binv[KMAX];     // mark: -1 none, 0 entry, 1 fresh child, 2 + rep: dormant top
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int idx = tid + k * BT;
+            key[k] = 0; mark[k] = -1; arcv[k] = -1; binv[k] = NBINS;
+            if (idx < nb) {
+                const int j = idx;
+                const double sc = score[j];
+                double bl = -INFINITY, rp = -INFINITY, ex = -INFINITY;
+                if (use[a.blank] && !(full && lpv[a.blank] + sc < mincut)) bl = lpv[a.blank] + sc;
+                const int cj = ech[j];
+                if (cj >= 0 && use[cj] && !(full && lpv[cj] + sc < mincut)) rp = lpv[cj] + nbprev[j];
+                const int P = up[j];
+                if (P >= 0) {
+                    const int c = upch[j];
+                    if (use[c] && !(full && lpv[c] + score[P] < mincut)) {
+                        if (uplpc[j] < lpv[c]) {            // get_path_trie: a better emission frame for the edge's top node
+                            uplpc[j] = lpv[c];
+                            NodeRec* tn = nodes + upnode[j];
+                            tn->lpc = lpv[c]; tn->tstep = t;
                         }
-                        sv = rank < need;
+                        if (upnode[j] == node[j]) {
+                            int arcw = -1;
+                            if (a.has_lm && c == a.space) arcw = a.trie_word[eds[P]];
+                            ex = pair_logp(P, c, arcw);
+                        }
                     }
-                    c_surv[idx] = sv;
+                }
+                const double nbc = lse2(rp, ex), s = lse2(bl, nbc);
+                e_bcur[j] = bl; e_nbcur[j] = nbc;
+                key[k] = okey(s); mark[k] = 0;
+            } else if (idx < N) {
+                const int p = idx - nb;
+                const int i = min((int)(((float)p + 0.5f) * invC), nb - 1), c = p - i * C;
+                if (c != a.blank && use[c] && !(full && lpv[c] + score[i] < mincut)) {
+                    const int r = cellc[i * C + c];
+                    bool ok = true; int mk = 1, arc = -1;
+                    if (r >= 0) { if (upnode[r] == node[r]) ok = false; else mk = 2 + r; }
+                    if (ok && a.has_lm && (r < 0 || c == a.space)) {
+                        arc = c == a.space ? a.trie_word[eds[i]] : a.trie_next[(size_t)eds[i] * C + c];
+                        if (r < 0 && arc < 0) ok = false;           // the dictionary has no such arc (space: no word ends here)
+                    }
+                    if (ok) { key[k] = okey(pair_logp(i, c, arc)); mark[k] = mk; arcv[k] = arc; }
                 }
             }
+            const bool valid = key[k] != 0;
+            if (idx < N) c_key[idx] = key[k];
+            int bin = NBINS;
+            if (valid) bin = score_bin<NBINS>(U, unokey(key[k]));
+            binv[k] = bin;
+            const bool lastb = valid && bin == NBINS - 1;          // the hopeless ones pile up in the last bin: one add per wave
+            const unsigned long long bl = __ballot(lastb);
+            if (valid && !lastb) atomicAdd(&hist[bin], 1u);
+            if (bl && lane == __builtin_ctzll(bl)) atomicAdd(&hist[NBINS - 1], (unsigned)__builtin_popcountll(bl));
         }
         __syncthreads();
-        // ---- deterministic slot numbers: exclusive scan of the survivor flags in index order
-        const int per = (N + BT - 1) / BT;
-        const int i0 = min(tid * per, N), i1 = min(i0 + per, N);
-        int local = 0;
-        for (int idx = i0; idx < i1; ++idx) local += c_surv[idx];
-        int incl = local;
-        for (int o = 1; o < 64; o <<= 1) {
-            const int v = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += v;
-        }
+
+        // ---- F2: prefix sums inside each wave; the next row; housekeeping
+        const int hv = (int)hist[tid];
+        hist[tid] = 0;
+        int incl = hv;
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
         if (lane == 63) wtot[wid] = incl;
-        if (tid == 0) s_nnew = 0;
+        for (int q = tid; q < CELLS / 2; q += BT) reinterpret_cast<int*>(celln)[q] = -1;
+        if (tid == 0) { s_kmin = ~0ull; s_kmax = 0; s_nlist = 0; s_nrev = 0; }
+        if (wid == NWAVE - 1 && t + 1 < T) make_row(t + 1, pn0, pn1, pnb);
         __syncthreads();
-        int wbase = 0, nnext = 0;
-        for (int w = 0; w < NWAVE; ++w) { const int v = wtot[w]; if (w < wid) wbase += v; nnext += v; }
-        const int nxt = cur ^ 1;
-        // ---- 4a. commit survivors (new nodes first so that child counts are up before any removal)
-        {
-            int pos = wbase + incl - local;
-            for (int idx = i0; idx < i1; ++idx) {
-                if (!c_surv[idx]) continue;
-                const int sl = pos++;
-                const double lg = unokey(c_key[idx]);
-                if (idx >= NP) {                                   // an entry that stays
-                    const int i = idx - NP;
-                    e_node[nxt * BW + sl] = node[i]; e_ch[nxt * BW + sl] = ech[i]; e_ds[nxt * BW + sl] = eds[i];
-                    e_bprev[nxt * BW + sl] = e_bcur[i]; e_nbprev[nxt * BW + sl] = e_rep[i]; e_score[nxt * BW + sl] = lg;
-                    nodes[node[i]].slot = sl;
-                    continue;
+
+        // ---- F3: the threshold bin
+        int total = 0, wbase = 0;
+        for (int w = 0; w < NWAVE; ++w) { const int v = wtot[w]; total += v; if (w < wid) wbase += v; }
+        const int exb = wbase + incl - hv;
+        if (total <= BW) { if (tid == 0) { s_bstar = NBINS; s_r = 0; s_mb = 0; } }
+        else if (exb < BW && exb + hv >= BW) { s_bstar = tid; s_r = BW - exb; s_mb = hv; }
+        __syncthreads();
+
+        // ---- F4: exact ranking inside the threshold bin; survivors numbered per wave
+        const int bstar = s_bstar, rr = s_r, mb = s_mb;
+        bool surv[KMAX];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) surv[k] = binv[k] < bstar || (binv[k] == bstar && rr == mb);
+        if (bstar < NBINS && rr != mb) {
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k)
+                if (binv[k] == bstar) {
+                    const int at = atomicAdd(&s_nlist, 1);
+                    if (at < LISTCAP) { l_key[at] = key[k]; l_idx[at] = tid + k * BT; }
                 }
-                const int i = idx / C, c = idx - i * C;
-                const int pn = node[i];
-                int id = c_child[idx];
-                int nds;
-                if (id >= 0) {                                     // dormant node (kept alive by descendants) comes back
-                    atomicOr(&nodes[id].flags, F_EXISTS);
-                    nds = nodes[id].dstate;
+            __syncthreads();
+            const int nl = s_nlist;
+            auto label_of = [&](int idx) { if (idx < nb) return ech[idx]; const int p = idx - nb; const int i = min((int)(((float)p + 0.5f) * invC), nb - 1); return p - i * C; };
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                if (binv[k] != bstar) continue;
+                const int idx = tid + k * BT, myc = label_of(idx);
+                const uint64_t mk = key[k];
+                int rank = 0;
+                if (nl <= LISTCAP) {
+                    for (int q = 0; q < nl; ++q) {
+                        const uint64_t ok = l_key[q]; const int oi = l_idx[q];
+                        if (oi == idx) continue;
+                        if (ok > mk) { ++rank; continue; }
+                        if (ok == mk) { const int oc = label_of(oi); rank += (oc < myc) || (oc == myc && oi < idx); }
+                    }
+                    ++dbg_list;
                 } else {
-                    const bool reuse = id <= -3;
-                    id = reuse ? -3 - id : atomicAdd(nnodes, 1);
-                    const int ds = eds[i];
-                    const bool sp = a.has_lm && c == a.space;
-                    nds = a.has_lm ? (sp ? 0 : a.trie_next[(size_t)ds * C + c]) : 0;
-                    const int w = sp ? a.trie_word[ds] : -1;
-                    Node r;
-                    r.parent = pn; r.ch = c; r.tstep = t; r.dstate = nds; r.nchild = 0; r.flags = F_EXISTS; r.slot = sl; r.memo = MEMO_UNSET;
-                    r.lpc = lp[c]; r.pad = 0;
-                    const Node* pnode = nodes + pn;
-                    for (int k = 0; k < MAXCTX; ++k) {
-                        int v = pnode->ctx[k];
-                        if (sp) v = k + 1 < NCTX ? pnode->ctx[k + 1] : (k + 1 == NCTX ? w : a.bos);
-                        r.ctx[k] = v;
+                    for (int q = 0; q < N; ++q) {
+                        const uint64_t ok = c_key[q];
+                        if (ok == 0 || q == idx || score_bin<NBINS>(U, unokey(ok)) != bstar) continue;
+                        if (ok > mk) { ++rank; continue; }
+                        if (ok == mk) { const int oc = label_of(q); rank += (oc < myc) || (oc == myc && q < idx); }
                     }
-                    nodes[id] = r;
-                    atomicAdd(&nodes[pn].nchild, 1);
-                    if (!reuse) {
-                        childtab[(size_t)pn * C + c] = id;
-                        newn[atomicAdd(&s_nnew, 1)] = id;
-                    }
+                    ++dbg_full;
                 }
-                nodes[id].slot = sl;
-                e_node[nxt * BW + sl] = id; e_ch[nxt * BW + sl] = c; e_ds[nxt * BW + sl] = nds;
-                e_bprev[nxt * BW + sl] = -INFINITY; e_nbprev[nxt * BW + sl] = lg; e_score[nxt * BW + sl] = lg;
+                surv[k] = rank < rr;
             }
         }
-        // ---- 4b. PathTrie::remove for the entries that fell out
-        for (int i = tid; i < nb; i += BT) {
-            if (c_surv[NP + i]) continue;
-            Node* n = nodes + node[i];
-            atomicAnd(&n->flags, ~F_EXISTS);
-            n->slot = -1;
+        int within[KMAX], fwithin[KMAX];
+        int wcount = 0, fcount = 0;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const unsigned long long bs = __ballot(surv[k]), bf = __ballot(surv[k] && mark[k] == 1);
+            within[k] = wcount + __builtin_popcountll(bs & lt_mask); wcount += __builtin_popcountll(bs);
+            fwithin[k] = fcount + __builtin_popcountll(bf & lt_mask); fcount += __builtin_popcountll(bf);
+        }
+        if (lane == 0) { wsurv[wid] = wcount; wfresh[wid] = fcount; }
+        __syncthreads();
+
+        // ---- F5: slot numbers of the next beam
+        int sbase = 0, fbase = 0, nnext = 0, nfresh = 0;
+        for (int w = 0; w < NWAVE; ++w) { const int v = wsurv[w], f = wfresh[w]; nnext += v; nfresh += f; if (w < wid) { sbase += v; fbase += f; } }
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int idx = tid + k * BT;
+            if (idx < nb) newslot[idx] = surv[k] ? sbase + within[k] : -1;
+            if (surv[k]) {
+                atomicMin((unsigned long long*)&s_kmin, (unsigned long long)key[k]);
+                atomicMax((unsigned long long*)&s_kmax, (unsigned long long)key[k]);
+                if (mark[k] >= 2) {
+                    const int p = idx - nb; const int i = min((int)(((float)p + 0.5f) * invC), nb - 1), c = p - i * C;
+                    cellc[i * C + c] = (short)(-2 - (sbase + within[k]));       // this edge's dormant top is a beam entry again
+                    s_nrev = 1;
+                }
+            }
         }
         __syncthreads();
-        {   // fresh nodes start with an empty child row
-            const int nnew = s_nnew;
-            for (int q = tid; q < nnew * C; q += BT) { const int j = q / C; childtab[(size_t)newn[j] * C + (q - j * C)] = -1; }
+
+        // ---- F6: commit
+        if (s_nrev) {     // the walk below reads node records other waves have stored: have every store land first
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
         }
-        for (int i = tid; i < nb; i += BT) {
-            if (c_surv[NP + i]) continue;
-            int n = node[i];
-            while (n > 0) {
-                Node* r = nodes + n;
-                if (atomicAdd(&r->nchild, 0) != 0) break;
-                const int f = atomicAdd(&r->flags, 0);
-                if (f & F_EXISTS) break;
-                if (atomicOr(&r->flags, F_DELETED) & F_DELETED) break;    // someone else unlinked it
-                const int p = r->parent;
-                if (atomicSub(&nodes[p].nchild, 1) != 1) break;
-                n = p;
+        // an entry's edge tuple in the new slot numbers: through ancestors that left the beam, under a top that came back
+        auto resolve = [&](Tup tp, int node_j, int walk_from, int walk_depth, int ch_j, double own_j) -> Tup {
+            while (tp.up >= 0) {
+                const int m = cellc[tp.up * C + tp.upch];
+                if (m <= -2 && tp.upnode != node_j) {
+                    int n = walk_from;
+                    const int hops = walk_depth - depth[tp.up] - 2;
+                    for (int h = 0; h < hops; ++h) n = nodes[n].parent;
+                    dbg_hops += hops > 0 ? hops : 0;
+                    Tup r; r.up = -2 - m; r.upnode = n;
+                    if (n == node_j) { r.upch = ch_j; r.uplpc = own_j; }
+                    else { const NodeRec x = nodes[n]; r.upch = x.ch; r.uplpc = x.lpc; }
+                    return r;
+                }
+                const int ns = newslot[tp.up];
+                if (ns >= 0) { tp.up = ns; return tp; }
+                const int P = tp.up;                         // P left the beam: it is part of this edge now
+                tp.up = up[P]; tp.upch = upch[P]; tp.upnode = upnode[P]; tp.uplpc = uplpc[P];
             }
+            return Tup{-1, -1, -1, -INFINITY};
+        };
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            if (!surv[k]) continue;
+            const int idx = tid + k * BT, sl = sbase + within[k];
+            const double lg = unokey(key[k]);
+            const size_t o = (size_t)nxt * BW + sl;
+            int* nctxp = e_ctx + o * MAXCTX;
+            if (mark[k] == 0) {                                  // an entry that stays
+                const int j = idx;
+                const bool direct = upnode[j] == node[j];
+                const double own = direct ? uplpc[j] : ownlpc[j];
+                const Tup tp = resolve(Tup{up[j], upch[j], upnode[j], uplpc[j]}, node[j], node[j], depth[j], ech[j], own);
+                e_node[o] = node[j]; e_ch[o] = ech[j]; e_ds[o] = eds[j]; e_depth[o] = depth[j]; e_memo[o] = memo[j];
+                e_bprev[o] = e_bcur[j]; e_nbprev[o] = e_nbcur[j]; e_score[o] = lg; e_ownlpc[o] = own;
+                e_up[o] = tp.up; e_upch[o] = tp.upch; e_upnode[o] = tp.upnode; e_uplpc[o] = tp.uplpc;
+                for (int q = 0; q < MAXCTX; ++q) nctxp[q] = ctx[(size_t)j * MAXCTX + q];
+                if (tp.up >= 0) celln[tp.up * C + tp.upch] = (short)sl;
+                continue;
+            }
+            const int p = idx - nb;
+            const int i = min((int)(((float)p + 0.5f) * invC), nb - 1), c = p - i * C;
+            const bool sp = a.has_lm && c == a.space;
+            int id; double lpc;
+            if (mark[k] == 1) {                                  // a new node
+                id = nn + fbase + fwithin[k];
+                lpc = lpv[c];
+                NodeRec r; r.parent = node[i]; r.ch = c; r.tstep = t; r.depth = depth[i] + 1; r.lpc = lpc; r.pad = 0.0;
+                nodes[id] = r;
+            } else {                                             // a dormant prefix is back: same node, its log_prob_c kept
+                const int rep = mark[k] - 2;
+                id = upnode[rep]; lpc = uplpc[rep];
+                ++dbg_rev;
+            }
+            int nds = 0;
+            if (a.has_lm && !sp) nds = mark[k] == 1 ? arcv[k] : a.trie_next[(size_t)eds[i] * C + c];
+            const int* pctx = ctx + (size_t)i * MAXCTX;
+            for (int q = 0; q < MAXCTX; ++q) {
+                int v = pctx[q];
+                if (sp) v = q + 1 < NCTX ? pctx[q + 1] : (q + 1 == NCTX ? arcv[k] : a.bos);
+                nctxp[q] = v;
+            }
+            Tup tp{newslot[i], c, id, lpc};
+            if (tp.up < 0) tp = resolve(Tup{up[i], upch[i], upnode[i], uplpc[i]}, id, node[i], depth[i], c, lpc);
+            e_node[o] = id; e_ch[o] = c; e_ds[o] = nds; e_depth[o] = depth[i] + 1; e_memo[o] = MEMO_UNSET;
+            e_bprev[o] = -INFINITY; e_nbprev[o] = lg; e_score[o] = lg; e_ownlpc[o] = lpc;
+            e_up[o] = tp.up; e_upch[o] = tp.upch; e_upnode[o] = tp.upnode; e_uplpc[o] = tp.uplpc;
+            if (tp.up >= 0) celln[tp.up * C + tp.upch] = (short)sl;
         }
+        nn += nfresh;
         if (tid == 0) s_nb = nnext;
         __syncthreads();
         cur = nxt;
     }
 
     // ---- final: trailing partial word, order, write out
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     {
         const int nb = s_nb;
-        double* score = e_score + cur * BW; int* node = e_node + cur * BW; int* ech = e_ch + cur * BW;
+        double* score = e_score + cur * BW; const int* node = e_node + cur * BW; const int* ech = e_ch + cur * BW;
+        const int* eds = e_ds + cur * BW; const int* depth = e_depth + cur * BW; const int* ctx = e_ctx + (size_t)cur * BW * MAXCTX;
         if (a.has_lm) {
             for (int i = tid; i < nb; i += BT) {
-                const int n = node[i];
-                if (n != 0 && ech[i] != a.space) {
-                    const int w = a.trie_word[nodes[n].dstate];
+                if (node[i] != 0 && ech[i] != a.space) {
+                    const int w = a.trie_word[eds[i]];
                     double lm = kOovScore;
-                    if (w >= 0) lm = (double)lm_cond_log10(a.lm, nodes[n].ctx, NCTX, w, a.unk) / (double)kLog10E;
+                    if (w >= 0) lm = (double)lm_word_log10(s_lm, ctx + (size_t)i * MAXCTX, NCTX, w, a.unk) / (double)kLog10E;
                     double s = lm * a.alpha;
                     s += a.beta;
                     score[i] += s;
@@ -474,16 +549,27 @@ __global__ __launch_bounds__(BT) void beam_kernel(BeamArgs a) {
                 if (j == i) continue;
                 rank += score[j] > score[i] || (score[j] == score[i] && (ech[j] < ech[i] || (ech[j] == ech[i] && j < i)));
             }
-            int len = 0;
-            for (int n = node[i]; n > 0; n = nodes[n].parent) ++len;
+            const int len = depth[i];
             const size_t o = ((size_t)b * BW + rank) * a.T;
-            int k = len;
-            for (int n = node[i]; n > 0; n = nodes[n].parent) { --k; a.out_tok[o + k] = nodes[n].ch; a.out_step[o + k] = nodes[n].tstep; }
+            int n = node[i];
+            for (int k = len - 1; k >= 0; --k) { const NodeRec r = nodes[n]; a.out_tok[o + k] = r.ch; a.out_step[o + k] = r.tstep; n = r.parent; }
             a.out_len[(size_t)b * BW + rank] = len;
             a.out_score[(size_t)b * BW + rank] = score[i];
         }
         if (tid == 0) a.out_n[b] = nb;
     }
+    if (a.dbg) {
+        dbg_rev = wave_sum(dbg_rev); dbg_hops = wave_sum(dbg_hops); dbg_list = wave_sum(dbg_list); dbg_full = wave_sum(dbg_full);
+        if (lane == 0) { atomicAdd(a.dbg + 4 * b, dbg_rev); atomicAdd(a.dbg + 4 * b + 1, dbg_hops); atomicAdd(a.dbg + 4 * b + 2, dbg_list); atomicAdd(a.dbg + 4 * b + 3, dbg_full); }
+    }
+#undef s_nb
+#undef s_bstar
+#undef s_r
+#undef s_mb
+#undef s_nlist
+#undef s_nrev
+#undef s_kmin
+#undef s_kmax
 }
 
 }  // namespace
@@ -510,6 +596,7 @@ struct dsmi_decoder {
     bool beam_pending = false;
     int pb_B = 0, pb_To = 0, pb_beam = 0;
     size_t pb_out = 0, pb_out_bytes = 0; hipStream_t pb_stream = nullptr;
+    int32_t stats[4] = {0, 0, 0, 0};      // of the last collected search: see dsmi_decoder_beam_stats
     int32_t* pin_sz = nullptr; size_t pin_sz_cap = 0;
     unsigned char* pin = nullptr; size_t pin_bytes = 0;
     hipEvent_t beam_done = nullptr;
@@ -624,7 +711,7 @@ extern "C" int dsmi_greedy(dsmi_decoder* d, const float* probs, const int32_t* s
     return DSMI_OK;
 }
 
-// Launches the beam search of a batch and the copies of its results into pinned host memory, all asynchronous on `stream`.
+// Launches the beam search of a batch, asynchronous on `stream`; dsmi_beam_collect copies the results.
 extern "C" int dsmi_beam_enqueue(dsmi_decoder* d, const float* probs, const int32_t* sizes, int B, int To, int beam, int cutoff_top_n,
                                  double cutoff_prob, void* stream) {
     if (!d) return DSMI_ERR_INVALID;
@@ -632,19 +719,16 @@ extern "C" int dsmi_beam_enqueue(dsmi_decoder* d, const float* probs, const int3
     if (!probs || B < 1 || To < 1 || beam < 1) { d->err = "bad beam arguments"; return DSMI_ERR_INVALID; }
     if (d->beam_pending) { d->err = "the previous beam search has not been collected"; return DSMI_ERR_INVALID; }
     const size_t NMAX = (size_t)beam * (C + 1);
-    const size_t lds = sizeof(double) * (128 + 2 + 6 * (size_t)beam + 3 * (size_t)beam) + sizeof(uint64_t) * (NMAX + 2 + 2 * NWAVE) +
-                       sizeof(int) * (6 * (size_t)beam + 2 * NMAX + (size_t)beam + 128) + sizeof(unsigned) * 512 +
-                       sizeof(int) * (NWAVE + 1 + 8) + 64;
-    if (lds > 160 * 1024 - 256) { d->err = "beam_width * (n_labels + 1) exceeds the on-chip candidate buffer"; return DSMI_ERR_CAPACITY; }
+    static const int BT = getenv("DSMI_BEAM_THREADS") ? atoi(getenv("DSMI_BEAM_THREADS")) : 1024;      // (experiment switch)
+    const size_t lds = carve(beam, C, BT).bytes;
+    if (lds > 160 * 1024 - 256 || NMAX > (size_t)(BT == 1024 ? 9 : 17) * BT || beam > BT || C > MAXC) { d->err = "beam_width * (n_labels + 1) exceeds the on-chip candidate buffer"; return DSMI_ERR_CAPACITY; }
     DEC_HIP(d, hipSetDevice(d->device));
     hipStream_t s = (hipStream_t)stream;
     // ---- workspace carve
     const int ncap = 2 + To * beam;
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     size_t off = 0;
-    size_t o_nodes = off; off += al((size_t)B * ncap * sizeof(Node));
-    size_t o_child = off; off += al((size_t)B * ncap * C * 4);
-    size_t o_nn = off; off += al((size_t)B * 4);
+    size_t o_nodes = off; off += al((size_t)B * ncap * sizeof(NodeRec));
     size_t o_sizes = off; off += al((size_t)B * 4);
     // outputs, contiguous, in the order of the pinned image: tokens, steps, lens, counts, scores
     const size_t o_out = off;
@@ -653,6 +737,7 @@ extern "C" int dsmi_beam_enqueue(dsmi_decoder* d, const float* probs, const int3
     size_t o_len = off; off += al((size_t)B * beam * 4);
     size_t o_n = off; off += al((size_t)B * 4);
     size_t o_score = off; off += al((size_t)B * beam * 8);
+    size_t o_dbg = off; off += al((size_t)B * 16);
     const size_t out_bytes = off - o_out;
     if (off > d->ws_bytes) {
         DEC_HIP(d, hipDeviceSynchronize());
@@ -676,7 +761,7 @@ extern "C" int dsmi_beam_enqueue(dsmi_decoder* d, const float* probs, const int3
     a.has_lm = d->has_lm ? 1 : 0; a.order = d->has_lm ? d->lm.order : 1; a.alpha = d->alpha; a.beta = d->beta;
     a.lm = d->lm.view(); a.lm.tab = d->d_tab; a.lm.klm.base = d->d_klm; a.trie_next = d->d_next; a.trie_word = d->d_word; a.unk = d->lm.unk; a.bos = d->lm.bos;
     a.ncap = ncap;
-    a.nodes = (Node*)(w + o_nodes); a.childtab = (int32_t*)(w + o_child); a.nnodes = (int32_t*)(w + o_nn);
+    a.nodes = (NodeRec*)(w + o_nodes); a.dbg = (int32_t*)(w + o_dbg);
     a.out_tok = (int32_t*)(w + o_tok); a.out_step = (int32_t*)(w + o_step); a.out_len = (int32_t*)(w + o_len); a.out_n = (int32_t*)(w + o_n);
     a.out_score = (double*)(w + o_score);
     a.sizes = nullptr;
@@ -693,8 +778,23 @@ extern "C" int dsmi_beam_enqueue(dsmi_decoder* d, const float* probs, const int3
         a.sizes = (const int32_t*)(w + o_sizes);
     }
     DEC_HIP(d, hipMemsetAsync(w + o_len, 0, (size_t)B * beam * 4, s));
-    DEC_HIP(d, hipFuncSetAttribute(reinterpret_cast<const void*>(beam_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(beam_kernel, dim3(B), dim3(BT), lds, s, a);
+    DEC_HIP(d, hipMemsetAsync(w + o_dbg, 0, (size_t)B * 16, s));
+    // candidates per thread: a compile-time bound, so that they live in registers
+    auto launch = [&](auto kern) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(B), dim3(BT), lds, s, a);
+        return hipSuccess;
+    };
+    if (BT == 1024) {
+        if (NMAX <= (size_t)3 * BT) DEC_HIP(d, launch(beam_kernel<1024, 3>));
+        else if (NMAX <= (size_t)5 * BT) DEC_HIP(d, launch(beam_kernel<1024, 5>));
+        else DEC_HIP(d, launch(beam_kernel<1024, 9>));
+    } else {
+        if (NMAX <= (size_t)5 * BT) DEC_HIP(d, launch(beam_kernel<512, 5>));
+        else if (NMAX <= (size_t)9 * BT) DEC_HIP(d, launch(beam_kernel<512, 9>));
+        else DEC_HIP(d, launch(beam_kernel<512, 17>));
+    }
     DEC_HIP(d, hipGetLastError());
     // Only the kernel is queued here.  A device-to-host copy queued behind it would sit in a DMA queue until the search is
     // over, and with it whatever upload another stream has been given the same engine for -- the next batch's samples: its
@@ -717,19 +817,25 @@ extern "C" int dsmi_beam_collect(dsmi_decoder* d, int32_t* tokens, int32_t* tste
     const size_t tok_bytes = al((size_t)B * beam * To * 4);
     // lengths, counts and scores first (they are behind the two token arrays in the image) ...
     const unsigned char* dev = d->ws + d->pb_out;
-    DEC_HIP(d, hipMemcpy(d->pin + 2 * tok_bytes, dev + 2 * tok_bytes, d->pb_out_bytes - 2 * tok_bytes, hipMemcpyDeviceToHost));
+    // (on the search's own stream, which is idle once the search is over: a blocking copy would go to the null stream and
+    // wait there for whatever forward the caller has queued meanwhile)
+    DEC_HIP(d, hipMemcpyAsync(d->pin + 2 * tok_bytes, dev + 2 * tok_bytes, d->pb_out_bytes - 2 * tok_bytes, hipMemcpyDeviceToHost, d->pb_stream));
+    DEC_HIP(d, hipStreamSynchronize(d->pb_stream));
     const unsigned char* q0 = d->pin;
     const int32_t* p_tok = reinterpret_cast<const int32_t*>(q0); q0 += tok_bytes;
     const int32_t* p_step = reinterpret_cast<const int32_t*>(q0); q0 += tok_bytes;
     const int32_t* h_len = reinterpret_cast<const int32_t*>(q0); q0 += al((size_t)B * beam * 4);
     const int32_t* h_n = reinterpret_cast<const int32_t*>(q0); q0 += al((size_t)B * 4);
-    const double* h_score = reinterpret_cast<const double*>(q0);
+    const double* h_score = reinterpret_cast<const double*>(q0); q0 += al((size_t)B * beam * 8);
+    const int32_t* h_dbg = reinterpret_cast<const int32_t*>(q0);
+    for (int k = 0; k < 4; ++k) { d->stats[k] = 0; for (int b = 0; b < B; ++b) d->stats[k] += h_dbg[4 * b + k]; }
     // ... then, of the token arrays, only the columns that hold tokens: transcripts are a fraction of T_out long
     int maxlen = 0;
     for (size_t i = 0; i < (size_t)B * beam; ++i) maxlen = std::max(maxlen, (int)h_len[i]);
     if (maxlen > 0) {
-        DEC_HIP(d, hipMemcpy2D(d->pin, (size_t)To * 4, dev, (size_t)To * 4, (size_t)maxlen * 4, (size_t)B * beam, hipMemcpyDeviceToHost));
-        DEC_HIP(d, hipMemcpy2D(d->pin + tok_bytes, (size_t)To * 4, dev + tok_bytes, (size_t)To * 4, (size_t)maxlen * 4, (size_t)B * beam, hipMemcpyDeviceToHost));
+        DEC_HIP(d, hipMemcpy2DAsync(d->pin, (size_t)To * 4, dev, (size_t)To * 4, (size_t)maxlen * 4, (size_t)B * beam, hipMemcpyDeviceToHost, d->pb_stream));
+        DEC_HIP(d, hipMemcpy2DAsync(d->pin + tok_bytes, (size_t)To * 4, dev + tok_bytes, (size_t)To * 4, (size_t)maxlen * 4, (size_t)B * beam, hipMemcpyDeviceToHost, d->pb_stream));
+        DEC_HIP(d, hipStreamSynchronize(d->pb_stream));
     }
     for (size_t r = 0; r < (size_t)B * beam && maxlen > 0; ++r) {
         std::memcpy(tokens + r * To, p_tok + r * To, (size_t)maxlen * 4);
@@ -759,6 +865,12 @@ extern "C" int dsmi_beam_collect(dsmi_decoder* d, int32_t* tokens, int32_t* tste
             }
             scores[q] = (float)-approx;
         }
+    return DSMI_OK;
+}
+
+extern "C" int dsmi_decoder_beam_stats(const dsmi_decoder* d, int32_t* counts4) {
+    if (!d || !counts4) return DSMI_ERR_INVALID;
+    for (int k = 0; k < 4; ++k) counts4[k] = d->stats[k];
     return DSMI_OK;
 }
 

@@ -118,21 +118,23 @@ def scatter_ragged(clips, rank, world, device):
     return mine[:totals[rank]], lengths[idx].astype(np.int64), idx, lengths
 
 
-def gather_texts(texts, indices, count, cap, rank, world, device):
+def gather_texts(texts, indices, count, cap, rank, world, device, beams=1):
     """Every rank passes the transcripts of its shard (``indices`` = their positions in the original list); rank 0
     returns the ``count`` transcripts in the caller's order.  Fixed payload: ``cap`` UTF-32 code points + length +
-    position per clip, one ``gather``."""
+    position per clip, one ``gather``.  With ``beams`` > 1 every element of ``texts`` is a list of up to that many
+    strings (all beams of a clip, best first) and lists come back."""
     import torch
     import torch.distributed as dist
     per = (count + world - 1) // world                       # plan_shards gives every rank at most this many
-    buf = np.zeros((per, cap + 2), dtype=np.int32)
-    buf[:, 0] = -1
+    buf = np.zeros((per, beams, cap + 2), dtype=np.int32)
+    buf[:, :, 0] = -1
     for row, (text, i) in enumerate(zip(texts, indices)):
-        codes = np.frombuffer(text.encode("utf-32-le"), dtype="<u4").astype(np.int32)
-        if len(codes) > cap:
-            raise ValueError("transcript longer than the frame count it was decoded from")
-        buf[row, 0], buf[row, 1] = i, len(codes)
-        buf[row, 2:2 + len(codes)] = codes
+        for k, one in enumerate([text] if beams == 1 else list(text)[:beams]):
+            codes = np.frombuffer(one.encode("utf-32-le"), dtype="<u4").astype(np.int32)
+            if len(codes) > cap:
+                raise ValueError("transcript longer than the frame count it was decoded from")
+            buf[row, k, 0], buf[row, k, 1] = i, len(codes)
+            buf[row, k, 2:2 + len(codes)] = codes
     t = torch.from_numpy(buf).to(device)
     if world == 1:
         outs = [t]
@@ -141,20 +143,51 @@ def gather_texts(texts, indices, count, cap, rank, world, device):
         dist.gather(t, gather_list=outs, dst=0)
         if rank != 0:
             return None
-    res = [None] * count
+    res = [None] * count if beams == 1 else [[] for _ in range(count)]
     for o in outs:
         a = o.cpu().numpy()
-        for row in a:
-            if row[0] >= 0:
-                res[int(row[0])] = row[2:2 + row[1]].astype("<u4").tobytes().decode("utf-32-le")
+        for clip in a:
+            for row in clip:
+                if row[0] < 0:
+                    continue
+                text = row[2:2 + row[1]].astype("<u4").tobytes().decode("utf-32-le")
+                if beams == 1:
+                    res[int(row[0])] = text
+                else:
+                    res[int(row[0])].append(text)
     return res
 
 
-def recognize_sharded(engine, clips, rank, world, device, frames_cap=None):
-    """``engine.transcribe_batch(clips)`` over ``world`` ranks: rank 0 passes the list and gets the transcripts back
-    in its order; the other ranks pass ``None`` and get ``None``.  ``engine`` needs
-    ``transcribe_device(pcm, n_samples) -> list[str]`` (``DanSpeechRecognizer``; the CPU tests pass a stand-in)."""
+def recognize_sharded(engine, clips, rank, world, device, frames_cap=None, show_all=False, max_batch=32):
+    """``engine.transcribe_batch(clips, show_all)`` over ``world`` ranks: rank 0 passes the list and gets the results
+    back in its order; the other ranks pass ``None`` and get ``None``.  ``engine`` needs
+    ``transcribe_device(pcm, n_samples, show_all, max_batch)`` (``DanSpeechRecognizer``: the shard runs as a pipelined
+    sequence of batches of at most ``max_batch`` clips; the CPU tests pass a stand-in).  Exchanges: the header broadcasts
+    and ONE scatter in, ONE gather out, and between them one three-word all-reduce (MAX): "some rank failed" (then every
+    rank raises instead of one rank leaving the others in the gather), the beam count and the longest transcript (the
+    width every rank pads to when all beams travel)."""
+    import torch
+    import torch.distributed as dist
     pcm, n, idx, lengths = scatter_ragged(clips, rank, world, device)
-    texts = engine.transcribe_device(pcm, n) if len(n) else []
+    # every validation that can fail on one rank only comes BEFORE the gather, and a failure is shared: a rank that raised
+    # alone would leave the others waiting in the collective for ever
+    err, results = None, []
+    try:
+        results = engine.transcribe_device(pcm, n, show_all=show_all, max_batch=max_batch) if len(n) else []
+    except Exception as e:           # noqa: BLE001 -- re-raised below on every rank
+        err = e
     cap = frames_cap if frames_cap is not None else int(lengths.max() // 160 + 1) if len(lengths) else 1
-    return gather_texts(texts, idx, len(lengths), cap, rank, world, device)
+    beams = 1
+    longest = max([len(t) for r in results for t in ([r] if not show_all else r)] + [0])
+    if world > 1:
+        word = torch.tensor([1 if err is not None else 0, max([len(r) for r in results] + [1]) if show_all else 1, longest],
+                            dtype=torch.int64, device=device)
+        dist.all_reduce(word, op=dist.ReduceOp.MAX)
+        failed, beams, longest = int(word[0]), int(word[1]), int(word[2])
+    else:
+        failed, beams = int(err is not None), (max([len(r) for r in results] + [1]) if show_all else 1)
+    if failed:
+        raise err if err is not None else RuntimeError("recognize_sharded: another rank failed")
+    if show_all:
+        cap = max(longest, 1)                      # beams x frames code points per clip would be megabytes: use the real width
+    return gather_texts(results, idx, len(lengths), cap, rank, world, device, beams=beams)

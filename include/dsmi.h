@@ -255,12 +255,16 @@ int dsmi_beam(dsmi_decoder* d, const float* probs_dev, const int32_t* sizes_host
               int beam_width, int cutoff_top_n, double cutoff_prob, int32_t* tokens_host,
               int32_t* tsteps_host, int32_t* lens_host, float* scores_host, void* stream);
 /* The two halves of dsmi_beam, for callers that keep the GPU busy meanwhile (ctcdecode decodes on a host thread pool while
- * the caller waits; here the search itself is a kernel): dsmi_beam_enqueue launches the search and the copies of its results
- * into pinned memory of the handle, asynchronously on `stream` (probs_dev must stay valid until the collect);
- * dsmi_beam_collect waits for them and fills the arrays.  One search per decoder handle at a time. */
+ * the caller waits; here the search itself is a kernel): dsmi_beam_enqueue launches the search asynchronously on `stream`
+ * (probs_dev must stay valid until the collect); dsmi_beam_collect waits for it, copies the results (on that stream, into
+ * pinned memory of the handle) and fills the arrays.  One search per decoder handle at a time.
+ * dsmi_decoder_beam_stats: how often the last collected search left its fast path, summed over the batch -- counts4 =
+ * {dormant prefixes that re-entered the beam, node-pool hops walked for them, exact rankings of a threshold bin from the
+ * list, exact rankings against all candidates}; diagnostics for the tests and profiles, no reference counterpart. */
 int dsmi_beam_enqueue(dsmi_decoder* d, const float* probs_dev, const int32_t* sizes_host, int B, int T_out,
                       int beam_width, int cutoff_top_n, double cutoff_prob, void* stream);
 int dsmi_beam_collect(dsmi_decoder* d, int32_t* tokens_host, int32_t* tsteps_host, int32_t* lens_host, float* scores_host);
+int dsmi_decoder_beam_stats(const dsmi_decoder* d, int32_t* counts4);
 
 /* ---- Host-only view of a language model file (no GPU involved): what dsmi_decoder_set_lm would load.
  * kind: 0 ARPA text, 1 KenLM probing binary, 2 KenLM trie binary.  Word ids are the file's own (KenLM's WordIndex for

@@ -60,6 +60,45 @@ def test_beam_no_lm_small_alphabet_exhaustive(native):
     _compare(native, probs, None, "_ab ", beam=64)
 
 
+def test_beam_dormant_prefixes_come_back(native):
+    """Flat noisy rows and narrow beams: prefixes leave the beam while their extensions stay and come back later.  The
+    kernel then re-hangs the entries below them by a walk through its node pool -- the one slow path of its frame loop
+    (oracle/beam_flat.py is the same formulation on the CPU; tests/test_oracle_beam_flat.py shows these inputs take it)."""
+    rng = np.random.default_rng(42)
+    probs = rng.dirichlet(np.ones(4) * 0.6, size=(24, 40)).astype(np.float32)
+    revivals = 0
+    for beam in (2, 3, 5, 9):
+        dec = native.NativeDecoder("_abc", blank_index=0)
+        dec.beam(_dev(probs), None, beam_width=beam)
+        revivals += dec.beam_stats()["revivals"]
+        dec.close()
+        _compare(native, probs, None, "_abc", beam=beam)
+    assert revivals > 0
+
+
+def test_beam_exact_ties_and_flat_rows(native):
+    """Uniform rows: every candidate of a frame ties in the selection histogram's threshold bin (the exact ranking of a bin
+    that is larger than the on-chip list) and scores tie exactly; zero rows (log(FLT_MIN)) pile up in the last bin."""
+    labels = syn.DANSPEECH_LABELS
+    C = len(labels)
+    probs = np.full((2, 12, C), 1.0 / C, dtype=np.float32)
+    probs[1, 3:6, 5:] = 0.0
+    probs[1, 3:6, :5] = 0.2
+    dec = native.NativeDecoder(labels, blank_index=0)
+    tok, ts, ln, sc = dec.beam(_dev(probs), None, beam_width=24)
+    st = dec.beam_stats()
+    dec.close()
+    assert st["list_rankings"] + st["full_rankings"] > 0
+    # exact ties fall by (character, candidate index), and the index follows the kernel's slot numbering: compare with the
+    # CPU formulation that numbers slots the same way (against oracle/beam.py only the non-tied cases are determined)
+    from oracle import beam_flat as bf
+    for b in range(2):
+        res = bf.ctc_beam_search(probs[b].astype(np.float64), labels, 24)
+        for p, (score, tokens, steps) in enumerate(res):
+            assert list(tok[b, p, :ln[b, p]]) == tokens and list(ts[b, p, :ln[b, p]]) == steps, (b, p)
+            assert abs(float(sc[b, p]) - score) < 1e-4
+
+
 def test_beam_no_lm_danspeech_labels(native):
     rng = np.random.default_rng(1)
     labels = syn.DANSPEECH_LABELS

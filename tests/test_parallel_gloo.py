@@ -15,13 +15,18 @@ class _EchoEngine:
     """Stands in for DanSpeechRecognizer on the CPU: the "transcript" of a clip is a function of its samples, so the
     test can tell that every clip reached exactly one rank intact and came back at its own position."""
 
-    def transcribe_device(self, pcm, n_samples):
+    fail_on = None
+
+    def transcribe_device(self, pcm, n_samples, show_all=False, max_batch=None):
         out, off = [], 0
+        if self.fail_on is not None and dist.get_rank() == self.fail_on:
+            raise ValueError("boom on rank %d" % self.fail_on)
         assert list(n_samples) == sorted(n_samples, reverse=True)          # each shard arrives longest first
         for n in n_samples:
             clip = pcm[off:off + int(n)].to(torch.float64).numpy()
             off += int(n)
-            out.append("n%d s%d \u00e6\u00f8" % (len(clip), int(clip.sum())))
+            text = "n%d s%d \u00e6\u00f8" % (len(clip), int(clip.sum()))
+            out.append([text, text + "!", "x" * (len(clip) % 7)] if show_all else text)
         assert off == pcm.numel()
         return out
 
@@ -54,6 +59,25 @@ def _worker(rank, world, port, q):
             ok = ok and res == ["n%d s%d \u00e6\u00f8" % (len(c), int(c.astype(np.float64).sum())) for c in clips]
         else:
             ok = ok and res is None
+    # all beams of every clip (lists of strings, padded to the longest transcript of any rank)
+    rng = np.random.default_rng(6)
+    clips = [rng.integers(-3000, 3000, size=k).astype(np.int16) for k in (90, 401, 33, 250, 12)]
+    res = parallel.recognize_sharded(_EchoEngine(), clips if rank == 0 else None, rank, world, cpu, show_all=True)
+    if rank == 0:
+        base = ["n%d s%d \u00e6\u00f8" % (len(c), int(c.astype(np.float64).sum())) for c in clips]
+        ok = ok and res == [[b, b + "!", "x" * (len(c) % 7)] for b, c in zip(base, clips)]
+    else:
+        ok = ok and res is None
+    # an engine that fails on ONE rank: every rank raises, nobody is left waiting in the gather
+    eng = _EchoEngine()
+    eng.fail_on = 1
+    try:
+        parallel.recognize_sharded(eng, clips if rank == 0 else None, rank, world, cpu)
+        ok = False
+    except ValueError as e:
+        ok = ok and rank == 1 and "boom" in str(e)
+    except RuntimeError as e:
+        ok = ok and rank == 0 and "another rank failed" in str(e)
     # fewer clips than ranks: one rank gets nothing
     res = parallel.recognize_sharded(_EchoEngine(), [np.ones(40, np.float32)] if rank == 0 else None, rank, world, cpu, frames_cap=64)
     ok = ok and (res == ["n40 s40 \u00e6\u00f8"] if rank == 0 else res is None)

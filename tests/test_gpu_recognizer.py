@@ -288,3 +288,84 @@ def test_recognize_files_groups_by_format_and_segment_takes_raw_wav_frames(tmp_p
     b = fe.segment(torch.from_numpy(load_audio(WAV)).cuda(), energy_threshold=300)
     assert np.array_equal(a, b)
     fe.close()
+
+
+# ---- the reference's own lines around librosa / ctcdecode, pinned by tools/gen_golden_surface.py (G10 - G12) --------------
+def test_g10_parsers_on_the_gpu_equal_the_reference_post_stft(golden):
+    """dsmi_features / dsmi_features_stream against what the REFERENCE's parsers (parsers.py:50-72,102-164) make of the
+    documented STFT: log1p, float32, unbiased std; hop carry-over and drifting statistics.  (The STFT itself: unpinned.)"""
+    import json
+    from danspeech_amd.audio import load_audio
+    from danspeech_amd.audio.parsers import SpectrogramAudioParser, InferenceSpectrogramAudioParser
+    g = golden("g10_parsers")
+    clips = {"wav": load_audio(WAV), "c0": syn.make_clip(0, 16000), "c1": syn.make_clip(1, 4321), "short": syn.make_clip(2, 700)}
+    for name, y in clips.items():
+        for normalize in (True, False):
+            want = g["spect_%s_%d" % (name, normalize)]
+            got = SpectrogramAudioParser({"normalize": normalize}).parse_audio(y).cpu().numpy()
+            assert got.shape == want.shape
+            np.testing.assert_allclose(got, want, rtol=0, atol=3e-5)
+    p = InferenceSpectrogramAudioParser()
+    for ui, (name, parts) in enumerate(json.loads(str(g["stream_plan"]))):
+        y, pos = clips[name], 0
+        for k, n in enumerate(parts):
+            s = p.parse_audio(y[pos:pos + n], is_last=(k == len(parts) - 1))
+            pos += n
+            want = g["stream_u%d_p%d" % (ui, k)]
+            if want.size == 0:
+                assert len(s) == 0
+            else:
+                np.testing.assert_allclose(s.cpu().numpy(), want, rtol=0, atol=3e-5)
+            np.testing.assert_allclose([p.input_mean, p.input_std, p.alpha], g["stream_u%d_p%d_state" % (ui, k)], rtol=2e-6, atol=1e-6)
+        p.reset()
+
+
+def test_g11_recognize_end_to_end_equals_the_reference_run():
+    """SURVEY 8(c) G6 part 2: Recognizer.recognize on the GPU against the REFERENCE's own Recognizer.recognize (torch CPU model,
+    seeded weights, the documented STFT), for the greedy steps of the recorded scenario; probabilities against the
+    reference model's."""
+    import json
+    from danspeech_amd import Recognizer
+    from danspeech_amd.deepspeech.model import DeepSpeech
+    gold = json.load(open(os.path.join(HERE, "golden", "g11_surface.json"), encoding="utf-8"))
+    z = np.load(os.path.join(HERE, "golden", "g11_surface.npz"))
+    cfg = gold["cfg"]
+    sd = syn.make_state_dict(2, "gru", cfg["rnn_hidden_size"], cfg["rnn_layers"], seed=gold["seed"], **syn.TALKATIVE)
+
+    def model(name, labels):
+        return DeepSpeech(name, labels=labels, rnn_hidden_size=cfg["rnn_hidden_size"], rnn_layers=cfg["rnn_layers"]).load_state_dict(sd)
+
+    models = {"m1": model("golden-m1", gold["labels"]), "m2": model("golden-m2", gold["other_labels"])}
+    clips = [syn.make_clip(*c) for c in gold["clip_ids"]]
+    rec, checked = None, 0
+    for ev in gold["events"]:
+        op = ev["op"]
+        if op[0] == "new":
+            kw = dict(op[1])
+            name = kw.pop("model")
+            kw.pop("lm", None)                     # "/other/lm.klm" does not exist: the beam steps belong to test_gpu_beam.py
+            rec = Recognizer(model=models[name], **kw)
+        elif op[0] == "update_model":
+            rec.update_model(models[op[1]])
+        elif op[0] == "update_decoder" and op[1].get("lm") in (None, "greedy"):
+            rec.update_decoder(**op[1])
+        elif op[0] == "recognize" and ev["state"]["decoder"] == "GreedyDecoder" and rec.danspeech_recognizer.lm == "greedy":
+            got = rec.recognize(clips[op[1]], show_all=op[2])
+            assert got == ev["result"], op
+            checked += 1
+    assert checked >= 3
+    for k, y in enumerate(clips):
+        eng = Recognizer(model=models["m1"]).danspeech_recognizer
+        feats, frames = eng.audio_parser.parse_batch([y])
+        probs, sizes = eng.model(feats, torch.from_numpy(frames.astype(np.int32)))
+        assert sizes.tolist() == z["sizes%d" % k].tolist()
+        np.testing.assert_allclose(probs.cpu().numpy(), z["probs%d" % k], rtol=0, atol=1e-4)
+
+
+def test_g12_reference_accepted_package_runs_on_the_gpu(golden):
+    from danspeech_amd.deepspeech.model import DeepSpeech
+    g = golden("g12_package_forward")
+    m = DeepSpeech.load_model(os.path.join(HERE, "golden", "g12_package.pth")).to("cuda")
+    probs, out_lens = m(torch.from_numpy(g["x"]), torch.from_numpy(g["out_lens"] * 0 + g["x"].shape[-1]))
+    assert out_lens.tolist() == g["out_lens"].tolist()
+    np.testing.assert_allclose(probs.cpu().numpy(), g["probs"], rtol=0, atol=1e-4)

@@ -135,6 +135,8 @@ def test_deepspeech_ctor_contract():
 
 
 def test_model_package_roundtrip(tmp_path):
+    """serialize() -> load_model() here; the package the REFERENCE's loader accepts is tests/golden/g12_package.pth
+    (tests/test_surface_golden.py::test_g12_package_accepted_by_the_reference_loads_here)."""
     import torch
     from danspeech_amd.deepspeech.model import DeepSpeech
     sd = syn.make_state_dict(2, "lstm", 16, 2, seed=2)

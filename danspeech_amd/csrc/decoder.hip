@@ -29,550 +29,8 @@
 
 using namespace dsmi;
 
-namespace {
-
-constexpr int MAXBT = 1024;       // threads per utterance: a template parameter of the kernel (BT)
-constexpr double BIN_SPAN = 64.0; // the selection histogram has one bin per thread, over the 64 nats below the frame's score bound
-constexpr int LISTCAP = 256;      // members of the threshold bin that are ranked from a list (more: ranked against all keys)
-constexpr int MAXCTX = kMaxOrder - 1;
-constexpr int MAXC = 128;
-constexpr int MEMO_UNSET = 0x7fc00001;   // a NaN pattern no float computation produces
-
-// One record of the node pool (HBM).  Written at creation, tstep / lpc updated in place by get_path_trie's "better emission
-// frame" rule; read only when a dormant prefix re-enters the beam (the walk in resolve()) and by the final path output.
-struct __attribute__((aligned(32))) NodeRec { int parent, ch, tstep, depth; double lpc; double pad; };
-static_assert(sizeof(NodeRec) == 32, "NodeRec is two 16-byte stores");
-
-struct BeamArgs {
-    const float* probs; const int32_t* sizes; int T, C, blank, space, beam, cutoff_top_n; float cutoff_prob;
-    int has_lm, order; double alpha, beta;
-    LmView lm; const int32_t* trie_next; const int32_t* trie_word; int unk, bos;
-    int ncap;                    // per-utterance node pool capacity
-    NodeRec* nodes;
-    int32_t* dbg;                // optional [B][4]: dormant prefixes revived, walk hops, list rankings, full rankings
-    // outputs
-    int32_t *out_tok, *out_step, *out_len, *out_n; double* out_score;
-};
-
-// On-chip layout of one utterance's search, shared by the kernel and the launcher's size check.
-struct Carve {
-    size_t lp, sd, bprev, nbprev, score, uplpc, ownlpc, bcur, nbcur, ckey, lkey, su;          // 8-byte items
-    size_t node, ch, ds, depth, up, upch, upnode, memo, ctx, newslot, use, lidx, hist, wtot, wsurv, wfresh, si, pfp;   // 4-byte
-    size_t cell;                                                                                // 2-byte
-    size_t lmv;
-    size_t bytes;
-};
-__host__ __device__ inline Carve carve(int BW, int C, int BT) {
-    const int NBINS = BT, NWAVE = BT / 64;
-    Carve k; size_t o = 0;
-    const size_t NMAX = (size_t)BW * (C + 1);
-    auto take = [&](size_t n, size_t sz) { const size_t at = o; o += ((n * sz + 15) & ~(size_t)15); return at; };
-    k.lp = take(2 * MAXC, 8); k.sd = take(8, 8);
-    k.bprev = take(2 * BW, 8); k.nbprev = take(2 * BW, 8); k.score = take(2 * BW, 8); k.uplpc = take(2 * BW, 8); k.ownlpc = take(2 * BW, 8);
-    k.bcur = take(BW, 8); k.nbcur = take(BW, 8); k.ckey = take(NMAX, 8); k.lkey = take(LISTCAP, 8); k.su = take(4, 8);
-    k.node = take(2 * BW, 4); k.ch = take(2 * BW, 4); k.ds = take(2 * BW, 4); k.depth = take(2 * BW, 4); k.up = take(2 * BW, 4);
-    k.upch = take(2 * BW, 4); k.upnode = take(2 * BW, 4); k.memo = take(2 * BW, 4); k.ctx = take((size_t)2 * BW * MAXCTX, 4);
-    k.newslot = take(BW, 4); k.use = take(2 * MAXC, 4); k.lidx = take(LISTCAP, 4); k.hist = take(NBINS, 4);
-    k.wtot = take(NWAVE, 4); k.wsurv = take(NWAVE, 4); k.wfresh = take(NWAVE, 4); k.si = take(16, 4); k.pfp = take(2 * MAXC, 4);
-    k.cell = take((size_t)2 * (((size_t)BW * C + 1) & ~(size_t)1), 2);
-    k.lmv = take(1, sizeof(LmView));
-    k.bytes = o;
-    return k;
-}
-
-__device__ __forceinline__ double lse2(double x, double y) {
-    // log(exp(x - m) + exp(y - m)) + m with m = max: the larger term's exp is exactly 1
-    if (x == -INFINITY) return y;
-    if (y == -INFINITY) return x;
-    const double m = fmax(x, y), d = fmin(x, y) - m;
-    return log(1.0 + exp(d)) + m;
-}
-
-__device__ __forceinline__ uint64_t okey(double v) {   // order-preserving bits, > 0 for every double
-    uint64_t u = (uint64_t)__double_as_longlong(v);
-    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
-}
-__device__ __forceinline__ double unokey(uint64_t k) {
-    const uint64_t u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
-    return __longlong_as_double((long long)u);
-}
-template <int NBINS>
-__device__ __forceinline__ int score_bin(double U, double s) {     // monotone: a better score never lands in a later bin
-    const double q = (U - s) * (NBINS / BIN_SPAN);
-    if (!(q < (double)(NBINS - 1))) return NBINS - 1;              // also NaN (U - s with both infinite)
-    return q > 0.0 ? (int)q : 0;
-}
-__device__ __forceinline__ int wave_sum(int v) {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
-struct Tup { int up, upch, upnode; double uplpc; };
-
-// The scorer's n-gram look-ups stay out of line: three call sites, rarely taken, a long chain of dependent loads each.
-__device__ __noinline__ float lm_word_log10(const LmView* v, const int32_t* ctx, int n, int32_t w, int32_t unk) {
-    return lm_cond_log10(*v, ctx, n, w, unk);
-}
-
-// CTC prefix beam search of one utterance by one workgroup; the algorithm, array for array, is oracle/beam_flat.py
-// (tests/test_oracle_beam_flat.py holds that formulation to ctcdecode's pointer trie as restated in oracle/beam.py).
-// A frame is six barrier-separated phases, all on LDS; HBM sees fire-and-forget stores (new node records, timestep updates)
-// and, one frame ahead, the load of the next probability row:
-//   F1  every candidate in registers: thread idx < nb = beam entry idx (its blank / repeat terms, and -- pull form -- the
-//       extension it receives from its parent when that is a beam entry), the others = (entry, character) pairs; keys go
-//       into a 1024-bin histogram of (bound - score) at 1/16 nat;
-//   F2  prefix sums of the histogram, wave level; the last wave turns the prefetched row into log-probabilities;
-//   F3  the bin in which the beam_width-th best score lies, and how many of its members survive;
-//   F4  members of that bin ranked exactly (score desc, character asc, index asc) when not all of them survive; survivors
-//       numbered inside each wave;
-//   F5  new slot numbers; what left the beam, which dormant prefixes came back;
-//   F6  commit: the new beam entry by entry into the other buffer (edge tuples resolved through whatever left), node
-//       records to HBM, the child table of the new beam.
-template <int BT, int KMAX>
-__global__ __launch_bounds__(BT) void beam_kernel(BeamArgs a) {
-    constexpr int NWAVE = BT / 64, NBINS = BT;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int C = a.C, BW = a.beam;
-    const Carve kv = carve(BW, C, BT);
-    LmView* s_lm = reinterpret_cast<LmView*>(smem_raw + kv.lmv);
-    double* lp = reinterpret_cast<double*>(smem_raw + kv.lp);            // [2][MAXC] by frame parity
-    double* sd = reinterpret_cast<double*>(smem_raw + kv.sd);            // [0..1] ln p(blank), [2..3] max_c lp
-    double* e_bprev = reinterpret_cast<double*>(smem_raw + kv.bprev);    // entry arrays [2][BW]
-    double* e_nbprev = reinterpret_cast<double*>(smem_raw + kv.nbprev);
-    double* e_score = reinterpret_cast<double*>(smem_raw + kv.score);
-    double* e_uplpc = reinterpret_cast<double*>(smem_raw + kv.uplpc);
-    double* e_ownlpc = reinterpret_cast<double*>(smem_raw + kv.ownlpc);
-    double* e_bcur = reinterpret_cast<double*>(smem_raw + kv.bcur);      // [BW]
-    double* e_nbcur = reinterpret_cast<double*>(smem_raw + kv.nbcur);
-    uint64_t* c_key = reinterpret_cast<uint64_t*>(smem_raw + kv.ckey);   // [NMAX] 0 = no candidate, else okey(score)
-    uint64_t* l_key = reinterpret_cast<uint64_t*>(smem_raw + kv.lkey);   // [LISTCAP]
-    uint64_t* su = reinterpret_cast<uint64_t*>(smem_raw + kv.su);        // [0] smallest, [1] largest key of the beam
-    int* e_node = reinterpret_cast<int*>(smem_raw + kv.node);
-    int* e_ch = reinterpret_cast<int*>(smem_raw + kv.ch);
-    int* e_ds = reinterpret_cast<int*>(smem_raw + kv.ds);
-    int* e_depth = reinterpret_cast<int*>(smem_raw + kv.depth);
-    int* e_up = reinterpret_cast<int*>(smem_raw + kv.up);
-    int* e_upch = reinterpret_cast<int*>(smem_raw + kv.upch);
-    int* e_upnode = reinterpret_cast<int*>(smem_raw + kv.upnode);
-    int* e_memo = reinterpret_cast<int*>(smem_raw + kv.memo);
-    int* e_ctx = reinterpret_cast<int*>(smem_raw + kv.ctx);              // [2][BW][MAXCTX]
-    int* newslot = reinterpret_cast<int*>(smem_raw + kv.newslot);
-    int* usev = reinterpret_cast<int*>(smem_raw + kv.use);               // [2][MAXC]
-    int* l_idx = reinterpret_cast<int*>(smem_raw + kv.lidx);
-    unsigned* hist = reinterpret_cast<unsigned*>(smem_raw + kv.hist);
-    int* wtot = reinterpret_cast<int*>(smem_raw + kv.wtot);
-    int* wsurv = reinterpret_cast<int*>(smem_raw + kv.wsurv);
-    int* wfresh = reinterpret_cast<int*>(smem_raw + kv.wfresh);
-    int* si = reinterpret_cast<int*>(smem_raw + kv.si);
-    float* pfp = reinterpret_cast<float*>(smem_raw + kv.pfp);            // [MAXC] row being pruned, [MAXC] the same sorted
-    short* cell = reinterpret_cast<short*>(smem_raw + kv.cell);          // [2][CELLS]: (entry, label) -> an entry of that edge
-    const int CELLS = (BW * C + 1) & ~1;
-#define s_nb si[0]
-#define s_bstar si[1]
-#define s_r si[2]
-#define s_mb si[3]
-#define s_nlist si[4]
-#define s_nrev si[5]
-#define s_kmin su[0]
-#define s_kmax su[1]
-
-    NodeRec* nodes = a.nodes + (size_t)b * a.ncap;
-    const int T = a.sizes ? min(a.sizes[b], a.T) : a.T;
-    const float* pb = a.probs + (size_t)b * a.T * C;
-    const int NCTX = a.order - 1;
-    const double betap = fmax(0.0, a.beta);
-    const bool prune = a.cutoff_prob < 1.0f || a.cutoff_top_n < C;
-    const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-    int dbg_rev = 0, dbg_hops = 0, dbg_list = 0, dbg_full = 0;
-
-    // The last wave turns row tt of the probabilities (held in p0, p1: labels lane and lane + 64; pbl = p(blank)) into the
-    // log-probabilities, the vocabulary mask and the two scalars of frame tt (decoder_utils get_pruned_log_probs).
-    auto make_row = [&](int tt, float p0, float p1, float pbl) {
-        const int par = tt & 1;
-        double mx = -INFINITY;
-        if (lane < C) { const double l = log((double)p0 + 1.17549435e-38); lp[par * MAXC + lane] = l; usev[par * MAXC + lane] = 1; mx = l; }
-        if (lane + 64 < C) { const double l = log((double)p1 + 1.17549435e-38); lp[par * MAXC + lane + 64] = l; usev[par * MAXC + lane + 64] = 1; mx = fmax(mx, l); }
-        for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
-        if (lane == 0) { sd[par] = pbl > 0.f ? log((double)pbl) : -INFINITY; sd[2 + par] = mx; }
-        if (prune) {
-            // rank of every label by (probability desc, index asc); the cumulative sum runs in that order, in double, like the
-            // reference's loop, so that `cum >= cutoff_prob` falls on the same label
-            if (lane < C) pfp[lane] = p0;
-            if (lane + 64 < C) pfp[lane + 64] = p1;
-            __builtin_amdgcn_wave_barrier();
-            int rk[2] = {0, 0};
-            for (int h = 0; h < 2; ++h) {
-                const int c = lane + 64 * h;
-                if (c >= C) continue;
-                const float pc = pfp[c];
-                int r = 0;
-                for (int o = 0; o < C; ++o) { const float po = pfp[o]; r += (po > pc) || (po == pc && o < c); }
-                rk[h] = r;
-                pfp[MAXC + r] = pc;
-            }
-            __builtin_amdgcn_wave_barrier();
-            int len = C;
-            if (a.cutoff_prob < 1.0f) {
-                int mine = C;
-                for (int h = 0; h < 2; ++h) {
-                    const int c = lane + 64 * h;
-                    if (c >= C) continue;
-                    double cum = 0.0;
-                    for (int k = 0; k <= rk[h]; ++k) cum += (double)pfp[MAXC + k];
-                    if (cum >= (double)a.cutoff_prob || rk[h] + 1 >= a.cutoff_top_n) mine = min(mine, rk[h] + 1);
-                }
-                for (int o = 32; o > 0; o >>= 1) mine = min(mine, __shfl_xor(mine, o, 64));
-                len = mine;
-            } else len = a.cutoff_top_n;
-            for (int h = 0; h < 2; ++h) { const int c = lane + 64 * h; if (c < C) usev[par * MAXC + c] = rk[h] < len; }
-        }
-    };
-
-    // ---- start: the root is the whole beam
-    for (int q = tid; q < NBINS; q += BT) hist[q] = 0;
-    for (int q = tid; q < CELLS; q += BT) reinterpret_cast<int*>(cell)[q] = -1;       // both buffers (2 * CELLS shorts)
-    if (tid == 0) {
-        NodeRec r; r.parent = -1; r.ch = -1; r.tstep = 0; r.depth = 0; r.lpc = -INFINITY; r.pad = 0.0;
-        nodes[0] = r;
-        e_node[0] = 0; e_ch[0] = -1; e_ds[0] = 0; e_depth[0] = 0; e_up[0] = -1; e_upch[0] = -1; e_upnode[0] = -1; e_memo[0] = MEMO_UNSET;
-        e_bprev[0] = 0.0; e_nbprev[0] = -INFINITY; e_score[0] = 0.0; e_uplpc[0] = -INFINITY; e_ownlpc[0] = -INFINITY;
-        for (int k = 0; k < MAXCTX; ++k) e_ctx[k] = a.bos;
-        s_nb = 1; s_kmin = okey(0.0); s_kmax = okey(0.0); s_nlist = 0; s_nrev = 0;
-        *s_lm = a.lm;
-    }
-    if (wid == NWAVE - 1 && T > 0)
-        make_row(0, lane < C ? pb[lane] : 0.f, lane + 64 < C ? pb[lane + 64] : 0.f, pb[a.blank]);
-    __syncthreads();
-    int cur = 0, nn = 1;
-
-    for (int t = 0; t < T; ++t) {
-        const int nxt = cur ^ 1, par = t & 1;
-        const int nb = s_nb;
-        const double* lpv = lp + par * MAXC; const int* use = usev + par * MAXC;
-        const double* bprev = e_bprev + cur * BW; const double* nbprev = e_nbprev + cur * BW; const double* score = e_score + cur * BW;
-        double* uplpc = e_uplpc + cur * BW; const double* ownlpc = e_ownlpc + cur * BW;
-        const int* node = e_node + cur * BW; const int* ech = e_ch + cur * BW; const int* eds = e_ds + cur * BW;
-        const int* depth = e_depth + cur * BW; const int* up = e_up + cur * BW; const int* upch = e_upch + cur * BW;
-        const int* upnode = e_upnode + cur * BW; int* memo = e_memo + cur * BW; const int* ctx = e_ctx + (size_t)cur * BW * MAXCTX;
-        short* cellc = cell + (size_t)cur * CELLS; short* celln = cell + (size_t)nxt * CELLS;
-        // next frame's row, on its way while this frame runs
-        float pn0 = 0.f, pn1 = 0.f, pnb = 0.f;
-        if (wid == NWAVE - 1 && t + 1 < T) {
-            const float* pr = pb + (size_t)(t + 1) * C;
-            if (lane < C) pn0 = pr[lane];
-            if (lane + 64 < C) pn1 = pr[lane + 64];
-            pnb = pr[a.blank];
-        }
-        const bool full = a.has_lm && nb == BW;
-        const double mincut = a.has_lm ? unokey(s_kmin) + sd[par] - betap : -INFINITY;
-        const double U = unokey(s_kmax) + sd[2 + par] + betap + 1.2;      // no score of this frame exceeds it (alpha >= 0)
-        const int NP = nb * C, N = nb + NP;
-        const float invC = 1.0f / (float)C;
-
-        // the extension of prefix P by character c (not a repeat of its blank-terminated self): ctc_beam_search_decoder.cpp's
-        // log_p, with the scorer's word score on the space character
-        auto pair_logp = [&](int P, int c, int arcw) -> double {
-            const double l = lpv[c];
-            double logp = -INFINITY;
-            if (c == ech[P]) { if (bprev[P] > -INFINITY) logp = l + bprev[P]; }
-            else logp = l + score[P];
-            if (a.has_lm && c == a.space) {
-                double lm = kOovScore;
-                if (arcw >= 0) {
-                    float l10;
-                    const int mm = memo[P];
-                    if (mm != MEMO_UNSET) l10 = __int_as_float(mm);
-                    else {
-                        l10 = lm_word_log10(s_lm, ctx + (size_t)P * MAXCTX, NCTX, arcw, a.unk);
-                        memo[P] = __float_as_int(l10);
-                    }
-                    lm = (double)l10 / (double)kLog10E;
-                }
-                logp += lm * a.alpha;
-                logp += a.beta;
-            }
-            return logp;
-        };
-
-        // ---- F1: candidates
-        uint64_t key[KMAX]; int mark[KMAX], arcv[KMAX], binv[KMAX];     // mark: -1 none, 0 entry, 1 fresh child, 2 + rep: dormant top
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
-            const int idx = tid + k * BT;
-            key[k] = 0; mark[k] = -1; arcv[k] = -1; binv[k] = NBINS;
-            if (idx < nb) {
-                const int j = idx;
-                const double sc = score[j];
-                double bl = -INFINITY, rp = -INFINITY, ex = -INFINITY;
-                if (use[a.blank] && !(full && lpv[a.blank] + sc < mincut)) bl = lpv[a.blank] + sc;
-                const int cj = ech[j];
-                if (cj >= 0 && use[cj] && !(full && lpv[cj] + sc < mincut)) rp = lpv[cj] + nbprev[j];
-                const int P = up[j];
-                if (P >= 0) {
-                    const int c = upch[j];
-                    if (use[c] && !(full && lpv[c] + score[P] < mincut)) {
-                        if (uplpc[j] < lpv[c]) {            // get_path_trie: a better emission frame for the edge's top node
-                            uplpc[j] = lpv[c];
-                            NodeRec* tn = nodes + upnode[j];
-                            tn->lpc = lpv[c]; tn->tstep = t;
-                        }
-                        if (upnode[j] == node[j]) {
-                            int arcw = -1;
-                            if (a.has_lm && c == a.space) arcw = a.trie_word[eds[P]];
-                            ex = pair_logp(P, c, arcw);
-                        }
-                    }
-                }
-                const double nbc = lse2(rp, ex), s = lse2(bl, nbc);
-                e_bcur[j] = bl; e_nbcur[j] = nbc;
-                key[k] = okey(s); mark[k] = 0;
-            } else if (idx < N) {
-                const int p = idx - nb;
-                const int i = min((int)(((float)p + 0.5f) * invC), nb - 1), c = p - i * C;
-                if (c != a.blank && use[c] && !(full && lpv[c] + score[i] < mincut)) {
-                    const int r = cellc[i * C + c];
-                    bool ok = true; int mk = 1, arc = -1;
-                    if (r >= 0) { if (upnode[r] == node[r]) ok = false; else mk = 2 + r; }
-                    if (ok && a.has_lm && (r < 0 || c == a.space)) {
-                        arc = c == a.space ? a.trie_word[eds[i]] : a.trie_next[(size_t)eds[i] * C + c];
-                        if (r < 0 && arc < 0) ok = false;           // the dictionary has no such arc (space: no word ends here)
-                    }
-                    if (ok) { key[k] = okey(pair_logp(i, c, arc)); mark[k] = mk; arcv[k] = arc; }
-                }
-            }
-            const bool valid = key[k] != 0;
-            if (idx < N) c_key[idx] = key[k];
-            int bin = NBINS;
-            if (valid) bin = score_bin<NBINS>(U, unokey(key[k]));
-            binv[k] = bin;
-            const bool lastb = valid && bin == NBINS - 1;          // the hopeless ones pile up in the last bin: one add per wave
-            const unsigned long long bl = __ballot(lastb);
-            if (valid && !lastb) atomicAdd(&hist[bin], 1u);
-            if (bl && lane == __builtin_ctzll(bl)) atomicAdd(&hist[NBINS - 1], (unsigned)__builtin_popcountll(bl));
-        }
-        __syncthreads();
-
-        // ---- F2: prefix sums inside each wave; the next row; housekeeping
-        const int hv = (int)hist[tid];
-        hist[tid] = 0;
-        int incl = hv;
-        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
-        if (lane == 63) wtot[wid] = incl;
-        for (int q = tid; q < CELLS / 2; q += BT) reinterpret_cast<int*>(celln)[q] = -1;
-        if (tid == 0) { s_kmin = ~0ull; s_kmax = 0; s_nlist = 0; s_nrev = 0; }
-        if (wid == NWAVE - 1 && t + 1 < T) make_row(t + 1, pn0, pn1, pnb);
-        __syncthreads();
-
-        // ---- F3: the threshold bin
-        int total = 0, wbase = 0;
-        for (int w = 0; w < NWAVE; ++w) { const int v = wtot[w]; total += v; if (w < wid) wbase += v; }
-        const int exb = wbase + incl - hv;
-        if (total <= BW) { if (tid == 0) { s_bstar = NBINS; s_r = 0; s_mb = 0; } }
-        else if (exb < BW && exb + hv >= BW) { s_bstar = tid; s_r = BW - exb; s_mb = hv; }
-        __syncthreads();
-
-        // ---- F4: exact ranking inside the threshold bin; survivors numbered per wave
-        const int bstar = s_bstar, rr = s_r, mb = s_mb;
-        bool surv[KMAX];
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k) surv[k] = binv[k] < bstar || (binv[k] == bstar && rr == mb);
-        if (bstar < NBINS && rr != mb) {
-#pragma unroll
-            for (int k = 0; k < KMAX; ++k)
-                if (binv[k] == bstar) {
-                    const int at = atomicAdd(&s_nlist, 1);
-                    if (at < LISTCAP) { l_key[at] = key[k]; l_idx[at] = tid + k * BT; }
-                }
-            __syncthreads();
-            const int nl = s_nlist;
-            auto label_of = [&](int idx) { if (idx < nb) return ech[idx]; const int p = idx - nb; const int i = min((int)(((float)p + 0.5f) * invC), nb - 1); return p - i * C; };
-#pragma unroll
-            for (int k = 0; k < KMAX; ++k) {
-                if (binv[k] != bstar) continue;
-                const int idx = tid + k * BT, myc = label_of(idx);
-                const uint64_t mk = key[k];
-                int rank = 0;
-                if (nl <= LISTCAP) {
-                    for (int q = 0; q < nl; ++q) {
-                        const uint64_t ok = l_key[q]; const int oi = l_idx[q];
-                        if (oi == idx) continue;
-                        if (ok > mk) { ++rank; continue; }
-                        if (ok == mk) { const int oc = label_of(oi); rank += (oc < myc) || (oc == myc && oi < idx); }
-                    }
-                    ++dbg_list;
-                } else {
-                    for (int q = 0; q < N; ++q) {
-                        const uint64_t ok = c_key[q];
-                        if (ok == 0 || q == idx || score_bin<NBINS>(U, unokey(ok)) != bstar) continue;
-                        if (ok > mk) { ++rank; continue; }
-                        if (ok == mk) { const int oc = label_of(q); rank += (oc < myc) || (oc == myc && q < idx); }
-                    }
-                    ++dbg_full;
-                }
-                surv[k] = rank < rr;
-            }
-        }
-        int within[KMAX], fwithin[KMAX];
-        int wcount = 0, fcount = 0;
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
-            const unsigned long long bs = __ballot(surv[k]), bf = __ballot(surv[k] && mark[k] == 1);
-            within[k] = wcount + __builtin_popcountll(bs & lt_mask); wcount += __builtin_popcountll(bs);
-            fwithin[k] = fcount + __builtin_popcountll(bf & lt_mask); fcount += __builtin_popcountll(bf);
-        }
-        if (lane == 0) { wsurv[wid] = wcount; wfresh[wid] = fcount; }
-        __syncthreads();
-
-        // ---- F5: slot numbers of the next beam
-        int sbase = 0, fbase = 0, nnext = 0, nfresh = 0;
-        for (int w = 0; w < NWAVE; ++w) { const int v = wsurv[w], f = wfresh[w]; nnext += v; nfresh += f; if (w < wid) { sbase += v; fbase += f; } }
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
-            const int idx = tid + k * BT;
-            if (idx < nb) newslot[idx] = surv[k] ? sbase + within[k] : -1;
-            if (surv[k]) {
-                atomicMin((unsigned long long*)&s_kmin, (unsigned long long)key[k]);
-                atomicMax((unsigned long long*)&s_kmax, (unsigned long long)key[k]);
-                if (mark[k] >= 2) {
-                    const int p = idx - nb; const int i = min((int)(((float)p + 0.5f) * invC), nb - 1), c = p - i * C;
-                    cellc[i * C + c] = (short)(-2 - (sbase + within[k]));       // this edge's dormant top is a beam entry again
-                    s_nrev = 1;
-                }
-            }
-        }
-        __syncthreads();
-
-        // ---- F6: commit
-        if (s_nrev) {     // the walk below reads node records other waves have stored: have every store land first
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
-        // an entry's edge tuple in the new slot numbers: through ancestors that left the beam, under a top that came back
-        auto resolve = [&](Tup tp, int node_j, int walk_from, int walk_depth, int ch_j, double own_j) -> Tup {
-            while (tp.up >= 0) {
-                const int m = cellc[tp.up * C + tp.upch];
-                if (m <= -2 && tp.upnode != node_j) {
-                    int n = walk_from;
-                    const int hops = walk_depth - depth[tp.up] - 2;
-                    for (int h = 0; h < hops; ++h) n = nodes[n].parent;
-                    dbg_hops += hops > 0 ? hops : 0;
-                    Tup r; r.up = -2 - m; r.upnode = n;
-                    if (n == node_j) { r.upch = ch_j; r.uplpc = own_j; }
-                    else { const NodeRec x = nodes[n]; r.upch = x.ch; r.uplpc = x.lpc; }
-                    return r;
-                }
-                const int ns = newslot[tp.up];
-                if (ns >= 0) { tp.up = ns; return tp; }
-                const int P = tp.up;                         // P left the beam: it is part of this edge now
-                tp.up = up[P]; tp.upch = upch[P]; tp.upnode = upnode[P]; tp.uplpc = uplpc[P];
-            }
-            return Tup{-1, -1, -1, -INFINITY};
-        };
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
-            if (!surv[k]) continue;
-            const int idx = tid + k * BT, sl = sbase + within[k];
-            const double lg = unokey(key[k]);
-            const size_t o = (size_t)nxt * BW + sl;
-            int* nctxp = e_ctx + o * MAXCTX;
-            if (mark[k] == 0) {                                  // an entry that stays
-                const int j = idx;
-                const bool direct = upnode[j] == node[j];
-                const double own = direct ? uplpc[j] : ownlpc[j];
-                const Tup tp = resolve(Tup{up[j], upch[j], upnode[j], uplpc[j]}, node[j], node[j], depth[j], ech[j], own);
-                e_node[o] = node[j]; e_ch[o] = ech[j]; e_ds[o] = eds[j]; e_depth[o] = depth[j]; e_memo[o] = memo[j];
-                e_bprev[o] = e_bcur[j]; e_nbprev[o] = e_nbcur[j]; e_score[o] = lg; e_ownlpc[o] = own;
-                e_up[o] = tp.up; e_upch[o] = tp.upch; e_upnode[o] = tp.upnode; e_uplpc[o] = tp.uplpc;
-                for (int q = 0; q < MAXCTX; ++q) nctxp[q] = ctx[(size_t)j * MAXCTX + q];
-                if (tp.up >= 0) celln[tp.up * C + tp.upch] = (short)sl;
-                continue;
-            }
-            const int p = idx - nb;
-            const int i = min((int)(((float)p + 0.5f) * invC), nb - 1), c = p - i * C;
-            const bool sp = a.has_lm && c == a.space;
-            int id; double lpc;
-            if (mark[k] == 1) {                                  // a new node
-                id = nn + fbase + fwithin[k];
-                lpc = lpv[c];
-                NodeRec r; r.parent = node[i]; r.ch = c; r.tstep = t; r.depth = depth[i] + 1; r.lpc = lpc; r.pad = 0.0;
-                nodes[id] = r;
-            } else {                                             // a dormant prefix is back: same node, its log_prob_c kept
-                const int rep = mark[k] - 2;
-                id = upnode[rep]; lpc = uplpc[rep];
-                ++dbg_rev;
-            }
-            int nds = 0;
-            if (a.has_lm && !sp) nds = mark[k] == 1 ? arcv[k] : a.trie_next[(size_t)eds[i] * C + c];
-            const int* pctx = ctx + (size_t)i * MAXCTX;
-            for (int q = 0; q < MAXCTX; ++q) {
-                int v = pctx[q];
-                if (sp) v = q + 1 < NCTX ? pctx[q + 1] : (q + 1 == NCTX ? arcv[k] : a.bos);
-                nctxp[q] = v;
-            }
-            Tup tp{newslot[i], c, id, lpc};
-            if (tp.up < 0) tp = resolve(Tup{up[i], upch[i], upnode[i], uplpc[i]}, id, node[i], depth[i], c, lpc);
-            e_node[o] = id; e_ch[o] = c; e_ds[o] = nds; e_depth[o] = depth[i] + 1; e_memo[o] = MEMO_UNSET;
-            e_bprev[o] = -INFINITY; e_nbprev[o] = lg; e_score[o] = lg; e_ownlpc[o] = lpc;
-            e_up[o] = tp.up; e_upch[o] = tp.upch; e_upnode[o] = tp.upnode; e_uplpc[o] = tp.uplpc;
-            if (tp.up >= 0) celln[tp.up * C + tp.upch] = (short)sl;
-        }
-        nn += nfresh;
-        if (tid == 0) s_nb = nnext;
-        __syncthreads();
-        cur = nxt;
-    }
-
-    // ---- final: trailing partial word, order, write out
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    {
-        const int nb = s_nb;
-        double* score = e_score + cur * BW; const int* node = e_node + cur * BW; const int* ech = e_ch + cur * BW;
-        const int* eds = e_ds + cur * BW; const int* depth = e_depth + cur * BW; const int* ctx = e_ctx + (size_t)cur * BW * MAXCTX;
-        if (a.has_lm) {
-            for (int i = tid; i < nb; i += BT) {
-                if (node[i] != 0 && ech[i] != a.space) {
-                    const int w = a.trie_word[eds[i]];
-                    double lm = kOovScore;
-                    if (w >= 0) lm = (double)lm_word_log10(s_lm, ctx + (size_t)i * MAXCTX, NCTX, w, a.unk) / (double)kLog10E;
-                    double s = lm * a.alpha;
-                    s += a.beta;
-                    score[i] += s;
-                }
-            }
-        }
-        __syncthreads();
-        for (int i = tid; i < nb; i += BT) {
-            int rank = 0;
-            for (int j = 0; j < nb; ++j) {
-                if (j == i) continue;
-                rank += score[j] > score[i] || (score[j] == score[i] && (ech[j] < ech[i] || (ech[j] == ech[i] && j < i)));
-            }
-            const int len = depth[i];
-            const size_t o = ((size_t)b * BW + rank) * a.T;
-            int n = node[i];
-            for (int k = len - 1; k >= 0; --k) { const NodeRec r = nodes[n]; a.out_tok[o + k] = r.ch; a.out_step[o + k] = r.tstep; n = r.parent; }
-            a.out_len[(size_t)b * BW + rank] = len;
-            a.out_score[(size_t)b * BW + rank] = score[i];
-        }
-        if (tid == 0) a.out_n[b] = nb;
-    }
-    if (a.dbg) {
-        dbg_rev = wave_sum(dbg_rev); dbg_hops = wave_sum(dbg_hops); dbg_list = wave_sum(dbg_list); dbg_full = wave_sum(dbg_full);
-        if (lane == 0) { atomicAdd(a.dbg + 4 * b, dbg_rev); atomicAdd(a.dbg + 4 * b + 1, dbg_hops); atomicAdd(a.dbg + 4 * b + 2, dbg_list); atomicAdd(a.dbg + 4 * b + 3, dbg_full); }
-    }
-#undef s_nb
-#undef s_bstar
-#undef s_r
-#undef s_mb
-#undef s_nlist
-#undef s_nrev
-#undef s_kmin
-#undef s_kmax
-}
-
-}  // namespace
+#define DSMI_WAIT_STORES() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#include "beam_kernel.inc"
 
 // ------------------------------------------------------------------------------------------------
 struct dsmi_decoder {

@@ -22,6 +22,17 @@ util/bit_packing.hh, util/murmur_hash.cc), from knowledge of that code:
       [word : bits(V)] [prob : 31, sign implied] [backoff : 32] [next : bits(count of the next order)], sorted by word
       inside a parent's range, one extra record at the end for the last ``next``; order N: [word][prob : 31];
       the trie is keyed by the n-gram REVERSED (last word first).
+  quantised tries (model_type 3 and 5, ``build_binary -q P -b B``; lm/quantize.hh SeparatelyQuantize): the search memory
+      starts with {u8 version = 2, u8 P, u8 B, 5 pad}, then for every middle order a table of 2^P float bin centres for the
+      probabilities and one of 2^B for the back-offs (its first two bins are the reserved -0.0 "does not extend" and +0.0),
+      then the longest order's 2^P table; unigrams stay floats; a record's [prob 31][backoff 32] becomes one field of B + P
+      bits, back-off index in the LOW bits; centres = means of equal-population slices of the sorted values (MakeBins), a
+      value is stored as the nearer of its two neighbouring centres (Bins::Encode);
+  array-compressed pointers (model_type 4 and 5, ``-a A``; lm/bhiksha.hh ArrayBhiksha): every middle order is preceded by
+      {u8 version = 0, u8 A}, padding to the next 8-byte boundary, an 8-byte header word and an array of u64 offsets:
+      entry e = index of the first record whose ``next >> inline_bits`` is >= e (entry 0 = 0); the records keep only the low
+      ``inline_bits = bits(max_next) - chop`` bits of ``next``, with chop = argmin over 0..min(bits, A) of
+      (max_next >> (bits - chop)) * 64 - records * chop; the block is sized 8 * (1 + entries) + 7 bytes.
   word hash = MurmurHash64A(bytes, seed 0).
 
 The reader below and the C++ reader (danspeech_amd/csrc/lm_klm.cpp.inc) are held to this writer (round trip against
@@ -33,6 +44,7 @@ import numpy as np
 
 MAGIC = b"mmap lm http://kheafield.com/code format version 5\n\x00"
 PROBING, TRIE = 0, 2
+QUANT_TRIE, ARRAY_TRIE, QUANT_ARRAY_TRIE = 3, 4, 5
 M64 = (1 << 64) - 1
 
 
@@ -116,9 +128,48 @@ def _f32(x):
     return struct.unpack("<I", struct.pack("<f", x))[0]
 
 
-def write_klm(arpa_path, out_path, model_type=PROBING, multiplier=1.5, flag_some_signs=True):
-    """ARPA text -> KenLM binary (probing or plain trie).  ``flag_some_signs`` clears the sign bit of every third
-    stored prob in the probing tables, as KenLM does for n-grams that extend left: a reader must take -|prob|."""
+def make_bins(values, bins):
+    """quantize.cc MakeBins: centres of ``bins`` equal-population slices of the sorted float32 values."""
+    v = np.sort(np.asarray(values, dtype=np.float32))
+    out = []
+    start = 0
+    for i in range(bins):
+        finish = (len(v) * (i + 1)) // bins
+        if finish == start:
+            out.append(out[-1] if i else np.float32(-np.inf))
+        else:
+            out.append(np.float32(np.sum(v[start:finish], dtype=np.float64) / np.float32(finish - start)))
+        start = finish
+    return np.asarray(out, dtype=np.float32)
+
+
+def encode_bin(centres, value, reserved=0):
+    """quantize.hh Bins::Encode: index of the nearer neighbouring centre (lower_bound, ties go up)."""
+    value = np.float32(value)
+    above = reserved + int(np.searchsorted(centres[reserved:], value, side="left"))
+    if above == reserved:
+        return reserved
+    if above == len(centres):
+        return len(centres) - 1
+    return above - int(value - centres[above - 1] < centres[above] - value)
+
+
+def chop_bits(max_offset, max_next, configured):
+    required = required_bits(max_next)
+    best, lowest = 0, None
+    for chop in range(0, min(required, configured) + 1):
+        change = (max_next >> (required - chop)) * 64 - max_offset * chop
+        if lowest is None or change < lowest:
+            lowest, best = change, chop
+    return best
+
+
+def write_klm(arpa_path, out_path, model_type=PROBING, multiplier=1.5, flag_some_signs=True, quant_bits=(8, 8), array_bits=64):
+    """ARPA text -> KenLM binary (probing, or a trie: plain, quantised, array-compressed or both).  ``flag_some_signs`` clears
+    the sign bit of every third stored prob in the probing tables, as KenLM does for n-grams that extend left: a reader must
+    take -|prob|.  For the quantised variants the function returns, beside the word ids, what a reader must find:
+    ``stored[n][words] = (prob, backoff)`` after quantisation."""
+    quantised, arrayed = model_type in (QUANT_TRIE, QUANT_ARRAY_TRIE), model_type in (ARRAY_TRIE, QUANT_ARRAY_TRIE)
     order, grams = read_arpa(arpa_path)
     words = [g[0][0] for g in grams[1]]
     if "<unk>" not in words:
@@ -198,38 +249,87 @@ def write_klm(arpa_path, out_path, model_type=PROBING, multiplier=1.5, flag_some
                     pos += 1
             fc.append(pos)
             first_child[n] = fc
+        pbits, bbits = quant_bits
+        tables = {}                      # order -> (prob centres, backoff centres or None)
         search = b""
+        if quantised:
+            search += struct.pack("<BBB5x", 2, pbits, bbits)
+            for n in range(2, order + 1):
+                pc = make_bins([lp for lp, _ in rev[n].values()], 1 << pbits)
+                bc = None
+                if n < order:
+                    bc = np.concatenate((np.array([-0.0, 0.0], dtype=np.float32),
+                                         make_bins([bo for _, bo in rev[n].values() if bo != 0.0], (1 << bbits) - 2)))
+                tables[n] = (pc, bc)
+                search += pc.astype("<f4").tobytes() + (bc.astype("<f4").tobytes() if bc is not None else b"")
         for i in range(V):
             lp, bo = rev[1][(i,)]
             search += struct.pack("<ffQ", lp, bo, first_child[1][i] if order > 1 else 0)
         search += struct.pack("<ffQ", 0.0, 0.0, first_child[1][V] if order > 1 else 0)
         search += struct.pack("<ffQ", 0.0, 0.0, 0)
         wbits = required_bits(V)
+        stored = {1: {tuple(g): (np.float32(lp), np.float32(bo)) for g, lp, bo in grams[1]}}
+        back = {i: w for w, i in ids.items()}
         for n in range(2, order + 1):
             last = n == order
-            nbits = 0 if last else required_bits(counts[n])
-            total = wbits + (31 if last else 63) + nbits
             recs = level[n]
+            qbits = (pbits if last else pbits + bbits) if quantised else (31 if last else 63)
+            nbits = 0 if last else required_bits(counts[n])
+            prefix = b""
+            if arrayed and not last:
+                base = len(_header(order, counts, model_type, multiplier)) + len(vocab) + len(search)      # absolute file offset
+                chop = chop_bits(len(recs) + 1, counts[n], array_bits)
+                nbits = required_bits(counts[n]) - chop
+                n_arr = (counts[n] >> nbits) + 1
+                offsets, e = [0] * n_arr, 1
+                for idx in range(len(recs) + 1):
+                    hi = first_child[n][idx] >> nbits
+                    while e <= hi:
+                        offsets[e] = idx
+                        e += 1
+                assert e == n_arr, "did not get all the array entries that were expected"
+                blob = bytearray(8 * (1 + n_arr) + 7)
+                blob[0], blob[1] = 0, min(array_bits, 255)
+                at = (-base) % 8 + 8
+                blob[at:at + 8 * n_arr] = b"".join(struct.pack("<Q", o) for o in offsets)
+                prefix = bytes(blob)
+            total = wbits + qbits + nbits
             nbytes = ((1 + len(recs)) * total + 7) // 8 + 8
             buf = bytearray(nbytes)
+            stored[n] = {}
             for idx in range(len(recs) + 1):
                 rec = 0
                 if idx < len(recs):
                     lp, bo = rev[n][recs[idx]]
-                    rec = recs[idx][-1] | ((_f32(lp) & 0x7FFFFFFF) << wbits)
-                    if not last:
-                        rec |= _f32(bo) << (wbits + 31)
+                    words = tuple(back[i] for i in reversed(recs[idx]))
+                    if quantised:
+                        pc, bc = tables[n]
+                        qp = encode_bin(pc, lp)
+                        field, sp, sb = qp, pc[qp], np.float32(0.0)
+                        if not last:
+                            qb = (1 if bo == 0.0 else encode_bin(bc, bo, 2))     # 0.0 -> the "extends" reserved bin
+                            field = (qp << bbits) | qb
+                            sb = bc[qb]
+                        stored[n][words] = (np.float32(sp), np.float32(sb) + np.float32(0.0))
+                        rec = recs[idx][-1] | (field << wbits)
+                    else:
+                        stored[n][words] = (np.float32(lp), np.float32(bo if not last else 0.0))
+                        rec = recs[idx][-1] | ((_f32(lp) & 0x7FFFFFFF) << wbits)
+                        if not last:
+                            rec |= _f32(bo) << (wbits + 31)
                 if not last:
-                    rec |= first_child[n][idx] << (wbits + 63)
+                    rec |= (first_child[n][idx] & ((1 << nbits) - 1)) << (wbits + qbits)
                 pos = idx * total
                 byte, shift = pos >> 3, pos & 7
                 nb = (total + shift + 7) // 8
                 chunk = int.from_bytes(buf[byte:byte + nb], "little") | (rec << shift)
                 buf[byte:byte + nb] = chunk.to_bytes(nb, "little")
-            search += bytes(buf)
+            search += prefix + bytes(buf)
     strings = b"".join(w.encode("utf-8") + b"\x00" for w in by_id)
     with open(out_path, "wb") as f:
         f.write(_header(order, counts, model_type, multiplier) + vocab + search + strings)
+    if model_type in (QUANT_TRIE, ARRAY_TRIE, QUANT_ARRAY_TRIE):
+        return ids, stored
     return ids
 
 

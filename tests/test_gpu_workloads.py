@@ -5,7 +5,8 @@ tools/run_configs.py time), against the CPU oracle on the same seeded inputs:
             2 directions x 2 sixteen-clip tiles x 50 workgroups of the persistent recurrent kernel
   config 3  the same batch through the 3-gram beam search (beam 64)
   config 4  cfgB (2 conv + 7 x BiGRU 1200) + 5-gram, beam 128, B = 64 ragged clips through
-            Recognizer.recognize_batch(show_all=True); 3 s clips bound the oracle's time
+            Recognizer.recognize_batch(show_all=True): once on 1.5..3 s clips with the oracle on every clip, once at the
+            configuration's own 4..10 s with the oracle on sampled clips
   config 5  one GPU's share of the long-form job: cfgA, B = 128 x 30 s (T = 3001), 3-gram beam 64: the
             software-pipelined multi-tile recurrent kernel; oracle on a sampled subset of the clips +
             batch invariance on all of them
@@ -64,9 +65,10 @@ def _margins(p, ol):
 
 
 def _check_greedy(native, probs, out_lens, p_ref, ol_ref, err, min_tokens):
-    """Transcripts and offsets identical to the oracle's.  A clip may differ only if the oracle's own top-2 margin somewhere
-    in it is within 4 x the measured probability error (an argmax that close is decided by fp32 summation order, in the
-    reference too); at least 90 % of the clips must be identical outright, and the weights must make that a real check."""
+    """Transcripts and offsets identical to the oracle's, for EVERY clip of the seeded batch (the inputs are deterministic, so
+    the count is too; it is printed).  Should a clip ever differ, the message says whether the oracle's own top-2 margin in it
+    was within reach of the measured probability error (an argmax that close is decided by fp32 summation order, in the
+    reference too) -- which would be a reason to look at the inputs, not to pass."""
     from oracle import decoder as od
     gd = native.NativeDecoder(LABELS, blank_index=0)
     dec = gd.greedy(probs, out_lens)
@@ -79,9 +81,9 @@ def _check_greedy(native, probs, out_lens, p_ref, ol_ref, err, min_tokens):
         if got == s_ref[b][0] and np.array_equal(dec[b][1], o_ref[b][0]):
             same += 1
         else:
-            assert mar[b] <= 4 * max(err, 1e-7), (b, got, s_ref[b][0], mar[b], err)
-    assert same >= 0.9 * len(dec), (same, len(dec))
+            print("clip %d differs: top-2 margin %.3g against max err %.3g\n  got  %r\n  want %r" % (b, mar[b], err, got, s_ref[b][0]))
     print("greedy transcripts identical: %d/%d (smallest top-2 margins %s, max err %.2g)" % (same, len(dec), np.sort(mar)[:3], err))
+    assert same == len(dec), (same, len(dec))
     assert min(lens) >= min_tokens, lens
     text = "".join("".join(LABELS[i] for i in d[0]) for d in dec)
     assert " " in text and len(set(text)) >= 10
@@ -114,6 +116,13 @@ def test_config2_cfgA_batch32_ragged_greedy(native, inflight):
     m.close(); fe.close()
 
 
+def _score_tol(ref):
+    """North star: beam scores within 1e-4.  The search carries float64 on both sides (agreement ~1e-12); what is compared is
+    the float32 the ABI returns, like ctcdecode's FloatTensor of scores: half a float32 ulp of the score comes on top (3e-5
+    at |score| = 1e3, 1.2e-4 at 4e3: the long clips of config 5)."""
+    return 1e-4 + 0.5 * float(np.spacing(np.float32(abs(ref))))
+
+
 def _compare_beams(native, probs_gpu, out_lens, lm_path, alpha, beta, beam, clips_to_check, n_check=10):
     """GPU beam search vs the oracle's on the SAME probabilities (the GPU's, copied to the host)."""
     from oracle import beam as ob
@@ -129,7 +138,7 @@ def _compare_beams(native, probs_gpu, out_lens, lm_path, alpha, beta, beam, clip
             want = "".join(LABELS[c] for c in ref[k][1])
             assert got == want, (b, k, got, want)
             assert list(ts[b, k, :ln[b, k]]) == list(ref[k][2]), (b, k)
-            assert abs(float(sc[b, k]) - ref[k][0]) < 1e-4 * max(1.0, abs(ref[k][0]) / 100.0), (b, k, sc[b, k], ref[k][0])
+            assert abs(float(sc[b, k]) - ref[k][0]) < _score_tol(ref[k][0]), (b, k, sc[b, k], ref[k][0])
     dec.close()
     return tok, ln, sc
 
@@ -192,6 +201,44 @@ def test_config4_cfgB_batch64_beam128_5gram_through_recognizer(native, tmp_path)
             clear += 1
             same += int("".join(LABELS[c] for c in ref[0][1]) == "".join(LABELS[c] for c in tok[b, 0, :ln[b, 0]]))
     assert clear >= 4 and same == clear, (clear, same)
+
+
+def test_config4_full_length_10s_clips(native, tmp_path):
+    """BASELINE.json configs[3] at its own clip length: B = 64 ragged 4..10 s clips (T' up to 501), 7 x BiGRU 1200, beam 128 +
+    5-gram through Recognizer.recognize_batch(show_all=True).  The oracle runs on four sampled clips, each as a batch of its
+    own (the reference's batch invariance is <= 1.2e-8): probabilities, then the search on the GPU's probabilities."""
+    from danspeech_amd import Recognizer
+    from danspeech_amd.deepspeech.model import DeepSpeech
+    from danspeech_amd.language_models import CustomLanguageModel
+    from oracle import torch_port as tp
+    H, L, B = 1200, 7, 64
+    cfg = _cfg(H, L)
+    sd = syn.make_state_dict(2, "gru", H, L, seed=4, **syn.TALKATIVE)
+    lm = str(tmp_path / "syn5.arpa")
+    syn.make_arpa(lm, order=5, n_words=5000, seed=12, ngrams_per_order=20000)
+    model = DeepSpeech("cfgB", rnn_type="gru", rnn_hidden_size=H, rnn_layers=L, conv_layers=2).load_state_dict(sd)
+    rec = Recognizer(model=model, lm=CustomLanguageModel(lm), alpha=1.2, beta=0.15, beam_width=128)
+    clips = _ragged_clips(B, 64000, 160000, seed=6)
+    beams = rec.recognize_batch(clips, show_all=True)
+    eng = rec.danspeech_recognizer
+    assert eng.model._native.recompute_count() == 0
+    assert len(beams) == B and all(len(b) == 128 for b in beams)
+    feats, frames = eng.audio_parser.parse_batch(clips)
+    probs, out_lens = eng.model(feats, torch.from_numpy(frames.astype(np.int32)))
+    assert int(out_lens.max()) == 501
+    pn = probs.cpu().numpy()
+    sample = [0, 21, 42, 63]
+    worst = 0.0
+    for b in sample:
+        x1, f1 = tp.spectrogram_batch([clips[b]])
+        p1, o1 = tp.forward(sd, cfg, x1, f1)
+        assert o1[0] == int(out_lens[b])
+        worst = max(worst, float(np.abs(pn[b, :o1[0]] - p1[0]).max()))
+    print("config 4 at 10 s (cfgB, B=64 ragged 4..10 s): max |probs - oracle| over %d sampled clips = %.3g" % (len(sample), worst))
+    assert worst < 1e-4
+    tok, ln, sc = _compare_beams(native, probs, out_lens.numpy(), lm, 1.2, 0.15, 128, sample, n_check=5)
+    for b in sample:
+        assert beams[b][0] == "".join(LABELS[c] for c in tok[b, 0, :ln[b, 0]])
 
 
 def test_config5_share_cfgA_batch128_30s_pipelined_kernel(native, tmp_path):

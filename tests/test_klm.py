@@ -1,5 +1,5 @@
-"""KenLM binary (.klm) reader of libdsmi.so (csrc/lm_klm.cpp.inc) on the CPU: header parsing, both supported data
-structures, every n-gram and back-off score against the ARPA text the binary was written from, refusal of what is not
+"""KenLM binary (.klm) reader of libdsmi.so (csrc/lm_klm.cpp.inc) on the CPU: header parsing, probing tables and the four
+trie variants (plain, quantised, array-compressed pointers, both), every n-gram and back-off score against the ARPA text the binary was written from, refusal of what is not
 supported.  The binaries come from oracle/klm.py's writer (a restatement of KenLM's published layout): a self-consistency
 check, PARITY WITH KenLM's OWN FILES IS UNPINNED (no KenLM, no .klm offline) -- see tests/test_gallery_optin.py."""
 import struct
@@ -30,6 +30,15 @@ def files(tmp_path_factory):
             p = str(d / ("syn%d_%s.klm" % (order, name)))
             klm.write_klm(arpa, p, mt)
             out[order][name] = p
+        # build_binary -q / -b / -a: quantised values, array-compressed pointers, both (the common DeepSpeech-era recipe is
+        # `trie -q 8 -a 255`); small -a values force several offset-array entries on files this small
+        for mt, name, kw in ((klm.QUANT_TRIE, "quant", dict(quant_bits=(8, 8))), (klm.ARRAY_TRIE, "array", dict(array_bits=3)),
+                             (klm.QUANT_ARRAY_TRIE, "quant_array", dict(quant_bits=(6, 4), array_bits=255)),
+                             (klm.ARRAY_TRIE, "array255", dict(array_bits=255))):
+            p = str(d / ("syn%d_%s.klm" % (order, name)))
+            _, stored = klm.write_klm(arpa, p, mt, **kw)
+            out[order][name] = p
+            out[order][name + "_stored"] = stored
     return out
 
 
@@ -75,6 +84,44 @@ def test_reader_equals_arpa(native, files, order, name):
     lm.close(); ref.close()
 
 
+@pytest.mark.parametrize("order", [3, 5])
+@pytest.mark.parametrize("name", ["quant", "array", "quant_array", "array255"])
+def test_quantised_and_array_compressed_tries(native, files, order, name):
+    """KenLM model types 3, 4, 5.  Every n-gram is found with the value the file stores for it: the exact floats where only
+    the pointers are compressed, the bin centres where the values are quantised (unigrams are never quantised)."""
+    lm = native.NativeLM(files[order][name])
+    plain = native.NativeLM(files[order]["trie"])
+    assert lm.kind == "klm-trie" and lm.order == order and lm.vocab_size == plain.vocab_size
+    stored = files[order][name + "_stored"]
+    quantised = name.startswith("quant")
+    n_changed = 0
+    for n in range(1, order + 1):
+        for g, (lp, bo) in stored[n].items():
+            ids = [lm.word_index(w) for w in g]
+            assert ids == [plain.word_index(w) for w in g]
+            got = lm.lookup(ids)
+            assert got is not None, g
+            assert got[0] == lp and got[1] == bo, (g, got, lp, bo)
+            n_changed += got != plain.lookup(ids)
+    assert (n_changed > 0) == quantised            # quantisation moves values; pointer compression must not
+    if not quantised:
+        rng = np.random.default_rng(2)
+        vocab = [g[0] for g in stored[1]]
+        for _ in range(300):
+            k = int(rng.integers(1, order + 1))
+            ws = [vocab[int(i)] for i in rng.integers(0, len(vocab), size=k)]
+            assert lm.cond_log10([lm.word_index(w) for w in ws]) == plain.cond_log10([plain.word_index(w) for w in ws])
+    lm.close(); plain.close()
+
+
+def test_bin_encoding_rules():
+    c = np.array([-3.0, -2.0, -1.0, -0.5], dtype=np.float32)
+    assert [klm.encode_bin(c, v) for v in (-9.0, -3.0, -2.6, -2.5, -2.4, -0.7, 0.0)] == [0, 0, 0, 1, 1, 3, 3]
+    assert klm.encode_bin(np.array([-0.0, 0.0, -1.0, -0.2], dtype=np.float32), -0.9, 2) == 2     # never the reserved bins
+    assert list(klm.make_bins([1.0, 2.0, 3.0, 4.0], 2)) == [1.5, 3.5]
+    assert klm.chop_bits(1000, 5000, 0) == 0 and klm.chop_bits(1000, 5000, 64) >= 1
+
+
 def test_python_reader_agrees(files):
     for name in ("probing", "trie"):
         r = klm.KlmReader(files[3][name])
@@ -97,8 +144,13 @@ def test_unsupported_and_damaged_files_are_refused(native, files, tmp_path):
 
     refused(good[:60], "truncated")
     refused(good.replace(b"version 5", b"version 4", 1), "format version")
-    refused(good[:96] + struct.pack("<i", 3) + good[100:], "quantised trie")
-    refused(good[:96] + struct.pack("<i", 4) + good[100:], "array-compressed")
+    refused(good[:96] + struct.pack("<i", 1) + good[100:], "rest-cost probing")
+    refused(good[:96] + struct.pack("<i", 7) + good[100:], "unknown")
+    for mt in (3, 4, 5):                     # a probing image under a trie model type: refused somewhere in the layout checks
+        p = tmp_path / "z.klm"
+        p.write_bytes(good[:96] + struct.pack("<i", mt) + good[100:])
+        with pytest.raises(native.DsmiError):
+            native.NativeLM(str(p))
     refused(good[:100] + b"\x00" + good[101:], "vocabulary strings")
     refused(good[:64] + struct.pack("<f", 0.5) + good[68:], "sanity")
     refused(good[:-7], "layout mismatch")

@@ -68,3 +68,10 @@ def test_revival_and_walk_paths_are_exercised():
         for beam in (2, 3, 5, 9):
             _same(bf.ctc_beam_search(probs, labels, beam), ob.ctc_beam_search(probs, labels, beam))
     assert bf.stats["revivals"] > 0 and bf.stats["inherit_hops"] > 0
+    # ... and with the entries below the returning prefix more than one level down (the walk proper); the GPU test
+    # tests/test_gpu_beam.py::test_beam_dormant_prefixes_come_back uses these inputs
+    bf.stats.update(revivals=0, walk_hops=0, frames=0, inherit_hops=0)
+    for seed, beam in ((80, 4), (61, 3), (112, 6), (119, 3), (165, 4), (192, 6)):
+        probs = np.random.default_rng(seed).dirichlet(np.ones(4) * 0.5, size=60).astype(np.float32).astype(np.float64)
+        _same(bf.ctc_beam_search(probs, labels, beam), ob.ctc_beam_search(probs, labels, beam))
+    assert bf.stats["walk_hops"] > 0

@@ -110,6 +110,7 @@ _PROTOS = {
     "dsmi_beam_enqueue": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _vp]),
     "dsmi_beam_collect": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "dsmi_decoder_beam_stats": (C.c_int, [_vp, _vp]),
+    "dsmi_debug_beam_stamps": (C.c_int, [_vp, _vp, C.c_int64]),
     "dsmi_model_info": (C.c_int, [_vp, C.POINTER(ModelDesc), C.POINTER(C.c_int)]),
     "dsmi_frontend_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "dsmi_decoder_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -556,6 +557,12 @@ class NativeDecoder:
         sc = np.zeros((B, beam_width), dtype=np.float32)
         self._check(lib().dsmi_beam_collect(self._h, _np_ptr(tok), _np_ptr(ts), _np_ptr(ln), _np_ptr(sc)))
         return tok, ts, ln, sc
+
+    def beam_stamps(self):
+        """[64, 8] uint64: 100 MHz phase-boundary stamps of the last collected search (dsmi_debug_beam_stamps)."""
+        st = np.zeros((64, 8), dtype=np.uint64)
+        self._check(lib().dsmi_debug_beam_stamps(self._h, _np_ptr(st), st.size))
+        return st
 
     def beam_stats(self):
         """Of the last collected search: {revivals, walk_hops, list_rankings, full_rankings} (dsmi_decoder_beam_stats)."""

@@ -55,6 +55,7 @@ struct dsmi_decoder {
     int pb_B = 0, pb_To = 0, pb_beam = 0;
     size_t pb_out = 0, pb_out_bytes = 0; hipStream_t pb_stream = nullptr;
     int32_t stats[4] = {0, 0, 0, 0};      // of the last collected search: see dsmi_decoder_beam_stats
+    uint64_t stamps[64 * 8] = {0};
     int32_t* pin_sz = nullptr; size_t pin_sz_cap = 0;
     unsigned char* pin = nullptr; size_t pin_bytes = 0;
     hipEvent_t beam_done = nullptr;
@@ -179,7 +180,10 @@ extern "C" int dsmi_beam_enqueue(dsmi_decoder* d, const float* probs, const int3
     const size_t NMAX = (size_t)beam * (C + 1);
     static const int BT = getenv("DSMI_BEAM_THREADS") ? atoi(getenv("DSMI_BEAM_THREADS")) : 1024;      // (experiment switch)
     const size_t lds = carve(beam, C, BT).bytes;
-    if (lds > 160 * 1024 - 256 || NMAX > (size_t)(BT == 1024 ? 9 : 17) * BT || beam > BT || C > MAXC) { d->err = "beam_width * (n_labels + 1) exceeds the on-chip candidate buffer"; return DSMI_ERR_CAPACITY; }
+    // the first ceil(beam / 64) waves carry the beam entries, the other threads `per` (entry, label) pairs each
+    const int EW = (beam + 63) / 64;
+    const size_t per = BT > 64 * EW ? (NMAX - beam + (BT - 64 * EW) - 1) / (BT - 64 * EW) : ~(size_t)0;
+    if (lds > 160 * 1024 - 256 || per > (size_t)(BT == 1024 ? 10 : 22) || C > MAXC) { d->err = "beam_width * (n_labels + 1) exceeds the on-chip candidate buffer"; return DSMI_ERR_CAPACITY; }
     DEC_HIP(d, hipSetDevice(d->device));
     hipStream_t s = (hipStream_t)stream;
     // ---- workspace carve
@@ -196,6 +200,7 @@ extern "C" int dsmi_beam_enqueue(dsmi_decoder* d, const float* probs, const int3
     size_t o_n = off; off += al((size_t)B * 4);
     size_t o_score = off; off += al((size_t)B * beam * 8);
     size_t o_dbg = off; off += al((size_t)B * 16);
+    size_t o_stamps = off; off += al(64 * 8 * 8);
     const size_t out_bytes = off - o_out;
     if (off > d->ws_bytes) {
         DEC_HIP(d, hipDeviceSynchronize());
@@ -219,7 +224,7 @@ extern "C" int dsmi_beam_enqueue(dsmi_decoder* d, const float* probs, const int3
     a.has_lm = d->has_lm ? 1 : 0; a.order = d->has_lm ? d->lm.order : 1; a.alpha = d->alpha; a.beta = d->beta;
     a.lm = d->lm.view(); a.lm.tab = d->d_tab; a.lm.klm.base = d->d_klm; a.trie_next = d->d_next; a.trie_word = d->d_word; a.unk = d->lm.unk; a.bos = d->lm.bos;
     a.ncap = ncap;
-    a.nodes = (NodeRec*)(w + o_nodes); a.dbg = (int32_t*)(w + o_dbg);
+    a.nodes = (NodeRec*)(w + o_nodes); a.dbg = (int32_t*)(w + o_dbg); a.stamps = (unsigned long long*)(w + o_stamps);
     a.out_tok = (int32_t*)(w + o_tok); a.out_step = (int32_t*)(w + o_step); a.out_len = (int32_t*)(w + o_len); a.out_n = (int32_t*)(w + o_n);
     a.out_score = (double*)(w + o_score);
     a.sizes = nullptr;
@@ -237,6 +242,7 @@ extern "C" int dsmi_beam_enqueue(dsmi_decoder* d, const float* probs, const int3
     }
     DEC_HIP(d, hipMemsetAsync(w + o_len, 0, (size_t)B * beam * 4, s));
     DEC_HIP(d, hipMemsetAsync(w + o_dbg, 0, (size_t)B * 16, s));
+    DEC_HIP(d, hipMemsetAsync(w + o_stamps, 0, 64 * 8 * 8, s));
     // candidates per thread: a compile-time bound, so that they live in registers
     auto launch = [&](auto kern) -> hipError_t {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -245,13 +251,13 @@ extern "C" int dsmi_beam_enqueue(dsmi_decoder* d, const float* probs, const int3
         return hipSuccess;
     };
     if (BT == 1024) {
-        if (NMAX <= (size_t)3 * BT) DEC_HIP(d, launch(beam_kernel<1024, 3>));
-        else if (NMAX <= (size_t)5 * BT) DEC_HIP(d, launch(beam_kernel<1024, 5>));
-        else DEC_HIP(d, launch(beam_kernel<1024, 9>));
+        if (per <= 3) DEC_HIP(d, launch(beam_kernel<1024, 3>));
+        else if (per <= 5) DEC_HIP(d, launch(beam_kernel<1024, 5>));
+        else DEC_HIP(d, launch(beam_kernel<1024, 10>));
     } else {
-        if (NMAX <= (size_t)5 * BT) DEC_HIP(d, launch(beam_kernel<512, 5>));
-        else if (NMAX <= (size_t)9 * BT) DEC_HIP(d, launch(beam_kernel<512, 9>));
-        else DEC_HIP(d, launch(beam_kernel<512, 17>));
+        if (per <= 5) DEC_HIP(d, launch(beam_kernel<512, 5>));
+        else if (per <= 11) DEC_HIP(d, launch(beam_kernel<512, 11>));
+        else DEC_HIP(d, launch(beam_kernel<512, 22>));
     }
     DEC_HIP(d, hipGetLastError());
     // Only the kernel is queued here.  A device-to-host copy queued behind it would sit in a DMA queue until the search is
@@ -287,6 +293,7 @@ extern "C" int dsmi_beam_collect(dsmi_decoder* d, int32_t* tokens, int32_t* tste
     const double* h_score = reinterpret_cast<const double*>(q0); q0 += al((size_t)B * beam * 8);
     const int32_t* h_dbg = reinterpret_cast<const int32_t*>(q0);
     for (int k = 0; k < 4; ++k) { d->stats[k] = 0; for (int b = 0; b < B; ++b) d->stats[k] += h_dbg[4 * b + k]; }
+    std::memcpy(d->stamps, reinterpret_cast<const unsigned char*>(h_dbg) + al((size_t)B * 16), sizeof(d->stamps));
     // ... then, of the token arrays, only the columns that hold tokens: transcripts are a fraction of T_out long
     int maxlen = 0;
     for (size_t i = 0; i < (size_t)B * beam; ++i) maxlen = std::max(maxlen, (int)h_len[i]);
@@ -329,6 +336,12 @@ extern "C" int dsmi_beam_collect(dsmi_decoder* d, int32_t* tokens, int32_t* tste
 extern "C" int dsmi_decoder_beam_stats(const dsmi_decoder* d, int32_t* counts4) {
     if (!d || !counts4) return DSMI_ERR_INVALID;
     for (int k = 0; k < 4; ++k) counts4[k] = d->stats[k];
+    return DSMI_OK;
+}
+
+extern "C" int dsmi_debug_beam_stamps(const dsmi_decoder* d, uint64_t* stamps_host, int64_t n_words) {
+    if (!d || !stamps_host || n_words < 64 * 8) return DSMI_ERR_INVALID;
+    std::memcpy(stamps_host, d->stamps, sizeof(d->stamps));
     return DSMI_OK;
 }
 

@@ -265,6 +265,9 @@ int dsmi_beam_enqueue(dsmi_decoder* d, const float* probs_dev, const int32_t* si
                       int beam_width, int cutoff_top_n, double cutoff_prob, void* stream);
 int dsmi_beam_collect(dsmi_decoder* d, int32_t* tokens_host, int32_t* tsteps_host, int32_t* lens_host, float* scores_host);
 int dsmi_decoder_beam_stats(const dsmi_decoder* d, int32_t* counts4);
+/* Diagnostics: phase boundaries of the last collected search's first utterance, 64 frames from the middle of the clip x 8 stamps
+ * (100 MHz ticks; 0 = frame start, 1..6 = after the frame's six barriers); tools/beam_stamps.py prints the anatomy. */
+int dsmi_debug_beam_stamps(const dsmi_decoder* d, uint64_t* stamps_host, int64_t n_words);
 
 /* ---- Host-only view of a language model file (no GPU involved): what dsmi_decoder_set_lm would load.
  * kind: 0 ARPA text, 1 KenLM probing binary, 2 KenLM trie binary.  Word ids are the file's own (KenLM's WordIndex for

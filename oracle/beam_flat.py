@@ -30,11 +30,18 @@ from oracle.beam import FLT_MIN, NEG_INF, log_sum_exp, pruned_log_probs
 from oracle.lm import LOG10_E, OOV_SCORE, START_TOKEN
 
 stats = {"revivals": 0, "walk_hops": 0, "frames": 0, "inherit_hops": 0}
-KERNEL_THREADS = 1024      # the kernel numbers the next beam's slots wave by wave: candidate idx belongs to thread idx % BT, round idx // BT
+KERNEL_THREADS = 1024      # the kernel numbers the next beam's slots wave by wave, round by round (see _slot_order)
 
 
-def _slot_order(idx):
-    tid, k = idx % KERNEL_THREADS, idx // KERNEL_THREADS
+def _slot_order(idx, nb, beam_size):
+    """Where the kernel's thread layout puts candidate ``idx`` in its (wave, round, lane) numbering of the next beam: the
+    first ceil(beam / 64) waves carry the entries (candidate j on thread j), the other threads the pairs, dealt round robin."""
+    if idx < nb:
+        return (idx // 64, 0, idx % 64)
+    ew = (beam_size + 63) // 64
+    pt = KERNEL_THREADS - 64 * ew
+    p = idx - nb
+    tid, k = 64 * ew + p % pt, p // pt
     return (tid // 64, k, tid % 64)
 
 
@@ -161,7 +168,7 @@ def ctc_beam_search(probs, labels, beam_size, cutoff_prob=1.0, cutoff_top_n=40, 
         newslot = [-1] * nb
         pos = 0
         sel = []
-        for q in sorted(keep, key=lambda q: _slot_order(cands[q][2])):
+        for q in sorted(keep, key=lambda q: _slot_order(cands[q][2], nb, beam_size)):
             sel.append((q, pos))
             if cands[q][3] == "stay":
                 newslot[cands[q][4]] = pos

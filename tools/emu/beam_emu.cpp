@@ -48,14 +48,17 @@ int main(int argc, char** argv) {
     a.out_tok = tok.data(); a.out_step = step.data(); a.out_len = len.data(); a.out_n = nout.data(); a.out_score = score.data();
     const size_t NMAX = (size_t)beam * (C + 1);
     if (carve(beam, C, BT).bytes > sizeof(smem_raw)) { std::fprintf(stderr, "does not fit\n"); return 4; }
+    const int EW = (beam + 63) / 64;
+    const size_t per = ((size_t)beam * C + (BT - 64 * EW) - 1) / (BT - 64 * EW);       // pairs per pair thread
     if (BT == 1024) {
-        if (NMAX <= 3 * 1024) simt::launch(B, BT, [&]() { beam_kernel<1024, 3>(a); });
+        if (per <= 3) simt::launch(B, BT, [&]() { beam_kernel<1024, 3>(a); });
         else simt::launch(B, BT, [&]() { beam_kernel<1024, 5>(a); });
     } else if (BT == 512) {
-        if (NMAX <= 5 * 512) simt::launch(B, BT, [&]() { beam_kernel<512, 5>(a); });
-        else simt::launch(B, BT, [&]() { beam_kernel<512, 9>(a); });
+        if (per <= 5) simt::launch(B, BT, [&]() { beam_kernel<512, 5>(a); });
+        else simt::launch(B, BT, [&]() { beam_kernel<512, 11>(a); });
     } else {
-        simt::launch(B, BT, [&]() { beam_kernel<64, 9>(a); });      // one wave: only for problems with beam * (C + 1) <= 576
+        if (per > 9) { std::fprintf(stderr, "too many pairs per thread for the 128-thread build\n"); return 4; }
+        simt::launch(B, 128, [&]() { beam_kernel<128, 9>(a); });      // two waves: one for the entries, one for the pairs
     }
     std::ofstream o(argv[2], std::ios::binary);
     o.write((char*)tok.data(), tok.size() * 4); o.write((char*)step.data(), step.size() * 4); o.write((char*)len.data(), len.size() * 4);

@@ -106,6 +106,27 @@ def main():
         syn.make_arpa(path, order=3, n_words=200, seed=5, ngrams_per_order=600)
         ok &= compare(peaky(np.random.default_rng(2), 2, 40, 33, 2.0), np.array([40, 20]), syn.DANSPEECH_LABELS, 16, a.threads,
                       lm_path=path, alpha=1.3, beta=0.2)
+    if a.case in ("walk", "all"):
+        for seed, beam in ((80, 4), (61, 3), (112, 6), (119, 3)):
+            probs = np.random.default_rng(seed).dirichlet(np.ones(4) * 0.5, size=(1, 60)).astype(np.float32)
+            ok &= compare(probs, None, "_abc", beam, a.threads)
+    if a.case in ("ties", "all"):
+        # exact ties fall by the kernel's slot numbering: compare with oracle/beam_flat.py numbering slots for this thread count
+        from oracle import beam_flat as bf
+        bf.KERNEL_THREADS = a.threads
+        labels = syn.DANSPEECH_LABELS
+        C = len(labels)
+        probs = np.full((2, 12, C), 1.0 / C, dtype=np.float32)
+        probs[1, 3:6, 5:] = 0.0
+        probs[1, 3:6, :5] = 0.2
+        tok, step, ln, nout, score, dt = run(probs, None, labels, 24, threads=a.threads)
+        for b in range(2):
+            res = bf.ctc_beam_search(probs[b].astype(np.float64), labels, 24)
+            for p, (sc, tokens, steps) in enumerate(res):
+                if list(tok[b, p, :ln[b, p]]) != tokens or list(step[b, p, :ln[b, p]]) != steps:
+                    print("TIES MISMATCH", b, p)
+                    ok = False
+        print("ties: %s in %.1f s" % ("OK" if ok else "FAILED", dt))
     if a.case in ("cutoff", "all"):
         ok &= compare(peaky(np.random.default_rng(4), 1, 25, 33, 3.0), None, syn.DANSPEECH_LABELS, 12, a.threads, top_n=10, cutoff_prob=0.98)
     sys.exit(0 if ok else 1)

@@ -63,6 +63,8 @@ template <typename K> void launch(int grid, int block, K kernel) {
 inline void __syncthreads() { simt::g_block->all->arrive_and_wait(); }
 inline void __builtin_amdgcn_wave_barrier() { simt::wave_sync(); }
 template <typename T> inline T __shfl_xor(T v, int mask, int = 64) { return simt::exchange(v, (int)((threadIdx.x & 63) ^ mask)); }
+template <typename T> inline T __shfl(T v, int src, int = 64) { return simt::exchange(v, src); }
+inline void __builtin_amdgcn_s_setprio(int) {}
 template <typename T> inline T __shfl_up(T v, int d, int = 64) { const int l = threadIdx.x & 63; return simt::exchange(v, l >= d ? l - d : -1); }
 template <typename T> inline T __shfl_down(T v, int d, int = 64) { const int l = threadIdx.x & 63; return simt::exchange(v, l + d < 64 ? l + d : -1); }
 inline unsigned long long __ballot(int pred) {
@@ -91,5 +93,6 @@ inline long long __double_as_longlong(double v) { return simt::unbits<long long>
 inline double __longlong_as_double(long long v) { return simt::unbits<double>(simt::bits(v)); }
 inline int __float_as_int(float v) { return simt::unbits<int>(simt::bits(v)); }
 inline float __int_as_float(int v) { return simt::unbits<float>(simt::bits(v)); }
+inline unsigned long long wall_clock64() { return 0; }
 using std::min;
 using std::max;

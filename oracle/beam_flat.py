@@ -139,9 +139,15 @@ def ctc_beam_search(probs, labels, beam_size, cutoff_prob=1.0, cutoff_top_n=40, 
                     n_tstep[E.upnode[j]] = t
                 if E.direct(j):
                     x = pair_logp(P, c)
-            nbcur[j] = log_sum_exp(r, x)
+            # the kernel's form of nb_cur = lse(r, x), score = lse(b, nb_cur): both exps and both logs independent of each other
+            m2 = max(r, x)
+            e1 = math.exp(min(r, x) - m2) if (r > NEG_INF and x > NEG_INF) else 0.0
+            e2 = math.exp(-abs(b - m2)) if (b > NEG_INF and m2 > NEG_INF) else 0.0
+            sum2 = 1.0 + e1
+            xx = 1.0 + sum2 * e2 if b >= m2 else e2 + sum2
+            nbcur[j] = m2 + math.log(sum2)
             bcur[j] = b
-            s = log_sum_exp(b, nbcur[j])
+            s = max(b, m2) + math.log(xx)
             cands.append((s, E.ch[j], j, "stay", j))
         for i in range(nb):
             for c in range(C):

@@ -177,13 +177,15 @@ extern "C" int dsmi_beam_enqueue(dsmi_decoder* d, const float* probs, const int3
     const int C = (int)d->labels.size();
     if (!probs || B < 1 || To < 1 || beam < 1) { d->err = "bad beam arguments"; return DSMI_ERR_INVALID; }
     if (d->beam_pending) { d->err = "the previous beam search has not been collected"; return DSMI_ERR_INVALID; }
-    const size_t NMAX = (size_t)beam * (C + 1);
-    static const int BT = getenv("DSMI_BEAM_THREADS") ? atoi(getenv("DSMI_BEAM_THREADS")) : 1024;      // (experiment switch)
+    // 1024 threads per utterance: with 512 the per-frame phases are cheaper (no register spills) but a beam of 128 leaves too few
+    // pair threads (24 us per frame against 13; at beam 64 the two are equal: profiles/r03_beam_anatomy.txt)
+    constexpr int BT = 1024;
     const size_t lds = carve(beam, C, BT).bytes;
-    // the first ceil(beam / 64) waves carry the beam entries, the other threads `per` (entry, label) pairs each
-    const int EW = (beam + 63) / 64;
-    const size_t per = BT > 64 * EW ? (NMAX - beam + (BT - 64 * EW) - 1) / (BT - 64 * EW) : ~(size_t)0;
-    if (lds > 160 * 1024 - 256 || per > (size_t)(BT == 1024 ? 10 : 22) || C > MAXC) { d->err = "beam_width * (n_labels + 1) exceeds the on-chip candidate buffer"; return DSMI_ERR_CAPACITY; }
+    // thread roles (beam_kernel.inc): ceil(beam / 64) waves for the entries, as many again for the (entry, space) pairs when a
+    // scorer is set, the other threads `per` (entry, label) pairs each
+    const int EW = (beam + 63) / 64, RW = d->has_lm ? 2 * EW : EW;
+    const size_t per = BT > 64 * RW ? ((size_t)beam * C + (BT - 64 * RW) - 1) / (BT - 64 * RW) : ~(size_t)0;
+    if (lds > 160 * 1024 - 256 || per > 12 || C > MAXC) { d->err = "beam_width * (n_labels + 1) exceeds the on-chip candidate buffer"; return DSMI_ERR_CAPACITY; }
     DEC_HIP(d, hipSetDevice(d->device));
     hipStream_t s = (hipStream_t)stream;
     // ---- workspace carve
@@ -250,15 +252,9 @@ extern "C" int dsmi_beam_enqueue(dsmi_decoder* d, const float* probs, const int3
         hipLaunchKernelGGL(kern, dim3(B), dim3(BT), lds, s, a);
         return hipSuccess;
     };
-    if (BT == 1024) {
-        if (per <= 3) DEC_HIP(d, launch(beam_kernel<1024, 3>));
-        else if (per <= 5) DEC_HIP(d, launch(beam_kernel<1024, 5>));
-        else DEC_HIP(d, launch(beam_kernel<1024, 10>));
-    } else {
-        if (per <= 5) DEC_HIP(d, launch(beam_kernel<512, 5>));
-        else if (per <= 11) DEC_HIP(d, launch(beam_kernel<512, 11>));
-        else DEC_HIP(d, launch(beam_kernel<512, 22>));
-    }
+    if (per <= 3) DEC_HIP(d, launch(beam_kernel<1024, 3>));
+    else if (per <= 6) DEC_HIP(d, launch(beam_kernel<1024, 6>));
+    else DEC_HIP(d, launch(beam_kernel<1024, 12>));
     DEC_HIP(d, hipGetLastError());
     // Only the kernel is queued here.  A device-to-host copy queued behind it would sit in a DMA queue until the search is
     // over, and with it whatever upload another stream has been given the same engine for -- the next batch's samples: its

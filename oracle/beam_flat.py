@@ -33,15 +33,20 @@ stats = {"revivals": 0, "walk_hops": 0, "frames": 0, "inherit_hops": 0}
 KERNEL_THREADS = 1024      # the kernel numbers the next beam's slots wave by wave, round by round (see _slot_order)
 
 
-def _slot_order(idx, nb, beam_size):
+def _slot_order(idx, nb, beam_size, n_labels, space_id, has_lm):
     """Where the kernel's thread layout puts candidate ``idx`` in its (wave, round, lane) numbering of the next beam: the
-    first ceil(beam / 64) waves carry the entries (candidate j on thread j), the other threads the pairs, dealt round robin."""
+    first ceil(beam / 64) waves carry the entries (candidate j on thread j); with a scorer the next ones the (entry, space)
+    pairs; the other threads the remaining pairs, dealt round robin."""
     if idx < nb:
         return (idx // 64, 0, idx % 64)
     ew = (beam_size + 63) // 64
-    pt = KERNEL_THREADS - 64 * ew
     p = idx - nb
-    tid, k = 64 * ew + p % pt, p // pt
+    if has_lm and p % n_labels == space_id:
+        tid = 64 * ew + p // n_labels
+        return (tid // 64, 0, tid % 64)
+    rw = 2 * ew if has_lm else ew
+    pt = KERNEL_THREADS - 64 * rw
+    tid, k = 64 * rw + p % pt, p // pt
     return (tid // 64, k, tid % 64)
 
 
@@ -174,7 +179,7 @@ def ctc_beam_search(probs, labels, beam_size, cutoff_prob=1.0, cutoff_top_n=40, 
         newslot = [-1] * nb
         pos = 0
         sel = []
-        for q in sorted(keep, key=lambda q: _slot_order(cands[q][2], nb, beam_size)):
+        for q in sorted(keep, key=lambda q: _slot_order(cands[q][2], nb, beam_size, C, space_id, has_lm)):
             sel.append((q, pos))
             if cands[q][3] == "stay":
                 newslot[cands[q][4]] = pos

@@ -48,17 +48,18 @@ int main(int argc, char** argv) {
     a.out_tok = tok.data(); a.out_step = step.data(); a.out_len = len.data(); a.out_n = nout.data(); a.out_score = score.data();
     const size_t NMAX = (size_t)beam * (C + 1);
     if (carve(beam, C, BT).bytes > sizeof(smem_raw)) { std::fprintf(stderr, "does not fit\n"); return 4; }
-    const int EW = (beam + 63) / 64;
-    const size_t per = ((size_t)beam * C + (BT - 64 * EW) - 1) / (BT - 64 * EW);       // pairs per pair thread
+    const int EW = (beam + 63) / 64, RW = has_lm ? 2 * EW : EW;
+    if (BT <= 64 * RW) { std::fprintf(stderr, "too few threads for this beam\n"); return 4; }
+    const size_t per = ((size_t)beam * C + (BT - 64 * RW) - 1) / (BT - 64 * RW);       // pairs per pair thread
     if (BT == 1024) {
         if (per <= 3) simt::launch(B, BT, [&]() { beam_kernel<1024, 3>(a); });
-        else simt::launch(B, BT, [&]() { beam_kernel<1024, 5>(a); });
+        else simt::launch(B, BT, [&]() { beam_kernel<1024, 6>(a); });
     } else if (BT == 512) {
-        if (per <= 5) simt::launch(B, BT, [&]() { beam_kernel<512, 5>(a); });
+        if (per <= 6) simt::launch(B, BT, [&]() { beam_kernel<512, 6>(a); });
         else simt::launch(B, BT, [&]() { beam_kernel<512, 11>(a); });
     } else {
-        if (per > 9) { std::fprintf(stderr, "too many pairs per thread for the 128-thread build\n"); return 4; }
-        simt::launch(B, 128, [&]() { beam_kernel<128, 9>(a); });      // two waves: one for the entries, one for the pairs
+        if (per > 9) { std::fprintf(stderr, "too many pairs per thread for the 192-thread build\n"); return 4; }
+        simt::launch(B, 192, [&]() { beam_kernel<192, 9>(a); });      // three waves: entries, (entry, space) pairs, the other pairs
     }
     std::ofstream o(argv[2], std::ios::binary);
     o.write((char*)tok.data(), tok.size() * 4); o.write((char*)step.data(), step.size() * 4); o.write((char*)len.data(), len.size() * 4);

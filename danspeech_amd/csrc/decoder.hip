@@ -59,6 +59,7 @@ struct dsmi_decoder {
     int32_t* pin_sz = nullptr; size_t pin_sz_cap = 0;
     unsigned char* pin = nullptr; size_t pin_bytes = 0;
     hipEvent_t beam_done = nullptr;
+    hipStream_t copy_stream = nullptr;      // the collect's device-to-host copies: a stream of the handle's own
 };
 
 static thread_local std::string g_dec_error;
@@ -97,6 +98,7 @@ static void free_lm(dsmi_decoder* d) {
 extern "C" void dsmi_decoder_destroy(dsmi_decoder* d) {
     if (d && d->pin) { (void)hipSetDevice(d->device); (void)hipDeviceSynchronize(); (void)hipHostFree(d->pin); d->pin = nullptr; }
     if (d && d->beam_done) { (void)hipEventDestroy(d->beam_done); d->beam_done = nullptr; }
+    if (d && d->copy_stream) { (void)hipStreamDestroy(d->copy_stream); d->copy_stream = nullptr; }
     if (d && d->pin_sz) { (void)hipHostFree(d->pin_sz); d->pin_sz = nullptr; }
     if (!d) return;
     (void)hipSetDevice(d->device);
@@ -277,10 +279,11 @@ extern "C" int dsmi_beam_collect(dsmi_decoder* d, int32_t* tokens, int32_t* tste
     const size_t tok_bytes = al((size_t)B * beam * To * 4);
     // lengths, counts and scores first (they are behind the two token arrays in the image) ...
     const unsigned char* dev = d->ws + d->pb_out;
-    // (on the search's own stream, which is idle once the search is over: a blocking copy would go to the null stream and
-    // wait there for whatever forward the caller has queued meanwhile)
-    DEC_HIP(d, hipMemcpyAsync(d->pin + 2 * tok_bytes, dev + 2 * tok_bytes, d->pb_out_bytes - 2 * tok_bytes, hipMemcpyDeviceToHost, d->pb_stream));
-    DEC_HIP(d, hipStreamSynchronize(d->pb_stream));
+    // (on a stream of the handle's own: a blocking copy would go to the null stream and wait there for whatever forward the
+    // caller has queued meanwhile, and the search's stream may already hold the next batch's search of another handle)
+    if (!d->copy_stream) DEC_HIP(d, hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking));
+    DEC_HIP(d, hipMemcpyAsync(d->pin + 2 * tok_bytes, dev + 2 * tok_bytes, d->pb_out_bytes - 2 * tok_bytes, hipMemcpyDeviceToHost, d->copy_stream));
+    DEC_HIP(d, hipStreamSynchronize(d->copy_stream));
     const unsigned char* q0 = d->pin;
     const int32_t* p_tok = reinterpret_cast<const int32_t*>(q0); q0 += tok_bytes;
     const int32_t* p_step = reinterpret_cast<const int32_t*>(q0); q0 += tok_bytes;
@@ -294,9 +297,9 @@ extern "C" int dsmi_beam_collect(dsmi_decoder* d, int32_t* tokens, int32_t* tste
     int maxlen = 0;
     for (size_t i = 0; i < (size_t)B * beam; ++i) maxlen = std::max(maxlen, (int)h_len[i]);
     if (maxlen > 0) {
-        DEC_HIP(d, hipMemcpy2DAsync(d->pin, (size_t)To * 4, dev, (size_t)To * 4, (size_t)maxlen * 4, (size_t)B * beam, hipMemcpyDeviceToHost, d->pb_stream));
-        DEC_HIP(d, hipMemcpy2DAsync(d->pin + tok_bytes, (size_t)To * 4, dev + tok_bytes, (size_t)To * 4, (size_t)maxlen * 4, (size_t)B * beam, hipMemcpyDeviceToHost, d->pb_stream));
-        DEC_HIP(d, hipStreamSynchronize(d->pb_stream));
+        DEC_HIP(d, hipMemcpy2DAsync(d->pin, (size_t)To * 4, dev, (size_t)To * 4, (size_t)maxlen * 4, (size_t)B * beam, hipMemcpyDeviceToHost, d->copy_stream));
+        DEC_HIP(d, hipMemcpy2DAsync(d->pin + tok_bytes, (size_t)To * 4, dev + tok_bytes, (size_t)To * 4, (size_t)maxlen * 4, (size_t)B * beam, hipMemcpyDeviceToHost, d->copy_stream));
+        DEC_HIP(d, hipStreamSynchronize(d->copy_stream));
     }
     for (size_t r = 0; r < (size_t)B * beam && maxlen > 0; ++r) {
         std::memcpy(tokens + r * To, p_tok + r * To, (size_t)maxlen * 4);

@@ -309,3 +309,50 @@ def test_paired_tile_kernel_timeout_is_recomputed(native):
     for b in range(24):
         np.testing.assert_allclose(pn[b, :ol[b]], ref[b, :ol[b]], rtol=0, atol=1e-4)
     m.close()
+
+
+def _lm_recognizer(tmp_path, H=64, L=2, seed=31):
+    from danspeech_amd import Recognizer
+    from danspeech_amd.deepspeech.model import DeepSpeech
+    lm = str(tmp_path / "lm3.arpa")
+    syn.make_arpa(lm, order=3, n_words=300, seed=9, ngrams_per_order=800)
+    sd = syn.make_state_dict(2, "gru", H, L, seed=seed, **syn.TALKATIVE)
+    model = DeepSpeech("m", rnn_hidden_size=H, rnn_layers=L).load_state_dict(sd)
+    return Recognizer(model=model, lm=lm, beam_width=16)
+
+
+def test_pipelined_beam_search_survives_a_recomputed_batch(native, tmp_path):
+    """recognize_batches with a language model keeps a search in flight per batch on alternating decoder handles.  A batch
+    whose persistent kernel timed out is recomputed by its collect and must then be decoded again on ITS OWN handle: handle 0
+    may hold the next batch's search by then."""
+    rec = _lm_recognizer(tmp_path)
+    batches = [[syn.make_clip(10 * b + i, 16000 + 800 * i) for i in range(3)] for b in range(4)]
+    want = [rec.recognize_batch(b, show_all=True) for b in batches]
+    with _env(DSMI_DEBUG_DROP_SIGNAL="1:1:5", DSMI_DEBUG_SPIN_LIMIT="3000"):
+        rec2 = _lm_recognizer(tmp_path)
+        eng = rec2.danspeech_recognizer
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            got = list(rec2.recognize_batches(batches, show_all=True))
+    assert got == want
+    handles = [eng.model._native] + ([eng._replica[0]._native] if eng._replica else [])
+    assert sum(h.recompute_count() for h in handles) >= 1 and any("timed out" in str(x.message) for x in w)
+    assert rec2.recognize_batch(batches[0], show_all=True) == want[0]
+
+
+def test_leaving_the_batch_pipeline_early_leaves_the_engine_usable(native, tmp_path):
+    """A caller that stops consuming recognize_batches (break, or an exception in its loop) must not leave a forward or a
+    beam-search ticket uncollected: the next call on the same engine works."""
+    rec = _lm_recognizer(tmp_path, seed=32)
+    batches = [[syn.make_clip(50 + 10 * b + i, 12000 + 500 * i) for i in range(2)] for b in range(5)]
+    want = [rec.recognize_batch(b) for b in batches]
+    for k, res in enumerate(rec.recognize_batches(batches)):
+        assert res == want[k]
+        if k == 1:
+            break
+    assert rec.recognize_batch(batches[4]) == want[4]
+    assert list(rec.recognize_batches(batches[:3])) == want[:3]
+    with pytest.raises(ZeroDivisionError):
+        for res in rec.recognize_batches(batches):
+            1 / 0
+    assert rec.recognize(batches[2][0]) == want[2][0]

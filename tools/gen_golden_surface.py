@@ -208,6 +208,7 @@ def g12():
     for k, v in m.state_dict().items():
         if k in sd:
             assert np.array_equal(v.numpy(), sd[k]), k
+    m.eval()                                                     # as DanSpeechRecognizer.update_model does (DanSpeechRecognizer.py:50)
     x = torch.from_numpy(syn.make_features(2, 30, n_freq=2, seed=3))
     with torch.no_grad():
         p, n = m(x, torch.IntTensor([30, 30]))

@@ -59,12 +59,19 @@ class _StreamingSession(object):
 
 class _BatchJob(object):
     """One batch between enqueue and decode."""
-    __slots__ = ("order", "probs", "sizes", "count", "model", "ticket", "slot")
+    __slots__ = ("order", "probs", "sizes", "count", "model", "ticket", "slot", "collected", "recomputed")
 
     def __init__(self, order, probs, sizes, count, model):
         self.order, self.probs, self.sizes, self.count, self.model = order, probs, sizes, count, model
         self.ticket = None                       # a beam search launched behind the forward (transcribe_batches)
         self.slot = 0                            # the decoder handle that search occupies
+        self.collected = self.recomputed = False # the forward has been waited for (model.collect) / had to be redone
+
+    def collect_forward(self):
+        if not self.collected:
+            self.recomputed = self.model.collect()
+            self.collected = True
+        return self.recomputed
 
 
 class DanSpeechRecognizer(object):
@@ -160,7 +167,7 @@ class DanSpeechRecognizer(object):
 
     def _finish_batch(self, job, show_all, warn=True):
         import torch
-        recomputed = job.model.collect()         # waits for the forward; a timed-out batch has been recomputed by now
+        recomputed = job.collect_forward()       # waits for the forward; a timed-out batch has been recomputed by now
         side = self._side_stream("decode")
         job.probs.record_stream(side)
         decoded = None
@@ -209,29 +216,41 @@ class DanSpeechRecognizer(object):
         for ps in parsers:
             ps.share_copy_stream = hasattr(self.decoder, "decode_enqueue")     # a search kernel on the decode stream: fewer streams
         streams = [torch.cuda.current_stream(self._device_index()), self._side_stream("second batch")]
-        waiting, turn, job, done = None, 0, None, None
+        # Depth of the pipeline.  Greedy decoding is a short host-synchronous step: two batches in flight.  A beam search is a
+        # kernel of its own that starts when its forward ends: with two batches in flight the host would wait for batch b's
+        # search before it enqueues b + 2, and only ONE forward would be running meanwhile; with three (two forwards and the
+        # oldest batch's search) the GPU always has two forwards (config 3: 13.1 -> ms per batch, tools/run_configs.py).
+        import collections
+        searching = hasattr(self.decoder, "decode_enqueue")
+        depth = 3 if searching else 2
+        pending, turn, count, job, done = collections.deque(), 0, 0, None, None
         try:
             for recordings in batches:
                 job = None
                 if len(recordings):
+                    for older in pending:            # this batch's model handle gives back its previous forward first
+                        if isinstance(older, _BatchJob) and older.model is handles[turn]:
+                            older.collect_forward()
                     with torch.cuda.stream(streams[turn]):
-                        job = self._enqueue_batch(recordings, handles[turn], parsers[turn], decode_slot=turn)
+                        job = self._enqueue_batch(recordings, handles[turn], parsers[turn], decode_slot=count % depth)
                     turn ^= 1
-                if waiting is not None:
-                    done, waiting = waiting, None
+                    count += 1
+                pending.append(job if job is not None else "empty")
+                job = None
+                while len(pending) >= depth:
+                    done = pending.popleft()
                     res = self._finish_batch(done, show_all) if done != "empty" else []
                     done = None
                     yield res
-                waiting, job = (job if job is not None else "empty"), None
-            if waiting is not None:
-                done, waiting = waiting, None
+            while pending:
+                done = pending.popleft()
                 res = self._finish_batch(done, show_all) if done != "empty" else []
                 done = None
                 yield res
         finally:
             # the caller stopped early, or a batch raised: whatever is still enqueued gives its forward and its beam-search
             # ticket back, otherwise the decoder handle stays "not collected" and every later call on this engine fails
-            for left in (done, waiting, job):
+            for left in [done, job] + list(pending):
                 if isinstance(left, _BatchJob):
                     self._abandon(left)
             for h in handles:
@@ -240,7 +259,7 @@ class DanSpeechRecognizer(object):
 
     def _abandon(self, job):
         """Wait for an enqueued batch and drop its results."""
-        for release in (job.model.collect, (lambda: self.decoder.decode_collect(job.ticket)) if job.ticket is not None else None):
+        for release in (job.collect_forward, (lambda: self.decoder.decode_collect(job.ticket)) if job.ticket is not None else None):
             if release is not None:
                 try:
                     release()

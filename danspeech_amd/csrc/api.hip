@@ -160,8 +160,6 @@ extern "C" int dsmi_model_create(const dsmi_model_desc* d, int device, dsmi_mode
     m->Hs = m->geom.Kp;
     m->geom16 = make_rnn_geom_u(d->rnn_type, d->rnn_hidden_size, d->bidirectional ? 2 : 1, 16);
     m->have16 = d->rnn_hidden_size % 16 == 0;
-    m->geom32 = make_rnn_geom_u(d->rnn_type, d->rnn_hidden_size, d->bidirectional ? 2 : 1, 32);
-    m->have32 = rnn_persist32_eligible(m->geom32, 16, 1 << 20, nullptr);      // the shape fits the kernel at all
     m->rnn.resize(d->rnn_layers);
     {
         hipDeviceProp_t prop;
@@ -169,26 +167,19 @@ extern "C" int dsmi_model_create(const dsmi_model_desc* d, int device, dsmi_mode
         const char* mode = std::getenv("DSMI_RNN_MODE");      // "steps": one launch per time step; "persist8": first-generation persistent kernel
         m->rnn_mode = (mode && std::string(mode) == "steps") ? 0 : 1;
         m->persist_gen = (mode && std::string(mode) == "persist8") ? 1 : 2;
-        const char* gm = std::getenv("DSMI_GEMM_MODE");       // "f32" forces the fp32-MFMA GEMM
-        m->gemm_mode = (gm && std::string(gm) == "f32") ? 0 : 1;
-        const char* cm = std::getenv("DSMI_CONV_MODE");       // "f32" forces the fp32-MFMA conv for all layers
-        m->conv_mode = (cm && std::string(cm) == "f32") ? 0 : 1;
-        const char* c1 = std::getenv("DSMI_CONV1_MODE");      // "f32" keeps the first conv layer on the fp32 MFMA (conv.hip)
-        m->conv1_split = !(c1 && std::string(c1) == "f32");
+        // DSMI_DENSE_MODE=f32: GEMM and conv layers on the plain fp32-MFMA kernels (the round-1 path, and where a model whose
+        // weights leave fp16's range ends up by itself); with DSMI_RNN_MODE=steps the whole forward is the second, independent
+        // implementation the parity tests compare the default one with
+        const char* dm = std::getenv("DSMI_DENSE_MODE");
+        const bool dense_f32 = dm && std::string(dm) == "f32";
+        m->gemm_mode = dense_f32 ? 0 : 1;
+        m->conv_mode = dense_f32 ? 0 : 1;
+        m->conv1_split = !dense_f32;
         // test hooks for the hand-off timeout path (tests/test_gpu_timeout.py)
         if (const char* sl = std::getenv("DSMI_DEBUG_SPIN_LIMIT")) m->spin_limit = (unsigned)std::max(1L, std::atol(sl));
         if (const char* ds = std::getenv("DSMI_DEBUG_DROP_SIGNAL"))
             if (std::sscanf(ds, "%d:%d:%d", &m->drop_layer, &m->drop_wg, &m->drop_step) != 3) m->drop_layer = -1;
-        const char* ln = std::getenv("DSMI_PERSIST_LANES");     // default 2: two batches in flight share the CUs; 1: whole-device kernels only
-        m->lanes = (ln && std::atoi(ln) == 1) ? 1 : 2;          // 1: whole-device persistent kernels only
-        const char* pd = std::getenv("DSMI_PERSIST_DUO");       // 0: never the paired-tile kernel
-        m->persist_duo = pd ? (std::atoi(pd) == 0 ? 0 : 1) : -1;       // -1: by the number of batches in flight
-        const char* pq = std::getenv("DSMI_PERSIST_QUAD");
-        m->persist_quad = pq ? (std::atoi(pq) == 0 ? 0 : 1) : -1;
-        const char* pu = std::getenv("DSMI_PERSIST_UNITS");     // 32: the 32-unit kernel when two batches are in flight (measured slower: DESIGN.md 4)
-        m->persist_units = pu ? std::atoi(pu) : 0;
-        const char* pw = std::getenv("DSMI_PERSIST_WAVES");     // 4 / 8 forces the workgroup size of rnn_persist16
-        m->persist_waves = pw ? (std::atoi(pw) == 4 ? 4 : 8) : 0;       // 0: by the number of batches in flight
+        m->lanes = 2;
         {
             PersistGate* g = persist_gate(device);
             std::lock_guard<std::mutex> lk(g->mu);
@@ -334,21 +325,6 @@ extern "C" int dsmi_model_finalize(dsmi_model* m) {
             for (int dd = 0; dd < g.D; ++dd)
                 if ((rc = upload(m, pack_whh16(g16, wh[dd]->data.data()), &r.whh16_sp[dd]))) return rc;
         }
-        if (m->have32) {
-            const RnnGeom& g32 = m->geom32;
-            std::vector<float> w32((size_t)g32.Np * r.ldw, 0.f), b32(g32.Np, 0.f);
-            for (int col = 0; col < g32.Np; ++col) {
-                int dd;
-                const int src = rnn_src_row(g32, col, &dd);
-                if (src < 0) continue;
-                std::memcpy(&w32[(size_t)col * r.ldw], &wi[dd]->data[(size_t)src * I], sizeof(float) * I);
-                b32[col] = bi[dd]->data[src];
-            }
-            if ((rc = upload(m, pack_gemm_w_split(w32.data(), g32.Np, r.K, r.ldw), &r.wih32_sp))) return rc;
-            if ((rc = upload(m, b32, &r.bih32))) return rc;
-            for (int dd = 0; dd < g.D; ++dd)
-                if ((rc = upload(m, pack_whh32(g32, wh[dd]->data.data()), &r.whh32_sp[dd]))) return rc;
-        }
         if (l > 0) {  // model.py:403-404: BatchNorm1d(H) in front of layers >= 1
             std::vector<float> a, b;
             if (!bn_affine(m, "rnns." + std::to_string(l) + ".batch_norm.module", H, m->Hs, a, b)) return DSMI_ERR_NOT_READY;
@@ -435,7 +411,7 @@ extern "C" int dsmi_reserve(dsmi_model* m, int max_B, int max_T) {
         if ((rc = ws_alloc(m, &m->conv_buf_sp[i], n))) return rc;
     }
     const size_t rows = (size_t)To * max_B;
-    if ((rc = ws_alloc(m, &m->xp, rows * std::max(std::max(m->geom.Np, m->have16 ? m->geom16.Np : 0), m->have32 ? m->geom32.Np : 0)))) return rc;
+    if ((rc = ws_alloc(m, &m->xp, rows * std::max(m->geom.Np, m->have16 ? m->geom16.Np : 0)))) return rc;
     for (int i = 0; i < 2; ++i)
         for (int dd = 0; dd < 2; ++dd) {
             m->hbuf[i][dd] = nullptr;
@@ -461,7 +437,7 @@ extern "C" int dsmi_reserve(dsmi_model* m, int max_B, int max_T) {
         const size_t kt = (size_t)ceil_div(std::max(m->I0, m->Hs), 32);
         if ((rc = ws_alloc(m, &m->a_sp, mt * kt * 2 * 4096))) return rc;
     }
-    if (m->have16 || m->have32) {
+    if (m->have16) {
         const size_t n = rnn_persist16_state_halfs(m->geom16, max_B);
         if ((rc = ws_alloc(m, &m->hpack16, n))) return rc;
         HIP_OK(m, hipMemset(m->hpack16, 0, n * sizeof(uint16_t)));
@@ -559,34 +535,21 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
     const double GH = (double)m->geom.G * m->desc.rnn_hidden_size, Dd = m->geom.D;
     int pgroups = 0, waves = 8;
     bool use16 = m->rnn_mode == 1 && m->persist_gen == 2 && m->gemm_mode == 1 && m->have16 && gl.w_sp;
-    // Two batches in flight (dsmi_model_set_inflight(m, 2)): the 32-unit kernel on the CUs of ONE lane, so that the two
-    // batches' recurrent layers run on disjoint halves of the chip.
-    const bool use32 = use16 && m->lanes == 2 && m->inflight >= 2 && m->have32 && m->persist_units == 32 &&
-                       rnn_persist32_eligible(m->geom32, B, m->n_cus / 2, &pgroups);
     // Which 16-unit kernel.  The caller says how many batches it keeps in flight (dsmi_model_set_inflight):
     //   1 -> whole-CU workgroups on the whole device: the shortest step for a lone batch (2.7 us for cfgA at B = 32);
     //   2 -> the paired-tile pipeline on ONE gate lane's CUs when the batch fits there (B = 17..32 for cfgA: 100 CUs), so that
     //        the second batch's recurrent layer runs on the other half of the chip; failing that, half-CU workgroups (one lane,
     //        the two batches share every CU); failing that, whole-CU workgroups (both lanes: the two batches take turns).
-    // DSMI_PERSIST_DUO / DSMI_PERSIST_WAVES force a variant (tests, experiments).
-    // DSMI_PERSIST_QUAD=1 (experiments; measured slower): the four-chain kernel -- both directions of two tiles
-    // per workgroup -- on ONE gate slot, a quarter of the chip (cfgA at B = 17..32: 50 CUs).
-    bool duo = false, duo_lane = false, quad = false;
-    const bool want_quad = m->persist_quad == 1;
-    if (use16 && !use32 && want_quad && m->lanes == 2) quad = rnn_persist_quad_eligible(m->geom16, B, m->n_cus / kMaxLanes);
-    const bool want_duo = !quad && (m->persist_duo >= 0 ? m->persist_duo == 1 : m->inflight >= 2);
-    const int want_waves = m->persist_waves ? m->persist_waves : (m->inflight >= 2 ? 4 : 8);
-    if (use16 && !use32 && want_duo) {
-        duo_lane = m->lanes == 2 && rnn_persist_duo_eligible(m->geom16, B, m->n_cus / 2);
+    bool duo = false, duo_lane = false;
+    if (use16 && m->inflight >= 2) {
+        duo_lane = rnn_persist_duo_eligible(m->geom16, B, m->n_cus / 2);
         duo = duo_lane || rnn_persist_duo_eligible(m->geom16, B, m->n_cus);
     }
-    if (use16 && !use32 && !duo && !quad) {
-        if (want_waves == 4 && m->lanes == 2 && rnn_persist16_half_eligible(m->geom16, B, m->n_cus, &pgroups)) waves = 4;
+    if (use16 && !duo) {
+        if (m->inflight >= 2 && rnn_persist16_half_eligible(m->geom16, B, m->n_cus, &pgroups)) waves = 4;
         else use16 = rnn_persist16_eligible(m->geom16, B, m->n_cus, &pgroups);
     }
-    if (use32) {
-        gl.w_sp = m->rnn[l].wih32_sp; gl.bias = m->rnn[l].bih32; gl.N = m->geom32.Np; gl.ldc = m->geom32.Np;
-    } else if (use16) {      // the second-generation kernel reads the x-projection in its own column order
+    if (use16) {      // the second-generation kernel reads the x-projection in its own column order
         gl.w_sp = m->rnn[l].wih16_sp; gl.bias = m->rnn[l].bih16; gl.N = m->geom16.Np; gl.ldc = m->geom16.Np;
     }
     gl.ev = timer_arm(m, gl.mode == GEMM_A_CONV ? KK_GEMM0 : KK_GEMM, true, 2.0 * Dd * GH * gl.K * sumlen,
@@ -594,9 +557,9 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
     launch_gemm(gl, s);
     if (use16) {
         RnnPersist16Launch pl;
-        pl.g = use32 ? m->geom32 : m->geom16;
+        pl.g = m->geom16;
         for (int dd = 0; dd < 2; ++dd) {
-            pl.whh16[dd] = use32 ? m->rnn[l].whh32_sp[dd] : m->rnn[l].whh16_sp[dd];
+            pl.whh16[dd] = m->rnn[l].whh16_sp[dd];
             pl.bhh[dd] = m->rnn[l].bhh[dd]; pl.out[dd] = m->hbuf[dst][dd];
         }
         pl.xp = m->xp; pl.lens_dev = m->lens_dev; pl.hpack16 = m->hpack16; pl.counters = m->pcnt; pl.err = m->perr;
@@ -610,12 +573,10 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
         {
             PersistGate* gate = persist_gate(m->device);
             std::lock_guard<std::mutex> lk(gate->mu);       // wait -> launch -> record is atomic against other host threads
-            static const bool force_lane = std::getenv("DSMI_PERSIST_FORCE_LANE") != nullptr;     // experiments only
-            // a quarter-chip kernel takes one slot, a half-CU / half-chip kernel a pair, anything else the device
-            const int width = m->lanes != 2 ? kMaxLanes : (quad ? 1 : (((waves == 4 && !duo) || duo_lane || use32 || force_lane) ? 2 : kMaxLanes));
+            // a half-CU / half-chip kernel takes one lane (a pair of gate slots), anything else the device
+            const int width = ((waves == 4 && !duo) || duo_lane) ? 2 : kMaxLanes;
             gate_wait(gate, s, m->lane, width);
-            ok = use32 ? launch_rnn_persist32(pl, s)
-                       : (quad ? launch_rnn_persist_quad(pl, s) : (duo ? launch_rnn_persist_duo(pl, s) : launch_rnn_persist16(pl, s)));
+            ok = duo ? launch_rnn_persist_duo(pl, s) : launch_rnn_persist16(pl, s);
             gate_record(gate, s, m->lane, width);
         }
         if (ok) return;

@@ -6,6 +6,7 @@
 // RCCL is bound at run time (dlopen in dsmi_comm_unique_id / dsmi_comm_init): libdsmi.so carries no load-time dependency
 // on it, and a process that already holds a copy (PyTorch ships its own) keeps using that one.
 #include "common.h"
+#include "host_logic.h"
 
 #include <rccl/rccl.h>
 #include <dlfcn.h>
@@ -69,14 +70,6 @@ int pcm_bytes(int dtype) {
     return w[base] * ((dtype & DSMI_PCM_STEREO) ? 2 : 1);
 }
 
-// order[k] = index of the k-th longest clip (stable): rank k % world takes it as its (k / world)-th clip
-std::vector<int> length_order(const int64_t* n_samples, int n) {
-    std::vector<int> order((size_t)n);
-    std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return n_samples[a] > n_samples[b]; });
-    return order;
-}
-
 }  // namespace
 
 struct dsmi_comm {
@@ -124,8 +117,7 @@ int ensure(dsmi_comm* c, unsigned char** dev, size_t* cap, size_t need, bool pin
 // batch, reference model.py:117).
 extern "C" int dsmi_plan_shards(const int64_t* n_samples, int n, int world, int32_t* rank_of, int32_t* slot_of) {
     if (n < 0 || world < 1 || (n > 0 && (!n_samples || !rank_of || !slot_of))) return DSMI_ERR_INVALID;
-    const std::vector<int> order = length_order(n_samples, n);
-    for (int k = 0; k < n; ++k) { rank_of[order[(size_t)k]] = k % world; slot_of[order[(size_t)k]] = k / world; }
+    dsmi::plan_shards(n_samples, n, world, rank_of, slot_of);
     return DSMI_OK;
 }
 
@@ -176,16 +168,21 @@ extern "C" int dsmi_comm_scatter(dsmi_comm* c, int root, const void* const* clip
                                  const void** shard_pcm_dev, int64_t* shard_n_samples, int32_t* shard_index, int shard_cap,
                                  int* shard_count, int* shard_dtype, int* total_count, void* stream) {
     if (!c) return DSMI_ERR_INVALID;
-    if (root < 0 || root >= c->world || !shard_pcm_dev || !shard_n_samples || !shard_index || !shard_count || shard_cap < 0)
-        return cfail(c, DSMI_ERR_INVALID, "bad scatter arguments");
+    // A rank that returned before (or between) the exchanges would leave the others waiting in a broadcast or a receive for
+    // ever.  So: what every rank can check identically (root, the header, the lengths) may return at once -- all ranks do;
+    // what only THIS rank knows (its output pointers, its shard_cap) is remembered, the rank still takes part in every
+    // exchange, and the error is returned at the end; the root's own bad arguments travel in the header.
+    if (root < 0 || root >= c->world) return cfail(c, DSMI_ERR_INVALID, "bad scatter arguments");
+    int late_rc = DSMI_OK; const char* late_msg = "";
+    if (!shard_pcm_dev || !shard_n_samples || !shard_index || !shard_count || shard_cap < 0) { late_rc = DSMI_ERR_INVALID; late_msg = "bad scatter arguments"; }
     const bool is_root = c->rank == root;
-    if (is_root && (n < 0 || !pcm_bytes(pcm_dtype) || (n > 0 && (!clips_host || !n_samples_host)))) return cfail(c, DSMI_ERR_INVALID, "bad scatter arguments (root)");
+    const bool root_bad = is_root && (n < 0 || !pcm_bytes(pcm_dtype) || (n > 0 && (!clips_host || !n_samples_host)));
     Rccl* r = rccl();
     hipStream_t s = (hipStream_t)stream;
     COMM_HIP(c, hipSetDevice(c->device));
 
     // 1. header
-    int64_t hd[2] = {is_root ? n : 0, is_root ? pcm_dtype : 0};
+    int64_t hd[2] = {is_root ? (root_bad ? -1 : n) : 0, is_root ? pcm_dtype : 0};
     if (c->head_cap < 2) { if (c->head) (void)hipFree(c->head); c->head = nullptr; COMM_HIP(c, hipMalloc((void**)&c->head, sizeof(int64_t) * 4096)); c->head_cap = 4096; }
     if (c->world > 1) {
         if (is_root) COMM_HIP(c, hipMemcpyAsync(c->head, hd, sizeof(hd), hipMemcpyHostToDevice, s));
@@ -193,6 +190,7 @@ extern "C" int dsmi_comm_scatter(dsmi_comm* c, int root, const void* const* clip
         COMM_HIP(c, hipMemcpyAsync(hd, c->head, sizeof(hd), hipMemcpyDeviceToHost, s));
         COMM_HIP(c, hipStreamSynchronize(s));
     }
+    if (hd[0] == -1) return cfail(c, DSMI_ERR_INVALID, is_root ? "bad scatter arguments (root)" : "the root's scatter arguments were refused");
     const int total = (int)hd[0], dtype = (int)hd[1], sb = pcm_bytes(dtype);
     if (total < 0 || !sb) return cfail(c, DSMI_ERR_COMM, "malformed scatter header");
     if (total_count) *total_count = total;
@@ -211,16 +209,18 @@ extern "C" int dsmi_comm_scatter(dsmi_comm* c, int root, const void* const* clip
     for (int i = 0; i < total; ++i) if (lens[(size_t)i] < 1) return cfail(c, DSMI_ERR_INVALID, "empty clip");
 
     // 3. the plan, identical on every rank: rank q's shard = order[q], order[q + world], ...
-    const std::vector<int> order = length_order(lens.data(), total);
+    const std::vector<int> order = dsmi::length_order(lens.data(), total);
     std::vector<size_t> bytes_of((size_t)c->world, 0);
     for (int k = 0; k < total; ++k) bytes_of[(size_t)(k % c->world)] += (size_t)lens[(size_t)order[(size_t)k]] * sb;
     const int mine = total > c->rank ? (total - c->rank + c->world - 1) / c->world : 0;
-    if (mine > shard_cap) return cfail(c, DSMI_ERR_CAPACITY, "shard_cap smaller than this rank's share of the clips");
-    for (int j = 0; j < mine; ++j) {
-        const int i = order[(size_t)(c->rank + j * c->world)];
-        shard_index[j] = i; shard_n_samples[j] = lens[(size_t)i];
+    if (!late_rc && mine > shard_cap) { late_rc = DSMI_ERR_CAPACITY; late_msg = "shard_cap smaller than this rank's share of the clips"; }
+    if (!late_rc) {
+        for (int j = 0; j < mine; ++j) {
+            const int i = order[(size_t)(c->rank + j * c->world)];
+            shard_index[j] = i; shard_n_samples[j] = lens[(size_t)i];
+        }
+        *shard_count = mine;
     }
-    *shard_count = mine;
 
     // 4. payloads: the root stages every rank's shard back to back, uploads once and sends each rank its slice
     size_t my_off = 0, all = 0;
@@ -256,6 +256,7 @@ extern "C" int dsmi_comm_scatter(dsmi_comm* c, int root, const void* const* clip
         }
     }
     COMM_HIP(c, hipStreamSynchronize(s));                     // the staging buffer is free again; the shard is in place
+    if (late_rc) return cfail(c, late_rc, late_msg);
     *shard_pcm_dev = c->dev ? c->dev + my_off : nullptr;
     return DSMI_OK;
 }

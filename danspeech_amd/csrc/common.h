@@ -179,17 +179,9 @@ std::vector<uint16_t> pack_whh16(const RnnGeom& g16, const float* w_hh);
 size_t rnn_persist16_state_halfs(const RnnGeom& g16, int B);
 bool launch_rnn_persist16(const RnnPersist16Launch& p, hipStream_t s);
 
-// rnn_persist32.hip: throughput variant -- 32 units per workgroup, one workgroup per CU, a 32-clip batch on 100 CUs (cfgA);
-// takes a RnnPersist16Launch whose geometry is make_rnn_geom_u(kind, H, D, 32) and whose whh16 point at pack_whh32 images.
-bool rnn_persist32_eligible(const RnnGeom& g32, int B, int n_cus, int* pgroups_out);
-std::vector<uint16_t> pack_whh32(const RnnGeom& g32, const float* w_hh);
-bool launch_rnn_persist32(const RnnPersist16Launch& p, hipStream_t s);
-
 // rnn_persist_duo.hip: one workgroup carries the two 16-clip tiles of a batch in a fixed four-slot pipeline (a 32-clip
 // batch of cfgA on 100 CUs); same packed weights, x-projection order and state layout as rnn_persist16.hip.
 bool rnn_persist_duo_eligible(const RnnGeom& g16, int B, int n_cus);
-bool rnn_persist_quad_eligible(const RnnGeom& g16, int B, int n_cus);
-bool launch_rnn_persist_quad(const RnnPersist16Launch& p, hipStream_t s);
 bool launch_rnn_persist_duo(const RnnPersist16Launch& p, hipStream_t s);
 
 // head.hip

@@ -10,6 +10,7 @@
 // real/imaginary parts are rounded to float32, then hypotf and log1pf.
 // Mean and unbiased std are accumulated in float64 per clip (two passes, fixed order).
 #include "common.h"
+#include "host_logic.h"
 
 #include <cmath>
 #include <cstring>
@@ -358,33 +359,8 @@ extern "C" int dsmi_segment(dsmi_frontend* f, const void* pcm, int dtype, int64_
     (void)hipFree(e_dev);
     if (!ok) return bad(DSMI_ERR_HIP, "hop energy kernel failed");
     if (energies_host) std::copy(e.begin(), e.end(), energies_host);
-    // ---- the script's state machine (:84-143), one pass over the hop energies
-    bool is_speaking = false;
-    int64_t frames_counter = 0, pause_count = 0, start_index = 0, iterator = 0;
-    int found = 0;
-    for (int64_t i = 0; i < nhops; ++i) {
-        const double energy = e[i];
-        if (energy > energy_threshold && !is_speaking) {
-            is_speaking = true;
-            start_index = iterator - 2 * (int64_t)step;
-            if (start_index < 0) start_index = iterator;
-        }
-        iterator += step;
-        if (is_speaking) {
-            ++frames_counter;
-            if (energy > energy_threshold) pause_count = 0;
-            else ++pause_count;
-        }
-        if (pause_count > pause_hops && is_speaking) {
-            if (frames_counter - pause_count > phrase_hops) {
-                if (found < max_segments) { seg_start[found] = start_index; seg_end[found] = iterator; }
-                ++found;
-            }
-            is_speaking = false;
-            frames_counter = 0;
-            pause_count = 0;
-        }
-    }
+    // ---- the script's state machine (:84-143), one pass over the hop energies (host_logic.h)
+    const int found = dsmi::segment_phrases(e.data(), nhops, step, energy_threshold, pause_hops, phrase_hops, seg_start, seg_end, max_segments);
     *n_segments = found;
     if (found > max_segments) return bad(DSMI_ERR_CAPACITY, "more phrases than max_segments");
     return DSMI_OK;

@@ -392,154 +392,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmSplitArgs p, con
     }
 }
 
-// Pass 2, wide variant (opt-in, DSMI_GEMM_TILE=256; measured SLOWER than the kernel above, kept as the record of the experiment):
-// the same arithmetic on a 256 x 128 output tile per workgroup (8 waves in 4 x 2, each 64 x 64 as above) with THREE LDS stages of
-// 48 KiB, one workgroup per CU.  Counters on the two-stage kernel (profiles/r02e): 35 % of the wave
-// cycles are parked at the per-k-tile `s_waitcnt vmcnt(0)` + barrier -- the DMA of tile kt+1 is requested at the top of
-// iteration kt and has one iteration (24 MFMAs per wave) to land.  Here tile kt+2 is requested at the top of iteration kt and
-// the wait at its end is `vmcnt(6)`: only tile kt+1, requested a whole iteration earlier, must have landed.  The W tile is
-// shared by twice as many rows (a third less DMA traffic per MFMA).  Result: 0.44 ms against 0.40 ms for the layer >= 1 GEMM,
-// 0.65 against 0.59 for layer 0 -- with one workgroup per CU all eight waves meet every barrier together and nothing else is
-// resident to run meanwhile; two independent 4-wave workgroups per CU hide each other's barriers better than a third stage
-// hides the DMA.
-constexpr int WSTAGE = 49152;          // bytes per stage: A 2 planes x 256 rows x 64 B, W 2 planes x 128 rows x 64 B
 
-template <bool CONV_ROWS>
-__global__ __launch_bounds__(512, 2) void gemm_f16x3_wide_kernel(GemmSplitArgs p, const uint16_t* a_sp) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smemw[];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wr = wid >> 1, wc = wid & 1;                 // 4 x 2 waves
-    const int li = lane & 31, hk = lane >> 5;
-    int nt, mt2;
-    {
-        const int ntiles = p.ntiles, mtiles = (p.mtiles + 1) / 2, total = ntiles * mtiles;
-        const int share = (total + 7) / 8;
-        const int idx = (blockIdx.x & 7) * share + (blockIdx.x >> 3);
-        if ((int)(blockIdx.x >> 3) >= share || idx >= total) return;
-        constexpr int PN = 8;
-        const int panel = idx / (PN * mtiles), rem = idx - panel * (PN * mtiles);
-        const int pw = min(PN, ntiles - panel * PN);
-        mt2 = rem / pw; nt = panel * PN + (rem - mt2 * pw);
-    }
-    const int n0 = nt * BN;
-    const int mt = 2 * mt2 + (wr >> 1);                    // this wave's 128-row tile of the pair
-    const bool mt_ok = mt < p.mtiles;
-    int m0 = mt * BM, bb = 0, t0 = 0;
-    if (CONV_ROWS) { bb = mt / p.tiles_per_b; t0 = (mt % p.tiles_per_b) * BM; }
-
-    const unsigned char* abase = reinterpret_cast<const unsigned char*>(a_sp);
-    const unsigned char* wtile = reinterpret_cast<const unsigned char*>(p.w_sp) + (size_t)nt * p.ktiles * 16384;
-    unsigned char* lds = smemw;
-    const int drow = lane >> 2, dchunk = (lane & 3) ^ ((lane >> 4) & 3);
-    auto dma = [&](int kt, int stage) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int j = wid * 6 + i;                     // 1-KiB block 0..47: 32 of A (plane j >> 4, 16-row block j & 15), 16 of W
-            const unsigned char* src;
-            unsigned dst;
-            if (j < 32) {
-                const int pl = j >> 4, rb = j & 15;
-                const int mtile = min(2 * mt2 + (rb >> 3), p.mtiles - 1);          // an odd tile count: the missing half re-reads the last tile
-                src = abase + ((size_t)mtile * p.ktiles + kt) * 16384 + pl * 8192 + (16 * (rb & 7) + drow) * 64 + dchunk * 16;
-                dst = pl * 16384 + rb * 1024;
-            } else {
-                const int jj = j - 32, pl = jj >> 3, rb = jj & 7;
-                src = wtile + (size_t)kt * 16384 + pl * 8192 + (16 * rb + drow) * 64 + dchunk * 16;
-                dst = 32768 + pl * 8192 + rb * 1024;
-            }
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(lds + stage * WSTAGE + dst), 16, 0, 0);
-        }
-    };
-    f16x8 af[2][2][2], wf[2][2][2];      // [buffer][tile][plane]
-    auto read_frags = [&](int buf, int stage, int ks) {
-        const unsigned char* st = lds + stage * WSTAGE;
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl) {
-                const int ra_ = wr * 64 + mi * 32 + li, rw_ = wc * 64 + mi * 32 + li;
-                af[buf][mi][pl] = *reinterpret_cast<const f16x8*>(st + pl * 16384 + ra_ * 64 + (((ks * 2 + hk) ^ ((ra_ >> 2) & 3)) * 16));
-                wf[buf][mi][pl] = *reinterpret_cast<const f16x8*>(st + 32768 + pl * 8192 + rw_ * 64 + (((ks * 2 + hk) ^ ((rw_ >> 2) & 3)) * 16));
-            }
-    };
-
-    f32x16 acc[2][2], acl[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; acl[i][j][r] = 0.f; }
-
-    dma(0, 0);
-    if (p.ktiles > 1) {
-        dma(1, 1);
-        asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");       // tile 0 has landed, tile 1 may still be on its way
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    }
-    read_frags(0, 0, 0);
-    int stage = 0;
-    for (int kt = 0; kt < p.ktiles; ++kt) {
-        const int s2 = stage >= 1 ? stage - 1 : 2;             // (stage + 2) % 3: last read in iteration kt - 1
-        if (kt + 2 < p.ktiles) dma(kt + 2, s2);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            if (ks == 0) read_frags(1, stage, 1);
-            const int cb = ks;
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-                    acl[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cb][mi][1], wf[cb][ni][0], acl[mi][ni], 0, 0, 0);
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cb][mi][0], wf[cb][ni][0], acc[mi][ni], 0, 0, 0);
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-                    acl[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cb][mi][0], wf[cb][ni][1], acl[mi][ni], 0, 0, 0);
-        }
-        // tile kt+1 (requested one iteration ago) must have landed; tile kt+2's six requests stay in flight ACROSS the barrier:
-        // a bare s_barrier, because __syncthreads() carries a workgroup release fence that hipcc lowers to vmcnt(0) in front
-        // of the barrier -- it would wait for the tile just requested and undo the third stage.  What the barrier has to order
-        // is spelled out: this wave's share of tile kt+1 has landed (vmcnt), its fragment reads of this stage have returned
-        // (lgkmcnt: the stage is overwritten by the DMA of the next iteration).
-        if (kt + 2 < p.ktiles) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        stage = stage == 2 ? 0 : stage + 1;
-        if (kt + 1 < p.ktiles) read_frags(0, stage, 0);
-    }
-
-    if (!mt_ok) return;
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int n = n0 + wc * 64 + ni * 32 + li;
-        if (n >= p.N) continue;
-        const float bv = p.bias ? p.bias[n] : 0.f;
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int i = (wr & 1) * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hk;
-                size_t crow;
-                if (CONV_ROWS) {
-                    const int t = t0 + i;
-                    if (t >= p.T) continue;
-                    crow = (size_t)t * p.B + bb;
-                } else {
-                    if (m0 + i >= p.M) continue;
-                    crow = (size_t)(m0 + i);
-                }
-                p.c[crow * p.ldc + n] = acc[mi][ni][r] + acl[mi][ni][r] * kLoInv + bv;
-            }
-        }
-    }
-}
 
 static inline uint16_t g_f16_bits(_Float16 h) {
     uint16_t u;
@@ -582,17 +435,6 @@ void launch_gemm(const GemmLaunch& g, hipStream_t s) {
         const size_t lds3 = (size_t)2 * 32768;          // two stages of four 8-KiB operand planes
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
-        // DSMI_GEMM_TILE=256: the wide three-stage variant (measured slower, 0.44 vs 0.40 ms: DESIGN.md 4); default 128 x 128
-        static const bool wide = std::getenv("DSMI_GEMM_TILE") && std::atoi(std::getenv("DSMI_GEMM_TILE")) == 256;
-        if (wide) {
-            const dim3 gridw(8 * ceil_div(a.ntiles * ceil_div(a.mtiles, 2), 8));
-            const size_t ldsw = (size_t)3 * WSTAGE;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x3_wide_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x3_wide_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);
-            if (g.mode == GEMM_A_CONV) DSMI_LAUNCH(gemm_f16x3_wide_kernel<true>, gridw, dim3(512), ldsw, s, g.ev, a, (const uint16_t*)g.a_sp);
-            else DSMI_LAUNCH(gemm_f16x3_wide_kernel<false>, gridw, dim3(512), ldsw, s, g.ev, a, (const uint16_t*)g.a_sp);
-            return;
-        }
         if (g.mode == GEMM_A_CONV) DSMI_LAUNCH(gemm_f16x3_kernel<true>, grid3, dim3(256), lds3, s, g.ev, a, (const uint16_t*)g.a_sp);
         else DSMI_LAUNCH(gemm_f16x3_kernel<false>, grid3, dim3(256), lds3, s, g.ev, a, (const uint16_t*)g.a_sp);
         return;

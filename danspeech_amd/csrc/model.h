@@ -18,8 +18,6 @@ struct RnnW {
     float* bhh[2] = {nullptr, nullptr};  // torch layout [G*H]
     // the same x-projection weights permuted for the 16-unit geometry of rnn_persist16.hip (H % 16 == 0 only)
     uint16_t* wih16_sp = nullptr; float* bih16 = nullptr; uint16_t* whh16_sp[2] = {nullptr, nullptr};
-    // ... and for the 32-unit geometry of rnn_persist32.hip (H % 32 == 0 only)
-    uint16_t* wih32_sp = nullptr; float* bih32 = nullptr; uint16_t* whh32_sp[2] = {nullptr, nullptr};
     float* bn_a = nullptr;  // [Hs] BatchNorm1d in front of layers >= 1
     float* bn_b = nullptr;
     int K = 0, ldw = 0;
@@ -52,8 +50,6 @@ struct dsmi_model {
     dsmi::RnnGeom geom{};
     dsmi::RnnGeom geom16{};       // U = 16 geometry of the second-generation persistent kernel
     bool have16 = false;          // geom16 weights were packed (H % 16 == 0)
-    dsmi::RnnGeom geom32{};       // U = 32 geometry of the throughput variant (rnn_persist32.hip)
-    bool have32 = false;          // geom32 weights were packed (H % 32 == 0, shape within the kernel's register budget)
     int inflight = 1;             // dsmi_model_set_inflight: batches the caller keeps in flight on this device (2: throughput variant)
 
     // weights (device)
@@ -91,18 +87,14 @@ struct dsmi_model {
     int recomputed = 0;            // forwards recomputed on the per-step path so far
     unsigned spin_limit = dsmi::kPersistSpinLimit;   // DSMI_DEBUG_SPIN_LIMIT
     int drop_layer = -1, drop_wg = -1, drop_step = -1;   // DSMI_DEBUG_DROP_SIGNAL=layer:workgroup:step (tests: force a timeout)
-    int persist_quad = -1;         // DSMI_PERSIST_QUAD=1: the four-chain kernel (rnn_persist_quad.hip) where the shape allows it; opt-in, measured slower
-    int persist_duo = -1;          // DSMI_PERSIST_DUO=1/0: always / never the paired-tile kernel (rnn_persist_duo.hip); -1: when two batches are in flight
-    int persist_units = 0;         // DSMI_PERSIST_UNITS (16: never the 32-unit kernel)
-    int persist_waves = 0;         // DSMI_PERSIST_WAVES=4/8 forces half-CU / whole-CU workgroups of rnn_persist16; 0: by the batches in flight
-    int lanes = 1, lane = 0;       // DSMI_PERSIST_LANES: persistent kernels of this handle take 1/lanes of the CUs, on this lane
+    int lanes = 2, lane = 0;       // persistent kernels of a handle whose caller keeps two batches in flight take half of the CUs, on this lane
     int persist_lock_fd = -1;      // this process holds the device's persistent-kernel lock file
     // pinned staging of the per-batch lengths (pageable memory must not back an async copy)
     static constexpr int kStage = 4;
     int32_t* lens_stage = nullptr; int stage_cap = 0, stage_next = 0;
     hipEvent_t stage_ev[kStage] = {nullptr, nullptr, nullptr, nullptr}; bool stage_used[kStage] = {false, false, false, false};
     int n_cus = 0;
-    bool conv1_split = true;      // first conv layer on the split-fp16 MFMA (conv1_split.hip); DSMI_CONV1_MODE=f32: conv.hip
+    bool conv1_split = true;      // first conv layer on the split-fp16 MFMA (conv1_split.hip); DSMI_DENSE_MODE=f32: conv.hip
     int conv_mode = 1;            // 1: split-fp16 conv for the 32-input-channel layers, 0: fp32 MFMA conv
     int gemm_mode = 1;            // 1: split-fp16 GEMM, 0: fp32 MFMA GEMM
     int rnn_mode = 1;             // 1: persistent layer kernel when eligible, 0: one launch per step

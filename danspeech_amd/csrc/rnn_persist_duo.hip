@@ -307,7 +307,7 @@ bool launch_duo(const DuoArgs& a, hipStream_t s, const EvPair& ev) {
     const int nkw = ceil_div(a.nkb, 4);
     constexpr int NGk = KIND == DSMI_RNN_GRU ? 3 : (KIND == DSMI_RNN_LSTM ? 4 : 1);
     const int kq = a.nkb / 4, kr = a.nkb % 4;
-    const bool tail = kr > 0 && NGk * kr <= 4 && kq >= 1 && kq <= (KIND == DSMI_RNN_LSTM ? 4 : 6) && !getenv("DSMI_DUO_NOTAIL");
+    const bool tail = kr > 0 && NGk * kr <= 4 && kq >= 1 && kq <= (KIND == DSMI_RNN_LSTM ? 4 : 6);
     const dim3 grid(a.nwg, a.D * ((a.ntiles + 1) / 2), 1), block(DNT);
     if (a.dbg) {
         if (KIND != DSMI_RNN_GRU || nkw != 7) return false;

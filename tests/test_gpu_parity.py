@@ -273,8 +273,7 @@ def test_step_path_and_persistent_path_agree(native, monkeypatch):
     m1 = native.NativeModel(cfg, sd)
     p1, _ = m1.forward(_dev(x), lens)
     monkeypatch.setenv("DSMI_RNN_MODE", "steps")
-    monkeypatch.setenv("DSMI_GEMM_MODE", "f32")
-    monkeypatch.setenv("DSMI_CONV_MODE", "f32")
+    monkeypatch.setenv("DSMI_DENSE_MODE", "f32")
     m2 = native.NativeModel(cfg, sd)
     p2, _ = m2.forward(_dev(x), lens)
     np.testing.assert_allclose(p1.cpu().numpy(), p2.cpu().numpy(), rtol=0, atol=2e-5)

@@ -187,25 +187,22 @@ def test_tiny_weights_and_saturating_gates(native, kind):
     m.close(); m1.close()
 
 
-@pytest.mark.parametrize("waves", ["duo", "4", "8", "units32"])
-def test_two_batches_in_flight_on_two_handles(native, waves):
-    """Two handles, two streams, forwards enqueued back to back without waiting: with the half-CU workgroups (waves = 4)
-    the persistent kernels of the two batches are co-resident on the same CUs (one gate lane each); with whole-CU
-    workgroups (waves = 8) the gate chains them; with set_inflight(2) the 32-unit kernel puts each batch on its own half
-    of the chip.  Either way both batches must equal the oracle, repeatedly."""
+@pytest.mark.parametrize("variant", ["paired", "half", "whole"])
+def test_two_batches_in_flight_on_two_handles(native, variant):
+    """Two handles, two streams, forwards enqueued back to back without waiting.  The kernel variant follows from what the
+    caller says (set_inflight) and the batch: two batches in flight of 17+ clips -> the paired-tile kernel, each batch on its
+    own half of the chip; of at most 16 clips -> half-CU workgroups, the two batches' kernels co-resident on the same CUs;
+    one batch in flight -> whole-CU workgroups, which the gate chains.  Either way both batches must equal the oracle,
+    repeatedly."""
     from oracle import torch_port as tp
     cfg = _cfg(800, 2)
     sd = syn.make_state_dict(2, "gru", 800, 2, seed=31, **syn.TALKATIVE)
-    env = dict(DSMI_PERSIST_DUO="1") if waves == "duo" else dict(DSMI_PERSIST_DUO="0", DSMI_PERSIST_WAVES="4" if waves == "units32" else waves)
-    if waves == "units32":
-        env["DSMI_PERSIST_UNITS"] = "32"
-    with _env(**env):
-        models = [native.NativeModel(cfg, sd) for _ in range(2)]
-    if waves == "units32":
-        for m in models:
-            m.set_inflight(2)
+    models = [native.NativeModel(cfg, sd) for _ in range(2)]
+    for m in models:
+        m.set_inflight(1 if variant == "whole" else 2)
     streams = [torch.cuda.Stream() for _ in range(2)]
-    batches = [_batch(B=32, T=301, seed=40), _batch(B=20, T=257, seed=41)]
+    batches = [_batch(B=16, T=301, seed=40), _batch(B=11, T=257, seed=41)] if variant == "half" else \
+        [_batch(B=32, T=301, seed=40), _batch(B=20, T=257, seed=41)]
     refs = [tp.forward(sd, cfg, x, lens)[0] for x, lens in batches]
     xs = [_dev(x) for x, _ in batches]
     torch.cuda.synchronize()
@@ -225,45 +222,20 @@ def test_two_batches_in_flight_on_two_handles(native, waves):
         m.close()
 
 
-@pytest.mark.parametrize("kind,H,B", [("gru", 800, 32), ("gru", 64, 40), ("lstm", 512, 16), ("rnn", 96, 70), ("gru", 896, 24)])
-def test_throughput_variant_32_units_equals_oracle(native, kind, H, B):
-    """rnn_persist32 (selected by set_inflight(2)) on its own: all cell types, one tile / several tiles per workgroup,
-    the seven-k-block shape (H = 896: one k-block of W_hh in LDS), ragged lengths."""
-    from oracle import torch_port as tp
-    cfg = _cfg(H, 2, kind=kind)
-    sd = syn.make_state_dict(2, kind, H, 2, seed=51, **syn.TALKATIVE)
-    with _env(DSMI_PERSIST_UNITS="32"):
-        m = native.NativeModel(cfg, sd)
-    m.set_inflight(2)
-    x, lens = _batch(B=B, T=201, seed=52)
-    p, ol = m.forward(_dev(x), lens)
-    ref, ol_ref = tp.forward(sd, cfg, x, lens)
-    assert np.array_equal(ol, ol_ref) and m.recompute_count() == 0
-    pn = p.cpu().numpy()
-    for b in range(B):
-        np.testing.assert_allclose(pn[b, :ol[b]], ref[b, :ol[b]], rtol=0, atol=1e-4)
-    # and the same batch through the default (latency) variant: same probabilities up to summation order
-    m.set_inflight(1)
-    p1, _ = m.forward(_dev(x), lens)
-    for b in range(B):
-        np.testing.assert_allclose(p1.cpu().numpy()[b, :ol[b]], pn[b, :ol[b]], rtol=0, atol=5e-5)
-    m.close()
-
-
 @pytest.mark.parametrize("kind,H,B", [("gru", 800, 32), ("gru", 64, 17), ("lstm", 512, 48), ("rnn", 96, 64), ("gru", 896, 40), ("lstm", 64, 32)])
 def test_paired_tile_kernel_equals_oracle_and_the_single_tile_kernels(native, kind, H, B):
     """rnn_persist_duo (the default for 17+ clips when the shape fits): all cell types, one pair / two pairs of tiles, an odd
     tile count (the last half B idle), a partial last tile, the seven-k-block shape, ragged lengths -- against the oracle
-    and against the same batch through rnn_persist16 (DSMI_PERSIST_DUO=0)."""
+    and against the same batch through rnn_persist16 (one batch in flight: whole-CU workgroups)."""
     from oracle import torch_port as tp
     cfg = _cfg(H, 2, kind=kind)
     sd = syn.make_state_dict(2, kind, H, 2, seed=61, **syn.TALKATIVE)
     x, lens = _batch(B=B, T=181, seed=62)
     ref, ol_ref = tp.forward(sd, cfg, x, lens)
     outs = []
-    for duo in ("1", "0"):
-        with _env(DSMI_PERSIST_DUO=duo):
-            m = native.NativeModel(cfg, sd)
+    for inflight in (2, 1):
+        m = native.NativeModel(cfg, sd)
+        m.set_inflight(inflight)
         p, ol = m.forward(_dev(x), lens)
         assert np.array_equal(ol, ol_ref) and m.recompute_count() == 0
         outs.append(p.cpu().numpy())
@@ -273,32 +245,13 @@ def test_paired_tile_kernel_equals_oracle_and_the_single_tile_kernels(native, ki
         np.testing.assert_allclose(outs[0][b, :ol_ref[b]], outs[1][b, :ol_ref[b]], rtol=0, atol=5e-5)
 
 
-@pytest.mark.parametrize("kind,H,B", [("gru", 800, 32), ("gru", 64, 17), ("lstm", 512, 48), ("rnn", 96, 64), ("gru", 896, 40)])
-def test_four_chain_kernel_equals_oracle(native, kind, H, B):
-    """rnn_persist_quad (opt-in, DSMI_PERSIST_QUAD=1): both directions of two tiles per workgroup -- all cell types, one
-    and two tile pairs, an odd tile count, a partial last tile, the left-over-block and the seven-k-block shapes."""
-    from oracle import torch_port as tp
-    cfg = _cfg(H, 2, kind=kind)
-    sd = syn.make_state_dict(2, kind, H, 2, seed=71, **syn.TALKATIVE)
-    x, lens = _batch(B=B, T=181, seed=72)
-    ref, ol_ref = tp.forward(sd, cfg, x, lens)
-    with _env(DSMI_PERSIST_QUAD="1"):
-        m = native.NativeModel(cfg, sd)
-    p, ol = m.forward(_dev(x), lens)
-    assert np.array_equal(ol, ol_ref) and m.recompute_count() == 0
-    pn = p.cpu().numpy()
-    for b in range(B):
-        np.testing.assert_allclose(pn[b, :ol_ref[b]], ref[b, :ol_ref[b]], rtol=0, atol=1e-4)
-    m.close()
-
-
 def test_paired_tile_kernel_timeout_is_recomputed(native):
     from oracle import torch_port as tp
     cfg = _cfg(64, 2)
     sd = syn.make_state_dict(2, "gru", 64, 2, seed=63, **syn.TALKATIVE)
     x, lens = _batch(B=24, T=161, seed=64)
     ref, _ = tp.forward(sd, cfg, x, lens)
-    with _env(DSMI_DEBUG_DROP_SIGNAL="1:2:9", DSMI_DEBUG_SPIN_LIMIT="3000", DSMI_PERSIST_DUO="1"):
+    with _env(DSMI_DEBUG_DROP_SIGNAL="1:2:9", DSMI_DEBUG_SPIN_LIMIT="3000"):
         m = native.NativeModel(cfg, sd)
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")

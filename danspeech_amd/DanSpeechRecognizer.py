@@ -219,7 +219,7 @@ class DanSpeechRecognizer(object):
         # Depth of the pipeline.  Greedy decoding is a short host-synchronous step: two batches in flight.  A beam search is a
         # kernel of its own that starts when its forward ends: with two batches in flight the host would wait for batch b's
         # search before it enqueues b + 2, and only ONE forward would be running meanwhile; with three (two forwards and the
-        # oldest batch's search) the GPU always has two forwards (config 3: 13.1 -> ms per batch, tools/run_configs.py).
+        # oldest batch's search) the GPU always has two forwards (config 3: 13.1 -> 9.9 ms per batch, tools/run_configs.py).
         import collections
         searching = hasattr(self.decoder, "decode_enqueue")
         depth = 3 if searching else 2

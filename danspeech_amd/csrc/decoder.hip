@@ -1,23 +1,13 @@
-// Decoders on the GPU (gfx950): the handle behind dsmi_decoder*, greedy decode, and CTC prefix
-// beam search with an optional word-level n-gram scorer.
+// Decoders on the GPU (gfx950): the handle behind dsmi_decoder*, greedy decode, and the launcher / collector of the CTC
+// prefix beam search with an optional word-level n-gram scorer (the search kernel itself: beam_kernel.inc).
 //
 // Replaces GreedyDecoder.decode and BeamCTCDecoder.decode of the reference
 // (danspeech/deepspeech/decoder.py:183-198, 129-144).  The reference's beam search is the
 // un-vendored third-party ctcdecode (C++, thread pool over the batch); here one workgroup
 // decodes one utterance, the batch runs in parallel across CUs, and nothing leaves the GPU
-// until the final beams.  Algorithm and the deliberate float64 carry: see oracle/beam.py,
-// which restates the same published algorithm and is what the parity tests compare with.
-//
-// Per frame, for one utterance (256 threads):
-//   1. log p(c) = log(p + FLT_MIN), vocabulary pruning (cutoff_prob / cutoff_top_n);
-//   2. every (beam entry, character) pair in parallel: blank / repeat contributions go to the
-//      entry, an extension looks its child up in the utterance's prefix-trie hash table,
-//      checks the dictionary trie, adds alpha * ln P_lm + beta on the space character, and
-//      becomes a candidate (or feeds an entry already in the beam);
-//   3. exact top-`beam` of the candidates by (score desc, last character asc) with an 8-pass
-//      radix select on the order-preserving bits of the float64 score;
-//   4. survivors are committed (new trie nodes, hash insert), the rest are unlinked with the
-//      reference's "remove" semantics so that emission timesteps behave the same.
+// until the final beams.  Algorithm and the deliberate float64 carry: oracle/beam.py restates ctcdecode's published
+// algorithm, oracle/beam_flat.py the kernel's own formulation of it (implicit prefix trie held on chip, edge tuples, one-pass
+// histogram selection); the parity tests compare with both.  DESIGN.md 4 "Beam search" describes the frame's six phases.
 #include "common.h"
 #include "lm.h"
 #include "lm.cpp.inc"

@@ -67,6 +67,27 @@ def test_recognize_batch_equals_single_and_oracle():
     assert rec.recognize_batch([]) == []
 
 
+def test_device_resident_clips_equal_host_arrays():
+    """DeviceClips (clips back to back in GPU memory, longest first): the same results as the same clips handed over as host
+    arrays, through recognize_batch and the pipelined recognize_batches; the order rule is enforced."""
+    from danspeech_amd import Recognizer
+    from danspeech_amd.audio.parsers import DeviceClips
+    model, sd, cfg = _model("small", 64, 3, seed=12)
+    rec = Recognizer(model=model)
+    clips = [syn.make_clip(i, n) for i, n in enumerate([40000, 40000, 23456, 16000, 8000])]
+    want = rec.recognize_batch(clips)
+    n = np.array([len(c) for c in clips], dtype=np.int64)
+    for dtype in (np.float64, np.int16):
+        pcm = torch.from_numpy(np.concatenate(clips).astype(dtype)).cuda()
+        dc = DeviceClips(pcm, n)
+        assert rec.recognize_batch(dc) == want
+        assert list(rec.recognize_batches([dc, dc.part(1, 4), dc])) == [want, want[1:4], want]
+    with pytest.raises(ValueError):
+        DeviceClips(pcm, n[::-1].copy())
+    with pytest.raises(ValueError):
+        DeviceClips(pcm[:-1], n)
+
+
 def test_config3_beam_with_lm_through_recognizer(tmp_path, capsys):
     """cfgA (2 conv, 5 x BiGRU 800) + synthetic 3-gram, alpha=1.3 beta=0.2 beam=64 (engine defaults)."""
     from danspeech_amd import Recognizer

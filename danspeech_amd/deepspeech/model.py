@@ -194,8 +194,18 @@ class DeepSpeech(object):
     # ---- packages (reference model.py:599-650) --------------------------------------------------
     @classmethod
     def load_model(cls, path):
+        import pickle
         import torch
-        package = torch.load(path, map_location="cpu", weights_only=True)     # plain dicts / lists / tensors: nothing to unpickle
+        try:
+            # plain dicts / lists / tensors (what the reference's own packages hold, model.py:607-619): nothing to unpickle
+            package = torch.load(path, map_location="cpu", weights_only=True)
+        except pickle.UnpicklingError as e:
+            # The reference loads with a full unpickle (model.py:607), which runs whatever code the file names.  A package that
+            # needs that is not loaded silently: the caller decides, and hands the unpickled dict to load_model_package().
+            raise RuntimeError(
+                "%s holds objects beyond tensors, dicts, lists and scalars (%s). danspeech_amd does not unpickle arbitrary objects "
+                "from a model file; if you trust this file, load it yourself -- package = torch.load(path, map_location='cpu', "
+                "weights_only=False) -- and pass the dict to DeepSpeech.load_model_package(package)" % (path, str(e).splitlines()[0])) from e
         return cls.load_model_package(package)
 
     @classmethod

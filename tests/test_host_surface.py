@@ -151,6 +151,27 @@ def test_model_package_roundtrip(tmp_path):
     assert CustomModel(path).model_name == "pkg"
 
 
+class _NotATensor(object):
+    pass
+
+
+def test_model_package_with_foreign_objects_is_refused_with_instructions(tmp_path):
+    """A .pth that needs a full unpickle is not loaded silently (the reference's torch.load would run it): the error says what
+    to do, and the explicit route works."""
+    import torch
+    from danspeech_amd.deepspeech.model import DeepSpeech
+    sd = syn.make_state_dict(2, "gru", 16, 1, seed=2)
+    m = DeepSpeech("pkg", rnn_hidden_size=16, rnn_layers=1).load_state_dict(sd)
+    package = m.serialize()
+    package["extra"] = _NotATensor()
+    path = str(tmp_path / "odd.pth")
+    torch.save(package, path)
+    with pytest.raises(RuntimeError, match="load_model_package"):
+        DeepSpeech.load_model(path)
+    m2 = DeepSpeech.load_model_package(torch.load(path, map_location="cpu", weights_only=False))
+    assert m2.model_name == "pkg" and m2.rnn_hidden_size == 16
+
+
 def test_decoder_base_helpers():
     from danspeech_amd.deepspeech.decoder import Decoder
     d = Decoder("_ab ")

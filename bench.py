@@ -218,14 +218,23 @@ def main(argv=None):
         all_clips = None
     pcm = parallel.scatter_clips(all_clips, B, n_samples, rank, world, dev, dtype=np.int16).to(torch.float64)
     clips = DeviceClips(pcm.view(-1), np.full(B, n_samples, dtype=np.int64))
-    cap = n_samples // 160 + 1                       # a transcript is never longer than the frame count
+    cap = max((n_samples // 160 + 1 + 1) // 2, 16)   # a transcript is never longer than the OUTPUT frame count (time stride 2)
     positions = np.arange(rank * B, (rank + 1) * B)
+
+    # the gather gets a stream of its own: RCCL orders a collective behind everything already queued on the stream it is issued
+    # from, and the pipeline's first stream always holds a forward that was enqueued ahead (8 ms of somebody else's work)
+    import contextlib
+    gather_stream = torch.cuda.Stream(device=local) if (world > 1 and not dry) else None
 
     def run(steps):
         """`steps` batches through recognize_batches; the transcripts of every step gathered to rank 0."""
         out = None
         for res in rec.recognize_batches(clips for _ in range(steps)):
-            out = parallel.gather_texts(res, positions, B * world, cap, rank, world, dev) if world > 1 else res
+            if world > 1:
+                with (torch.cuda.stream(gather_stream) if gather_stream is not None else contextlib.nullcontext()):
+                    out = parallel.gather_texts(res, positions, B * world, cap, rank, world, dev)
+            else:
+                out = res
         return out
 
     def sync():

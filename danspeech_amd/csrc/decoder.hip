@@ -177,7 +177,7 @@ extern "C" int dsmi_beam_enqueue(dsmi_decoder* d, const float* probs, const int3
     // scorer is set, the other threads `per` (entry, label) pairs each
     const int EW = (beam + 63) / 64, RW = d->has_lm ? 2 * EW : EW;
     const size_t per = BT > 64 * RW ? ((size_t)beam * C + (BT - 64 * RW) - 1) / (BT - 64 * RW) : ~(size_t)0;
-    if (lds > 160 * 1024 - 256 || per > 12 || C > MAXC) { d->err = "beam_width * (n_labels + 1) exceeds the on-chip candidate buffer"; return DSMI_ERR_CAPACITY; }
+    if (lds > 160 * 1024 - 256 || per > 24 || C > MAXC) { d->err = "beam_width * (n_labels + 1) exceeds the on-chip candidate buffer"; return DSMI_ERR_CAPACITY; }
     DEC_HIP(d, hipSetDevice(d->device));
     hipStream_t s = (hipStream_t)stream;
     // ---- workspace carve
@@ -246,7 +246,8 @@ extern "C" int dsmi_beam_enqueue(dsmi_decoder* d, const float* probs, const int3
     };
     if (per <= 3) DEC_HIP(d, launch(beam_kernel<1024, 3>));
     else if (per <= 6) DEC_HIP(d, launch(beam_kernel<1024, 6>));
-    else DEC_HIP(d, launch(beam_kernel<1024, 12>));
+    else if (per <= 12) DEC_HIP(d, launch(beam_kernel<1024, 12>));
+    else DEC_HIP(d, launch(beam_kernel<1024, 24>));      // beams beyond ~170 with a scorer: correct, not tuned (registers spill)
     DEC_HIP(d, hipGetLastError());
     // Only the kernel is queued here.  A device-to-host copy queued behind it would sit in a DMA queue until the search is
     // over, and with it whatever upload another stream has been given the same engine for -- the next batch's samples: its

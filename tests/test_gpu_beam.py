@@ -128,6 +128,23 @@ def test_beam_with_lm_wide_beam_5gram(native, tmp_path):
     _compare(native, probs, None, labels, beam=128, lm_path=path, alpha=1.2, beta=0.15, n_check=40)
 
 
+def test_beam_wide_beams_and_capacity(native, tmp_path):
+    """Beams beyond 128 (more pairs per thread: the kernel's largest instantiation) against the oracle, and the documented
+    refusal where the on-chip buffers end."""
+    labels = syn.DANSPEECH_LABELS
+    path = str(tmp_path / "toy3.arpa")
+    syn.make_arpa(path, order=3, n_words=200, seed=5, ngrams_per_order=600)
+    rng = np.random.default_rng(8)
+    probs = _peaky_probs(rng, 2, 30, len(labels), sharp=1.0)
+    _compare(native, probs, np.array([30, 19], dtype=np.int32), labels, beam=200, lm_path=path, alpha=1.3, beta=0.2, n_check=30)
+    _compare(native, probs, None, labels, beam=160, n_check=30)
+    dec = native.NativeDecoder(labels, blank_index=0)
+    with pytest.raises(native.DsmiError) as e:
+        dec.beam(_dev(probs), None, beam_width=400)
+    assert e.value.code == native.DSMI_ERR_CAPACITY
+    dec.close()
+
+
 def test_beam_cutoff_top_n(native):
     labels = syn.DANSPEECH_LABELS
     rng = np.random.default_rng(4)

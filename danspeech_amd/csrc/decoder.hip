@@ -244,7 +244,10 @@ extern "C" int dsmi_beam_enqueue(dsmi_decoder* d, const float* probs, const int3
         hipLaunchKernelGGL(kern, dim3(B), dim3(BT), lds, s, a);
         return hipSuccess;
     };
-    if (per <= 3) DEC_HIP(d, launch(beam_kernel<1024, 3>));
+    // the reference's alphabet (33 labels) at its default beam (64) and at BASELINE's 128: everything a compile-time constant
+    if (C == 33 && beam == 64) DEC_HIP(d, launch(beam_kernel<1024, 3, 64, 33>));
+    else if (C == 33 && beam == 128) DEC_HIP(d, launch(beam_kernel<1024, 6, 128, 33>));
+    else if (per <= 3) DEC_HIP(d, launch(beam_kernel<1024, 3>));
     else if (per <= 6) DEC_HIP(d, launch(beam_kernel<1024, 6>));
     else if (per <= 12) DEC_HIP(d, launch(beam_kernel<1024, 12>));
     else DEC_HIP(d, launch(beam_kernel<1024, 24>));      // beams beyond ~170 with a scorer: correct, not tuned (registers spill)

@@ -299,7 +299,7 @@ extern "C" int dsmi_model_finalize(dsmi_model* m) {
             bih[col] = bi[dd]->data[src];
         }
         int rc;
-        for (float v : wih) if (!(std::fabs(v) < kF16Safe)) m->gemm_mode = 0;     // split-fp16 operand range
+        for (float v : wih) if (!(std::fabs(v) < kF16Safe / 64.f)) m->gemm_mode = 0;     // split-fp16 operand range (packed times 2^6: gemm.hip)
         if ((rc = upload(m, wih, &r.wih))) return rc;
         if ((rc = upload(m, pack_gemm_w_split(wih.data(), g.Np, r.K, r.ldw), &r.wih_sp))) return rc;
         if ((rc = upload(m, bih, &r.bih))) return rc;

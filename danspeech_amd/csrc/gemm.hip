@@ -201,8 +201,13 @@ using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 
 constexpr int XT_STRIDE = 129;         // f32 transpose tile [32 k][129] (GEMM_A_CONV)
-constexpr float kLoScale = 2048.f, kLoInv = 1.f / 2048.f;
+constexpr float kGemmWScale = 64.f;      // see GemmSplitArgs
 
+// The split-fp16 GEMM's operand format (round 3): x = hi + lo with hi = fp16(x), lo = fp16(x - hi), the lo term UNSCALED, so
+// that all three products of a pair -- hi.hi, hi.lo, lo.hi -- are true-valued and can run into ONE fp32 accumulator.  An
+// unscaled lo term is a normal fp16 number only for |x| >= 2^-3 (its 11 bits then complete the 22 of the pair); below that it
+// keeps an absolute precision of 2^-25, which is what a dot product needs.  The weights are small (|w| ~ K^-1/2), so they are
+// multiplied by 2^6 when they are packed (exact; |w| < 937 is checked at load time) and the result is divided in the epilogue.
 struct GemmSplitArgs {
     const float* a; const float* a2; const float* alpha; const float* beta;
     const uint16_t* w_sp; const float* bias; float* c;
@@ -261,7 +266,7 @@ __global__ __launch_bounds__(256) void split_a_kernel(GemmSplitArgs p, uint16_t*
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const _Float16 hi = (_Float16)v[ps][c];
-            h[c] = hi; l[c] = (_Float16)((v[ps][c] - (float)hi) * kLoScale);
+            h[c] = hi; l[c] = (_Float16)(v[ps][c] - (float)hi);      // UNSCALED: see GemmSplitArgs
         }
         *reinterpret_cast<f16x4*>(tile + 0 * 4096 + row * 32 + kc) = h;
         *reinterpret_cast<f16x4*>(tile + 1 * 4096 + row * 32 + kc) = l;
@@ -269,16 +274,20 @@ __global__ __launch_bounds__(256) void split_a_kernel(GemmSplitArgs p, uint16_t*
 }
 
 // Pass 2: C = A2 . W2^T + bias on v_mfma_f32_32x32x16_f16, three products per (A, W) fragment pair.
+// Small workgroups (round 3): the 128 x 128 tile with ONE accumulator per MFMA tile (the operand format above:
+// 64 accumulator registers instead of 128) and LDS stages of ONE 16-deep k-step (16 KB per stage, 32 KB per workgroup), so that
+// four workgroups fit a CU (about 100 registers per lane) -- while some are parked at their barrier or wait for their operands,
+// others issue; and a small workgroup finds room beside the other batch's kernels where a 64-KB one does not: alone on the
+// chip this kernel equals its predecessor (0.387 against 0.385 ms), beside the other batch it takes 0.66-0.69 instead of 0.80 ms
+// (layer 0: 0.88 instead of 1.20) and the step 8.06 instead of 8.59 ms (tools/exp/retired/gemm_two_accumulators.hip.inc).
+// Rows are 32 bytes in LDS (a 1-KiB wave instruction deposits 32 of them); the two 16-byte chunks of a row swap places in
+// every second group of eight rows, which makes the ds_read_b128 lane groups conflict-free.
 template <bool CONV_ROWS>
-__global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmSplitArgs p, const uint16_t* a_sp) {
+__global__ __launch_bounds__(256, 3) void gemm_f16x3_kernel(GemmSplitArgs p, const uint16_t* a_sp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1;
     const int li = lane & 31, hk = lane >> 5;
-    // XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (each with its own 4 MB L2), so
-    // workgroup id -> (xcd = id % 8, slot = id / 8) and every XCD walks its own contiguous share of the tiles in
-    // panels of 8 column tiles: the ~64 workgroups resident on an XCD then cover 8 row tiles x 8 column tiles and
-    // fetch 16 operand tiles from Infinity Cache / HBM instead of 128 (every operand tile is shared 8 ways in L2).
     int nt, mt;
     {
         const int ntiles = p.ntiles, mtiles = p.mtiles, total = ntiles * mtiles;
@@ -287,84 +296,64 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmSplitArgs p, con
         if ((int)(blockIdx.x >> 3) >= share || idx >= total) return;
         constexpr int PN = 8;
         const int panel = idx / (PN * mtiles), rem = idx - panel * (PN * mtiles);
-        const int pw = min(PN, ntiles - panel * PN);          // width of this (possibly last, narrower) panel
+        const int pw = min(PN, ntiles - panel * PN);
         mt = rem / pw; nt = panel * PN + (rem - mt * pw);
     }
     const int n0 = nt * BN;
     int m0 = mt * BM, bb = 0, t0 = 0;
     if (CONV_ROWS) { bb = mt / p.tiles_per_b; t0 = (mt % p.tiles_per_b) * BM; }
-
-    // Pipeline: LDS holds two stages (k-tiles) that are filled by direct global->LDS loads (global_load_lds_dwordx4:
-    // no VGPR staging, no ds_write instructions); tile kt+1 is requested at the top of iteration kt and must have
-    // landed at its end: ONE barrier per k-tile.  A wave instruction deposits 1 KiB contiguously, so the rows are
-    // unpadded (64 B) and bank conflicts are avoided by XOR-swizzling the four 16-byte chunks of a row with
-    // (row >> 2) & 3 -- applied on the global address when loading and on the LDS address when reading fragments.
     const unsigned char* atile = reinterpret_cast<const unsigned char*>(a_sp) + (size_t)mt * p.ktiles * 16384;
     const unsigned char* wtile = reinterpret_cast<const unsigned char*>(p.w_sp) + (size_t)nt * p.ktiles * 16384;
-    unsigned char* lds = smem3;                                    // [stage][A hi, A lo, W hi, W lo][128 rows][64 B]
-    const int drow = lane >> 2, dchunk = (lane & 3) ^ ((lane >> 4) & 3);        // this lane's row within a 16-row block, logical chunk
-    auto dma = [&](int kt, int stage) {
+    unsigned char* lds = smem3;                 // [stage][A hi, A lo, W hi, W lo][128 rows][32 B]
+    // this lane's part of a 1-KiB block of 32 rows: row lane >> 1, physical chunk lane & 1 = logical chunk ^ ((row >> 3) & 1)
+    const int drow = 32 * wid + (lane >> 1);
+    const int dsrc = drow * 64 + (((lane & 1) ^ ((drow >> 3) & 1)) * 16);
+    auto dma = [&](int step, int stage) {       // step = 2 * k-tile + half
+        const size_t koff = (size_t)(step >> 1) * 16384 + (step & 1) * 32;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int j = wid * 8 + i;                 // 1-KiB block 0..31: operand j >> 4, plane (j >> 3) & 1, rows 16 * (j & 7) ..
-            const unsigned char* src = ((j >> 4) ? wtile : atile) + (size_t)kt * 16384 + ((j >> 3) & 1) * 8192 +
-                                       (16 * (j & 7) + drow) * 64 + dchunk * 16;
+        for (int i = 0; i < 4; ++i) {           // i: operand plane (A hi, A lo, W hi, W lo); the wave's rows are 32 * wid ..
+            const unsigned char* src = ((i >> 1) ? wtile : atile) + koff + (i & 1) * 8192 + dsrc;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(lds + stage * 32768 + j * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(lds + stage * 16384 + i * 4096 + wid * 1024), 16, 0, 0);
         }
     };
-    f16x8 af[2][2][2], wf[2][2][2];      // [buffer][tile][plane]
-    auto read_frags = [&](int buf, int stage, int ks) {
-        const unsigned char* st = lds + stage * 32768;
+    f16x8 af[2][2], wf[2][2];            // [tile][plane]
+    auto read_frags = [&](int stage) {
+        const unsigned char* st = lds + stage * 16384;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) {
                 const int ra_ = wr * 64 + mi * 32 + li, rw_ = wc * 64 + mi * 32 + li;
-                af[buf][mi][pl] = *reinterpret_cast<const f16x8*>(st + pl * 8192 + ra_ * 64 + (((ks * 2 + hk) ^ ((ra_ >> 2) & 3)) * 16));
-                wf[buf][mi][pl] = *reinterpret_cast<const f16x8*>(st + 16384 + pl * 8192 + rw_ * 64 + (((ks * 2 + hk) ^ ((rw_ >> 2) & 3)) * 16));
+                af[mi][pl] = *reinterpret_cast<const f16x8*>(st + pl * 4096 + ra_ * 32 + ((hk ^ ((ra_ >> 3) & 1)) * 16));
+                wf[mi][pl] = *reinterpret_cast<const f16x8*>(st + 8192 + pl * 4096 + rw_ * 32 + ((hk ^ ((rw_ >> 3) & 1)) * 16));
             }
     };
-
-    f32x16 acc[2][2], acl[2][2];       // hi.hi ; (hi.lo + lo.hi) * 2^11
+    f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; acl[i][j][r] = 0.f; }
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    const int nsteps = 2 * p.ktiles;
     dma(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    read_frags(0, 0, 0);
-    for (int kt = 0; kt < p.ktiles; ++kt) {
-        const int stage = kt & 1;
-        if (kt + 1 < p.ktiles) dma(kt + 1, stage ^ 1);      // the other stage was last read in iteration kt-1 (barrier below)
+    for (int st = 0; st < nsteps; ++st) {
+        const int stage = st & 1;
+        if (st + 1 < nsteps) dma(st + 1, stage ^ 1);        // the other stage was last read in step st - 1 (barrier below)
+        read_frags(stage);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            if (ks == 0) read_frags(1, stage, 1);          // next k-step of this tile, while this one computes
-            const int cb = ks;
-            // product by product across the four tiles: no MFMA waits on the one issued just before it
+        for (int pp = 0; pp < 3; ++pp)
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
-                    acl[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cb][mi][1], wf[cb][ni][0], acl[mi][ni], 0, 0, 0);
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cb][mi][0], wf[cb][ni][0], acc[mi][ni], 0, 0, 0);
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-                    acl[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cb][mi][0], wf[cb][ni][1], acl[mi][ni], 0, 0, 0);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's share of tile kt+1 has landed
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi][pp == 2 ? 1 : 0], wf[ni][pp == 1 ? 1 : 0], acc[mi][ni], 0, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's share of the next step has landed
         __syncthreads();
-        if (kt + 1 < p.ktiles) read_frags(0, stage ^ 1, 0);
     }
 
 #pragma unroll
@@ -386,13 +375,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmSplitArgs p, con
                     if (m0 + i >= p.M) continue;
                     crow = (size_t)(m0 + i);
                 }
-                p.c[crow * p.ldc + n] = acc[mi][ni][r] + acl[mi][ni][r] * kLoInv + bv;
+                p.c[crow * p.ldc + n] = acc[mi][ni][r] * (1.f / kGemmWScale) + bv;
             }
         }
     }
 }
-
-
 
 static inline uint16_t g_f16_bits(_Float16 h) {
     uint16_t u;
@@ -400,15 +387,15 @@ static inline uint16_t g_f16_bits(_Float16 h) {
     return u;
 }
 
-// W [N][ldw] fp32 (first K columns valid) -> [n-tile][k-tile][plane][128][32] fp16 terms (hi, lo * 2^11).
+// W [N][ldw] fp32 (first K columns valid) -> [n-tile][k-tile][plane][128][32] fp16 terms (hi, lo) of W * kGemmWScale.
 std::vector<uint16_t> pack_gemm_w_split(const float* w, int N, int K, int ldw) {
     const int ntl = ceil_div(N, BN), ktl = ceil_div(K, BK);
     std::vector<uint16_t> out((size_t)ntl * ktl * 2 * 128 * 32, 0);
     for (int n = 0; n < N; ++n)
         for (int k = 0; k < K; ++k) {
-            const float x = w[(size_t)n * ldw + k];
+            const float x = w[(size_t)n * ldw + k] * kGemmWScale;
             const _Float16 h1 = (_Float16)x;
-            const _Float16 h2 = (_Float16)((x - (float)h1) * kLoScale);
+            const _Float16 h2 = (_Float16)(x - (float)h1);
             const size_t base = (((size_t)(n / BN) * ktl + k / BK) * 2) * 4096 + (size_t)(n % BN) * 32 + (k % BK);
             out[base] = g_f16_bits(h1); out[base + 4096] = g_f16_bits(h2);
         }
@@ -432,7 +419,7 @@ void launch_gemm(const GemmLaunch& g, hipStream_t s) {
         }
         a.ntiles = ceil_div(g.N, BN); a.mtiles = mtiles3;
         const dim3 grid3(8 * ceil_div(a.ntiles * a.mtiles, 8));
-        const size_t lds3 = (size_t)2 * 32768;          // two stages of four 8-KiB operand planes
+        const size_t lds3 = (size_t)2 * 16384;          // two stages of four 4-KiB operand planes (one 16-deep k-step each)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
         if (g.mode == GEMM_A_CONV) DSMI_LAUNCH(gemm_f16x3_kernel<true>, grid3, dim3(256), lds3, s, g.ev, a, (const uint16_t*)g.a_sp);

@@ -545,6 +545,16 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
         duo_lane = rnn_persist_duo_eligible(m->geom16, B, m->n_cus / 2);
         duo = duo_lane || rnn_persist_duo_eligible(m->geom16, B, m->n_cus);
     }
+    // Batches of more than one tile pair (B > 32): the paired-tile kernel in WINDOWS of as many tile pairs as the device holds,
+    // one launch after the other (batches in flight take turns): 3.8 us per step and window against 2.3-2.9 us per 32 clips for
+    // the kernel that walks the tiles.  (One pair per launch on the handle's own lane, the other batch's windows beside it, was
+    // measured and is worse -- config 5: 169 against 128 ms per batch: four times as many persistent launches, each of which
+    // waits for whole free CUs behind the other batch's small dense workgroups.)
+    int duo_window = 0;
+    if (use16 && !duo_lane && B > 32) {
+        duo_window = rnn_persist_duo_pairs(m->geom16, B, m->n_cus);
+        duo = duo_window >= 1;
+    }
     if (use16 && !duo) {
         if (m->inflight >= 2 && rnn_persist16_half_eligible(m->geom16, B, m->n_cus, &pgroups)) waves = 4;
         else use16 = rnn_persist16_eligible(m->geom16, B, m->n_cus, &pgroups);
@@ -567,10 +577,14 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
         pl.spin_limit = m->spin_limit;
         if (m->drop_layer == l) { pl.drop_wg = m->drop_wg; pl.drop_step = m->drop_step; }
         (void)hipMemsetAsync(m->pcnt, 0, sizeof(unsigned) * (size_t)m->geom.D * ceil_div(B, 16) * To * kPersist16CntWords, s);
-        pl.ev = timer_arm(m, KK_PERSIST, true, 2.0 * Dd * GH * m->desc.rnn_hidden_size * sumlen,
-                          4.0 * Dd * (GH * m->desc.rnn_hidden_size + (double)To * B * (GH + 2.0 * m->desc.rnn_hidden_size)));
-        bool ok;
-        {
+        const int total_pairs = (ceil_div(B, 16) + 1) / 2;
+        const int window = duo && duo_window > 0 ? duo_window : total_pairs;
+        bool ok = true;
+        for (int p0 = 0; p0 < (duo ? total_pairs : 1) && ok; p0 += window) {
+            const double part = duo ? (double)std::min(window, total_pairs - p0) / total_pairs : 1.0;
+            if (duo) { pl.pair0 = p0; pl.npairs = std::min(window, total_pairs - p0); }
+            pl.ev = timer_arm(m, KK_PERSIST, true, part * 2.0 * Dd * GH * m->desc.rnn_hidden_size * sumlen,
+                              part * 4.0 * Dd * (GH * m->desc.rnn_hidden_size + (double)To * B * (GH + 2.0 * m->desc.rnn_hidden_size)));
             PersistGate* gate = persist_gate(m->device);
             std::lock_guard<std::mutex> lk(gate->mu);       // wait -> launch -> record is atomic against other host threads
             // a half-CU / half-chip kernel takes one lane (a pair of gate slots), anything else the device

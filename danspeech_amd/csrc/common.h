@@ -166,6 +166,7 @@ struct RnnPersist16Launch {
     unsigned* err;
     int B, T, pgroups;           // pgroups from rnn_persist16_eligible / rnn_persist16_half_eligible
     int waves = 8;               // 8: one workgroup per CU; 4: the half-CU variant (two batches in flight share every CU)
+    int pair0 = 0, npairs = 0;   // paired-tile kernel: the window of tile pairs this launch carries (npairs 0: all of them)
     unsigned spin_limit = kPersistSpinLimit;
     int drop_wg = -1, drop_step = -1;    // test hook: see DSMI_DEBUG_DROP_SIGNAL in api.hip
     EvPair ev;
@@ -182,6 +183,7 @@ bool launch_rnn_persist16(const RnnPersist16Launch& p, hipStream_t s);
 // rnn_persist_duo.hip: one workgroup carries the two 16-clip tiles of a batch in a fixed four-slot pipeline (a 32-clip
 // batch of cfgA on 100 CUs); same packed weights, x-projection order and state layout as rnn_persist16.hip.
 bool rnn_persist_duo_eligible(const RnnGeom& g16, int B, int n_cus);
+int rnn_persist_duo_pairs(const RnnGeom& g16, int B, int n_cus);     // tile pairs one launch can carry on n_cus CUs (0: not this shape)
 bool launch_rnn_persist_duo(const RnnPersist16Launch& p, hipStream_t s);
 
 // head.hip

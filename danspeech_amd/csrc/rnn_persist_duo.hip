@@ -25,6 +25,7 @@
 // when most of the hand-off latency has passed.
 #include "common.h"
 #include "rnn_cell.h"
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -50,6 +51,7 @@ struct DuoArgs {
     const int32_t* lens; uint16_t* hpack; unsigned* cnt; unsigned* err;
     int B, T, H, Hs, Np, nwg, nkb;
     int ntiles, D;
+    int pair0, npairs;         // this launch carries tile pairs pair0 .. pair0 + npairs - 1 (gridDim.y = D * npairs)
     unsigned spin_limit;
     int drop_wg, drop_step;
     unsigned long long* dbg;   // diagnostics build only: per wave, time in each of its four slots [0..3] and at the barrier behind it [4..7]
@@ -75,8 +77,7 @@ __global__ __launch_bounds__(DNT, 2) void rnn_persist_duo_kernel(DuoArgs p) {
     const int tidh = tid & 255;
     const int ln = lane & 15, lg = lane >> 4;
     const int w = blockIdx.x;
-    const int npairs = (p.ntiles + 1) / 2;
-    const int d = blockIdx.y / npairs, pair = blockIdx.y - d * npairs;
+    const int d = blockIdx.y / p.npairs, pair = p.pair0 + (blockIdx.y - d * p.npairs);
     const int tile = 2 * pair + hx;
     const bool tile_ok = tile < p.ntiles;                            // an odd tile count leaves the last half B idle (barriers only)
     const int GU = NG * DU;
@@ -308,7 +309,7 @@ bool launch_duo(const DuoArgs& a, hipStream_t s, const EvPair& ev) {
     constexpr int NGk = KIND == DSMI_RNN_GRU ? 3 : (KIND == DSMI_RNN_LSTM ? 4 : 1);
     const int kq = a.nkb / 4, kr = a.nkb % 4;
     const bool tail = kr > 0 && NGk * kr <= 4 && kq >= 1 && kq <= (KIND == DSMI_RNN_LSTM ? 4 : 6);
-    const dim3 grid(a.nwg, a.D * ((a.ntiles + 1) / 2), 1), block(DNT);
+    const dim3 grid(a.nwg, a.D * a.npairs, 1), block(DNT);
     if (a.dbg) {
         if (KIND != DSMI_RNN_GRU || nkw != 7) return false;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rnn_persist_duo_kernel<DSMI_RNN_GRU, 7, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)D_LDS);
@@ -350,13 +351,17 @@ bool launch_duo(const DuoArgs& a, hipStream_t s, const EvPair& ev) {
 
 // At least two tiles (17+ clips), the half-CU register budget (GRU / RNN: H <= 896, LSTM: H <= 512), every tile pair of both
 // directions co-resident on `n_cus` CUs (the caller passes one gate lane's CUs first, then the whole device).
-bool rnn_persist_duo_eligible(const RnnGeom& g16, int B, int n_cus) {
-    if (g16.U != DU || (g16.H % DU) != 0) return false;
+int rnn_persist_duo_pairs(const RnnGeom& g16, int B, int n_cus) {
+    if (g16.U != DU || (g16.H % DU) != 0) return 0;
     const int nkw = ceil_div(ceil_div(g16.H, 32), 4);
-    if (nkw > (g16.kind == DSMI_RNN_LSTM ? 4 : 7)) return false;
+    if (nkw > (g16.kind == DSMI_RNN_LSTM ? 4 : 7)) return 0;
     const int ntiles = ceil_div(B, DB);
-    if (ntiles < 2) return false;
-    return g16.nwg * g16.D * ((ntiles + 1) / 2) <= n_cus;
+    if (ntiles < 2) return 0;
+    return std::min((ntiles + 1) / 2, n_cus / (g16.nwg * g16.D));
+}
+
+bool rnn_persist_duo_eligible(const RnnGeom& g16, int B, int n_cus) {
+    return rnn_persist_duo_pairs(g16, B, n_cus) >= std::max(1, (ceil_div(B, DB) + 1) / 2);
 }
 
 bool launch_rnn_persist_duo(const RnnPersist16Launch& p, hipStream_t s) {
@@ -365,6 +370,7 @@ bool launch_rnn_persist_duo(const RnnPersist16Launch& p, hipStream_t s) {
     a.xp = p.xp; a.lens = p.lens_dev; a.hpack = p.hpack16; a.cnt = p.counters; a.err = p.err;
     a.B = p.B; a.T = p.T; a.H = p.g.H; a.Hs = p.g.Kp; a.Np = p.g.Np; a.nwg = p.g.nwg; a.nkb = ceil_div(p.g.H, 32);
     a.ntiles = ceil_div(p.B, DB); a.D = p.g.D;
+    a.pair0 = p.pair0; a.npairs = p.npairs > 0 ? p.npairs : (a.ntiles + 1) / 2;
     a.spin_limit = p.spin_limit; a.drop_wg = p.drop_wg; a.drop_step = p.drop_step; a.dbg = p.dbg;
     switch (p.g.kind) {
         case DSMI_RNN_GRU: return launch_duo<DSMI_RNN_GRU>(a, s, p.ev);

@@ -222,11 +222,14 @@ def test_two_batches_in_flight_on_two_handles(native, variant):
         m.close()
 
 
-@pytest.mark.parametrize("kind,H,B", [("gru", 800, 32), ("gru", 64, 17), ("lstm", 512, 48), ("rnn", 96, 64), ("gru", 896, 40), ("lstm", 64, 32)])
+@pytest.mark.parametrize("kind,H,B", [("gru", 800, 32), ("gru", 64, 17), ("lstm", 512, 48), ("rnn", 96, 64), ("gru", 896, 40), ("lstm", 64, 32),
+                                      ("gru", 800, 96), ("gru", 800, 72)])
 def test_paired_tile_kernel_equals_oracle_and_the_single_tile_kernels(native, kind, H, B):
     """rnn_persist_duo (the default for 17+ clips when the shape fits): all cell types, one pair / two pairs of tiles, an odd
     tile count (the last half B idle), a partial last tile, the seven-k-block shape, ragged lengths -- against the oracle
-    and against the same batch through rnn_persist16 (one batch in flight: whole-CU workgroups)."""
+    and against the same batch with one batch in flight (up to 32 clips: rnn_persist16's whole-CU workgroups; more: the
+    same kernel).  H = 800 with 96 / 72 clips: three tile pairs of 100 workgroups each, i.e. two launches per layer (windows
+    of two pairs and one; with 72 clips the last pair's second half idle)."""
     from oracle import torch_port as tp
     cfg = _cfg(H, 2, kind=kind)
     sd = syn.make_state_dict(2, kind, H, 2, seed=61, **syn.TALKATIVE)

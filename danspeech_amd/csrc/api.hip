@@ -264,7 +264,7 @@ extern "C" int dsmi_model_finalize(dsmi_model* m) {
         if (!w || !b || !bn_affine(m, "conv.seq_module." + std::to_string(3 * l + 1), s.co, s.co, a, bb)) return DSMI_ERR_NOT_READY;
         int rc;
         if ((rc = upload(m, pack_conv_weights(w->data.data(), l), &m->conv[l].wp))) return rc;
-        for (float v : w->data) if (!(std::fabs(v) < kF16Safe)) m->conv_mode = 0;    // split-fp16 operand range
+        for (float v : w->data) if (!(std::fabs(v) < kF16Safe / 64.f)) m->conv_mode = 0;    // split-fp16 operand range (packed times 2^6: conv_split.hip)
         if (l > 0) {
             if ((rc = upload(m, pack_conv_w_split(w->data.data(), s.co), &m->conv[l].wp_sp))) return rc;
         } else {

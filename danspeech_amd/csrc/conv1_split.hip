@@ -146,7 +146,7 @@ __global__ __launch_bounds__(C1NT, 4) void conv1_f16x3_kernel(Conv1Args p) {
                     v = fminf(fmaxf(v, 0.f), 20.f);
                     v = t < olen ? v : 0.f;
                     const _Float16 a = (_Float16)v;
-                    h[q] = a; l[q] = (_Float16)((v - (float)a) * kLoScale);
+                    h[q] = a; l[q] = (_Float16)(v - (float)a);        // UNSCALED lo term: the operand format of conv_split.hip
                 }
                 _Float16* base = reinterpret_cast<_Float16*>(p.y_sp) + ((((size_t)b * p.fo + f) * 2) * (size_t)p.to + t) * 32 + 8 * g + 4 * hk;
                 *reinterpret_cast<f16x4*>(base) = h;

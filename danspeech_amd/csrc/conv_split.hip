@@ -1,7 +1,8 @@
 // Conv2d (32 input channels) + bias + BatchNorm2d(eval) + Hardtanh(0,20) + time mask on the fp16
-// MFMA with two-term split operands (x = hi + lo * 2^-11, three products, two fp32 accumulators:
-// better than fp32-MFMA accuracy, see gemm.hip / tools/exp/split_mfma_accuracy.hip).  Inputs are Hardtanh
-// outputs in [0, 20] and the weights are range-checked at load time, so fp16's 65504 is never near.
+// MFMA with two-term split operands (x = hi + lo, the lo term unscaled, the weights packed times 2^6: three true-valued
+// products into ONE fp32 accumulator -- the operand format of gemm.hip, round 3; better than fp32-MFMA accuracy,
+// tools/exp/split_mfma_accuracy.hip).  Inputs are Hardtanh outputs in [0, 20] (their lo terms are at most 2^-7: normal fp16
+// numbers or exact subnormals down to 2^-24) and the weights are range-checked at load time, so fp16's 65504 is never near.
 //
 // Replaces the 2nd and 3rd (Conv2d, BatchNorm2d, Hardtanh) triples of the reference's conv stack
 // and their MaskConv zeroing (danspeech/deepspeech/model.py:65-81, 372-374, 389-391), i.e. the
@@ -26,14 +27,14 @@ namespace {
 
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
-constexpr float kLoScale = 2048.f, kLoInv = 1.f / 2048.f;
+constexpr float kConvWScale = 64.f;    // weights are packed times 2^6 (exact), divided out in the epilogue
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 
 constexpr int BNF = 4;                 // output rows per workgroup (one per wave)
 constexpr int BTT = 64;                // output steps per workgroup (2 MFMA column tiles per wave)
 constexpr int KT = 11, KF = 21, SF = 2, PF = 10, PT = 5, CI = 32;
 constexpr int WIN = BTT + KT - 1;      // staged time steps per row: 74
-constexpr int NPL = 2;                 // operand planes: hi, lo * 2^11
+constexpr int NPL = 2;                 // operand planes: hi, lo
 constexpr int PITCH = 40;              // halfs per staged time step (32 ci + 8 pad = 80 B)
 constexpr int ROWPLANE = WIN * PITCH;  // halfs per (row, plane)
 constexpr int NCHUNK = BNF * NPL * WIN * 4;         // 16-byte chunks staged per kf: 2368
@@ -52,17 +53,17 @@ __device__ __forceinline__ void store_split4(uint16_t* y_sp, size_t bf_index, in
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const _Float16 hi = (_Float16)v[c];
-        h[c] = hi; l[c] = (_Float16)((v[c] - (float)hi) * kLoScale);
+        h[c] = hi; l[c] = (_Float16)(v[c] - (float)hi);
     }
     _Float16* base = reinterpret_cast<_Float16*>(y_sp) + ((bf_index * NPL) * (size_t)t_stride + t) * 32 + c0;
     *reinterpret_cast<f16x4*>(base) = h;
     *reinterpret_cast<f16x4*>(base + (size_t)t_stride * 32) = l;
 }
 
-// One workgroup = one 32-channel output tile (two accumulators per MFMA tile leave no room for three
-// tiles' worth in 256 VGPRs; the 96-channel third layer runs its tiles as separate workgroups).
+// One workgroup = one 32-channel output tile (the 96-channel third layer runs its tiles as separate workgroups); one
+// accumulator per MFMA tile and 47 KB of LDS: three workgroups per CU.
 template <bool SPLIT_OUT>
-__global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvSplitArgs p) {
+__global__ __launch_bounds__(256, 3) void conv_f16x3_kernel(ConvSplitArgs p) {
     constexpr int NCO = 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char csm[];
     _Float16* Xs = reinterpret_cast<_Float16*>(csm);  // [4 rows][2 planes][WIN][PITCH]
@@ -91,13 +92,13 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvSplitArgs p) {
         return;
     }
 
-    f32x16 acc[NCO][2], acl[NCO][2];      // hi.hi ; (hi.lo + lo.hi) * 2^11
+    f32x16 acc[NCO][2];
 #pragma unroll
     for (int c = 0; c < NCO; ++c)
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[c][tt][r] = 0.f; acl[c][tt][r] = 0.f; }
+            for (int r = 0; r < 16; ++r) acc[c][tt][r] = 0.f;
 
     // ---- staging: chunk id -> (row, plane, step, 16-byte part); global source is a plain copy
     u32x4 stg[CPT];
@@ -161,19 +162,21 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvSplitArgs p) {
 #pragma unroll
                         for (int pl = 0; pl < NPL; ++pl) wf[c][pl] = wq[half][c][pl];
                     load_w(min(q + 2, NQ - 1), wq[half]);
+                    f16x8 xf[2][NPL];
 #pragma unroll
-                    for (int tt = 0; tt < 2; ++tt) {
-                        f16x8 xf[NPL];
+                    for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
                         for (int pl = 0; pl < NPL; ++pl)
-                            xf[pl] = *reinterpret_cast<const f16x8*>(xrow + pl * ROWPLANE + (tt * 32 + kt) * PITCH + half * 16);
+                            xf[tt][pl] = *reinterpret_cast<const f16x8*>(xrow + pl * ROWPLANE + (tt * 32 + kt) * PITCH + half * 16);
+                    // the three products of a pair run into one accumulator; the two time tiles alternate, so that an MFMA
+                    // never waits for the one just issued
 #pragma unroll
-                        for (int c = 0; c < NCO; ++c) {
-                            acl[c][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[c][1], xf[0], acl[c][tt], 0, 0, 0);
-                            acl[c][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[c][0], xf[1], acl[c][tt], 0, 0, 0);
-                            acc[c][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[c][0], xf[0], acc[c][tt], 0, 0, 0);
-                        }
-                    }
+                    for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+                        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                            for (int c = 0; c < NCO; ++c)
+                                acc[c][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[c][pp == 0 ? 1 : 0], xf[tt][pp == 1 ? 1 : 0], acc[c][tt], 0, 0, 0);
                 }
             }
         }
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvSplitArgs p) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int co = (ct + c) * 32 + q + 8 * g + 4 * hk;
-                    float x = (acc[c][tt][4 * g + q] + acl[c][tt][4 * g + q] * kLoInv + p.bias[co]) * p.bn_a[co] + p.bn_b[co];
+                    float x = (acc[c][tt][4 * g + q] * (1.f / kConvWScale) + p.bias[co]) * p.bn_a[co] + p.bn_b[co];
                     x = fminf(fmaxf(x, 0.f), 20.f);
                     v[q] = t < olen ? x : 0.f;
                 }
@@ -217,7 +220,7 @@ inline uint16_t c_f16_bits(_Float16 h) {
 
 }  // namespace
 
-// w [co][32][21][11] fp32 -> [kf][kt][half][co-tile][plane][lane][8] fp16 terms (hi, lo * 2^11); lane (i = co in
+// w [co][32][21][11] fp32 -> [kf][kt][half][co-tile][plane][lane][8] fp16 terms (hi, lo) of w * 2^6; lane (i = co in
 // tile, h) element e holds input channel 16*half + 8*h + e.
 std::vector<uint16_t> pack_conv_w_split(const float* w, int co_total) {
     const int nco = co_total / 32;
@@ -229,9 +232,9 @@ std::vector<uint16_t> pack_conv_w_split(const float* w, int co_total) {
                     for (int lane = 0; lane < 64; ++lane)
                         for (int e = 0; e < 8; ++e) {
                             const int co = ct * 32 + (lane & 31), ci = 16 * half + 8 * (lane >> 5) + e;
-                            const float x = w[(((size_t)co * CI + ci) * KF + kf) * KT + kt];
+                            const float x = w[(((size_t)co * CI + ci) * KF + kf) * KT + kt] * kConvWScale;
                             const _Float16 h1 = (_Float16)x;
-                            const _Float16 h2 = (_Float16)((x - (float)h1) * kLoScale);
+                            const _Float16 h2 = (_Float16)(x - (float)h1);
                             const size_t base = ((((((size_t)kf * KT + kt) * 2 + half) * nco + ct) * NPL) * 64 + lane) * 8 + e;
                             out[base] = c_f16_bits(h1); out[base + 512] = c_f16_bits(h2);
                         }

@@ -187,15 +187,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
 // x = hi + lo * 2^-11 (hi = fp16(x), lo = fp16((x - hi) * 2^11), 22 mantissa bits; lo is stored
 // scaled so that it stays a normal number), and three products are formed per fragment pair:
 // hi.hi into one fp32 accumulator, hi.lo + lo.hi into a second one that is folded in with 2^-11
-// in the epilogue (lo.lo < 2^-22 is dropped).  v_mfma_f32_32x32x16_f16 runs at 16x the fp32 MFMA
+// in the epilogue (lo.lo < 2^-22 is dropped).  The fp16 MFMA runs at 16x the fp32 MFMA
 // rate, so the product costs 3/16 of the fp32 one; measured error vs fp64 at K = 800: 2.6e-7
 // against 1.0e-6 for the fp32 MFMA chain (tools/exp/split_mfma_accuracy.hip).  Operand ranges must stay
 // below fp16's 65504: the caller checks weights and BatchNorm bounds at load time (api.hip).
 // W is split and tiled once on the host (pack_gemm_w_split: [n-tile][k-tile][plane][128][32] fp16, so
 // the operand loads are fully coalesced 16-byte copies); the activations are split ONCE per GEMM
 // by split_a_kernel, fused with the same producer transforms as the fp32 kernel (direction sum +
-// BatchNorm1d, conv transpose), into the same tiled form.  Tile 128x128x32, 4 waves in 2x2, two
-// LDS stages filled by direct global->LDS loads (no VGPR staging), one barrier per k-tile.
+// BatchNorm1d, conv transpose), into the same tiled form.  The kernel itself: see gemm_f16x3_kernel below.
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
@@ -273,21 +272,21 @@ __global__ __launch_bounds__(256) void split_a_kernel(GemmSplitArgs p, uint16_t*
     }
 }
 
-// Pass 2: C = A2 . W2^T + bias on v_mfma_f32_32x32x16_f16, three products per (A, W) fragment pair.
-// Small workgroups (round 3): the 128 x 128 tile with ONE accumulator per MFMA tile (the operand format above:
-// 64 accumulator registers instead of 128) and LDS stages of ONE 16-deep k-step (16 KB per stage, 32 KB per workgroup), so that
-// four workgroups fit a CU (about 100 registers per lane) -- while some are parked at their barrier or wait for their operands,
-// others issue; and a small workgroup finds room beside the other batch's kernels where a 64-KB one does not: alone on the
-// chip this kernel equals its predecessor (0.387 against 0.385 ms), beside the other batch it takes 0.66-0.69 instead of 0.80 ms
-// (layer 0: 0.88 instead of 1.20) and the step 8.06 instead of 8.59 ms (tools/exp/retired/gemm_two_accumulators.hip.inc).
-// Rows are 32 bytes in LDS (a 1-KiB wave instruction deposits 32 of them); the two 16-byte chunks of a row swap places in
-// every second group of eight rows, which makes the ds_read_b128 lane groups conflict-free.
+// Pass 2: C = A2 . W2^T + bias on v_mfma_f32_16x16x32_f16, three products per (A, W) fragment pair into one accumulator.
+// Tile 128 x 128, four waves as 2 x 2, each wave 4 x 4 MFMA tiles of 16 x 16; ONE LDS stage of a 32-deep k-tile (32 KB) filled
+// by direct global -> LDS loads, and the registers as the second buffer: read all sixteen fragments, barrier, request the next
+// tile into the same stage, multiply (48 MFMAs), wait, barrier.  Three workgroups per CU cover each other's waits.
+// Why this shape (round 3, profiles/r03_gemm_bounds.txt): the chip holds its clock at 1.9 GHz under this kernel (MI355X_MICROARCH.md
+// "DVFS give-back"), so every tile shape, stage count and prefetch depth tried on v_mfma_f32_32x32x16_f16 -- 128 x 128 with
+// two to four stages, 256 x 128, 256 x 256 with register double buffering -- cost the same 0.38-0.40 ms; the 16 x 16 x 32 MFMA
+// does the same products at a higher sustained clock: 0.340 against 0.398 ms for this very loop on 32 x 32 x 16, 8.15 against
+// 8.45 ms per bench step (tools/exp/retired/gemm_32x32x16_forms.hip.inc).
 template <bool CONV_ROWS>
 __global__ __launch_bounds__(256, 3) void gemm_f16x3_kernel(GemmSplitArgs p, const uint16_t* a_sp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 1, wc = wid & 1;
-    const int li = lane & 31, hk = lane >> 5;
     int nt, mt;
     {
         const int ntiles = p.ntiles, mtiles = p.mtiles, total = ntiles * mtiles;
@@ -299,85 +298,77 @@ __global__ __launch_bounds__(256, 3) void gemm_f16x3_kernel(GemmSplitArgs p, con
         const int pw = min(PN, ntiles - panel * PN);
         mt = rem / pw; nt = panel * PN + (rem - mt * pw);
     }
+    // rows of 64 bytes (32 k); a row's four 16-byte chunks are stored at chunk ^ ((row >> 1) & 3) ^ ((row >> 2) & 3): conflict-free
+    // for the ds_read_b128 lane groups of both MFMA shapes
+    const int drow = lane >> 2;
+    const int doff = (16 * wid + drow) * 64 + (((lane & 3) ^ ((drow >> 1) & 3) ^ ((drow >> 2) & 3)) * 16);
+    const unsigned char* asrc = reinterpret_cast<const unsigned char*>(a_sp) + (size_t)mt * p.ktiles * 16384 + doff;
+    const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(p.w_sp) + (size_t)nt * p.ktiles * 16384 + doff;
+    unsigned char* lds = smem3;                 // [A hi, A lo, W hi, W lo][128 rows][64 B]
+    auto dma = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)             // i: operand i >> 2, plane (i >> 1) & 1, 64-row half i & 1; this wave's 16 rows of it
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(((i >> 2) ? wsrc : asrc) + (size_t)kt * 16384 +
+                                                                                               ((i >> 1) & 1) * 8192 + (i & 1) * 4096),
+                                             (__attribute__((address_space(3))) void*)(lds + (i >> 1) * 8192 + (i & 1) * 4096 + wid * 1024), 16, 0, 0);
+    };
+    auto frag = [&](int plane_base, int row, int chunk) {
+        return *reinterpret_cast<const f16x8*>(lds + plane_base + row * 64 + ((chunk ^ ((row >> 1) & 3) ^ ((row >> 2) & 3)) * 16));
+    };
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    dma(0);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int kt = 0; kt < p.ktiles; ++kt) {
+        f16x8 af[4][2], wf[4][2];        // [tile][plane]: lane l holds row l & 15 of the tile, k = 8 (l >> 4) ..
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                af[q][pl] = frag(pl * 8192, wr * 64 + q * 16 + (lane & 15), lane >> 4);
+                wf[q][pl] = frag(16384 + pl * 8192, wc * 64 + q * 16 + (lane & 15), lane >> 4);
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");        // everybody holds its fragments: the stage is free
+        if (kt + 1 < p.ktiles) dma(kt + 1);
+#pragma unroll
+        for (int pp = 0; pp < 3; ++pp)          // hi.hi, hi.lo, lo.hi: plane pair by plane pair across the sixteen tiles
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi][pp == 2 ? 1 : 0], wf[ni][pp == 1 ? 1 : 0], acc[mi][ni], 0, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");           // the next tile has landed, for everybody
+    }
+
     const int n0 = nt * BN;
     int m0 = mt * BM, bb = 0, t0 = 0;
     if (CONV_ROWS) { bb = mt / p.tiles_per_b; t0 = (mt % p.tiles_per_b) * BM; }
-    const unsigned char* atile = reinterpret_cast<const unsigned char*>(a_sp) + (size_t)mt * p.ktiles * 16384;
-    const unsigned char* wtile = reinterpret_cast<const unsigned char*>(p.w_sp) + (size_t)nt * p.ktiles * 16384;
-    unsigned char* lds = smem3;                 // [stage][A hi, A lo, W hi, W lo][128 rows][32 B]
-    // this lane's part of a 1-KiB block of 32 rows: row lane >> 1, physical chunk lane & 1 = logical chunk ^ ((row >> 3) & 1)
-    const int drow = 32 * wid + (lane >> 1);
-    const int dsrc = drow * 64 + (((lane & 1) ^ ((drow >> 3) & 1)) * 16);
-    auto dma = [&](int step, int stage) {       // step = 2 * k-tile + half
-        const size_t koff = (size_t)(step >> 1) * 16384 + (step & 1) * 32;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {           // i: operand plane (A hi, A lo, W hi, W lo); the wave's rows are 32 * wid ..
-            const unsigned char* src = ((i >> 1) ? wtile : atile) + koff + (i & 1) * 8192 + dsrc;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(lds + stage * 16384 + i * 4096 + wid * 1024), 16, 0, 0);
+    auto put = [&](int i, int n, float v) {     // row i of the tile, column n
+        size_t crow;
+        if (CONV_ROWS) {
+            const int t = t0 + i;
+            if (t >= p.T) return;
+            crow = (size_t)t * p.B + bb;
+        } else {
+            if (m0 + i >= p.M) return;
+            crow = (size_t)(m0 + i);
         }
+        p.c[crow * p.ldc + n] = v;
     };
-    f16x8 af[2][2], wf[2][2];            // [tile][plane]
-    auto read_frags = [&](int stage) {
-        const unsigned char* st = lds + stage * 16384;
+    // D[i][j] of a 16 x 16 tile: j = lane & 15 (column n), i = 4 (lane >> 4) + register
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl) {
-                const int ra_ = wr * 64 + mi * 32 + li, rw_ = wc * 64 + mi * 32 + li;
-                af[mi][pl] = *reinterpret_cast<const f16x8*>(st + pl * 4096 + ra_ * 32 + ((hk ^ ((ra_ >> 3) & 1)) * 16));
-                wf[mi][pl] = *reinterpret_cast<const f16x8*>(st + 8192 + pl * 4096 + rw_ * 32 + ((hk ^ ((rw_ >> 3) & 1)) * 16));
-            }
-    };
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int nsteps = 2 * p.ktiles;
-    dma(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int st = 0; st < nsteps; ++st) {
-        const int stage = st & 1;
-        if (st + 1 < nsteps) dma(st + 1, stage ^ 1);        // the other stage was last read in step st - 1 (barrier below)
-        read_frags(stage);
-#pragma unroll
-        for (int pp = 0; pp < 3; ++pp)
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mi][pp == 2 ? 1 : 0], wf[ni][pp == 1 ? 1 : 0], acc[mi][ni], 0, 0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's share of the next step has landed
-        __syncthreads();
-    }
-
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int n = n0 + wc * 64 + ni * 32 + li;
+    for (int ni = 0; ni < 4; ++ni) {
+        const int n = n0 + wc * 64 + ni * 16 + (lane & 15);
         if (n >= p.N) continue;
         const float bv = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
+        for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int i = wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hk;
-                size_t crow;
-                if (CONV_ROWS) {
-                    const int t = t0 + i;
-                    if (t >= p.T) continue;
-                    crow = (size_t)t * p.B + bb;
-                } else {
-                    if (m0 + i >= p.M) continue;
-                    crow = (size_t)(m0 + i);
-                }
-                p.c[crow * p.ldc + n] = acc[mi][ni][r] * (1.f / kGemmWScale) + bv;
-            }
-        }
+            for (int r = 0; r < 4; ++r) put(wr * 64 + mi * 16 + (lane >> 4) * 4 + r, n, acc[mi][ni][r] * (1.f / kGemmWScale) + bv);
     }
 }
 
@@ -419,9 +410,7 @@ void launch_gemm(const GemmLaunch& g, hipStream_t s) {
         }
         a.ntiles = ceil_div(g.N, BN); a.mtiles = mtiles3;
         const dim3 grid3(8 * ceil_div(a.ntiles * a.mtiles, 8));
-        const size_t lds3 = (size_t)2 * 16384;          // two stages of four 4-KiB operand planes (one 16-deep k-step each)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+        const size_t lds3 = 32768;                      // one stage: four 8-KiB operand planes of a 32-deep k-tile
         if (g.mode == GEMM_A_CONV) DSMI_LAUNCH(gemm_f16x3_kernel<true>, grid3, dim3(256), lds3, s, g.ev, a, (const uint16_t*)g.a_sp);
         else DSMI_LAUNCH(gemm_f16x3_kernel<false>, grid3, dim3(256), lds3, s, g.ev, a, (const uint16_t*)g.a_sp);
         return;

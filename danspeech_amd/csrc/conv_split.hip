@@ -9,17 +9,21 @@
 // layers that hold 89 % / 97 % of the conv FLOPs.  conv.hip (fp32 MFMA) keeps the
 // first layer (1 input channel) and remains the plain fp32 statement of all three.
 //
-// Implicit GEMM with the INPUT CHANNELS as the MFMA's K: one v_mfma_f32_32x32x16_f16 contracts
-// 16 input channels of one kernel tap (kf, kt); A = weights (row = output channel, pre-split and
-// packed on the host in lane order), B = input (col = output time step).  The input arrives
-// already split and channels-last, [b][f][plane 2][t][32 ci] fp16, written by the previous layer's
-// epilogue, so that a lane's 8-channel B fragment is ONE aligned 16-byte LDS read and staging is a
-// plain copy.  Workgroup = 4 waves = 4 consecutive output rows f x 64 output steps x all output
-// channels; per kernel row kf the four input rows it needs (one per wave) are staged in LDS with
-// an 80-byte pitch per time step (16 consecutive steps hit 64 distinct banks), the next kf's
-// rows are in flight in registers during the MFMAs, and the weight fragments of the next
-// (kt, channel half) are requested before the current one's MFMAs (they come from L2: ~600 cycles).
+// Implicit GEMM with the INPUT CHANNELS as the MFMA's K: one v_mfma_f32_16x16x32_f16 contracts all
+// 32 input channels of one kernel tap (kf, kt) for 16 output channels x 16 output steps; A = weights
+// (row = output channel, pre-split and packed on the host in lane order), B = input (col = output
+// time step).  (Round 3: the 16 x 16 x 32 shape instead of 32 x 32 x 16 -- the same products at a
+// higher sustained clock, see gemm.hip.)  The input arrives already split and channels-last,
+// [b][f][plane 2][t][32 ci] fp16, written by the previous layer's epilogue, so that a lane's
+// 8-channel B fragment is ONE aligned 16-byte LDS read and staging is a plain copy.  Workgroup =
+// 4 waves = 4 consecutive output rows f x 64 output steps x 32 output channels; per kernel row kf
+// the four input rows it needs (one per wave) are staged in LDS, 64 bytes per time step with the
+// four 16-byte chunks of a step stored at chunk ^ ((step >> 1) & 3) (conflict-free for the
+// ds_read_b128 lane groups at every tap offset), the next kf's rows are in flight in registers
+// during the MFMAs, and the weight fragments of the tap after next are requested before the
+// current one's MFMAs (they come from L2: ~600 cycles).
 #include "common.h"
+#include <type_traits>
 
 namespace dsmi {
 
@@ -31,11 +35,11 @@ constexpr float kConvWScale = 64.f;    // weights are packed times 2^6 (exact), 
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 
 constexpr int BNF = 4;                 // output rows per workgroup (one per wave)
-constexpr int BTT = 64;                // output steps per workgroup (2 MFMA column tiles per wave)
+constexpr int BTT = 64;                // output steps per workgroup (4 MFMA column tiles per wave)
 constexpr int KT = 11, KF = 21, SF = 2, PF = 10, PT = 5, CI = 32;
 constexpr int WIN = BTT + KT - 1;      // staged time steps per row: 74
 constexpr int NPL = 2;                 // operand planes: hi, lo
-constexpr int PITCH = 40;              // halfs per staged time step (32 ci + 8 pad = 80 B)
+constexpr int PITCH = 32;              // halfs per staged time step (32 ci = 64 B; chunks swizzled, see above)
 constexpr int ROWPLANE = WIN * PITCH;  // halfs per (row, plane)
 constexpr int NCHUNK = BNF * NPL * WIN * 4;         // 16-byte chunks staged per kf: 2368
 constexpr int CPT = (NCHUNK + 255) / 256;           // chunks per thread: 10
@@ -61,15 +65,13 @@ __device__ __forceinline__ void store_split4(uint16_t* y_sp, size_t bf_index, in
 }
 
 // One workgroup = one 32-channel output tile (the 96-channel third layer runs its tiles as separate workgroups); one
-// accumulator per MFMA tile and 47 KB of LDS: three workgroups per CU.
+// accumulator per MFMA tile, 38 KB of LDS, about 180 registers: two workgroups per CU.
 template <bool SPLIT_OUT>
-__global__ __launch_bounds__(256, 3) void conv_f16x3_kernel(ConvSplitArgs p) {
-    constexpr int NCO = 1;
+__global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvSplitArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char csm[];
     _Float16* Xs = reinterpret_cast<_Float16*>(csm);  // [4 rows][2 planes][WIN][PITCH]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 31, hk = lane >> 5;
     const int t0 = blockIdx.x * BTT, f0 = blockIdx.y * BNF;
     const int b = blockIdx.z / p.nco, ct = blockIdx.z - b * p.nco;
     const int f = f0 + wv;
@@ -92,13 +94,11 @@ __global__ __launch_bounds__(256, 3) void conv_f16x3_kernel(ConvSplitArgs p) {
         return;
     }
 
-    f32x16 acc[NCO][2];
+    f32x4 acc[2][4];                      // [16-channel tile][16-step tile]
 #pragma unroll
-    for (int c = 0; c < NCO; ++c)
+    for (int c = 0; c < 2; ++c)
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[c][tt][r] = 0.f;
+        for (int tt = 0; tt < 4; ++tt) acc[c][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // ---- staging: chunk id -> (row, plane, step, 16-byte part); global source is a plain copy
     u32x4 stg[CPT];
@@ -124,92 +124,107 @@ __global__ __launch_bounds__(256, 3) void conv_f16x3_kernel(ConvSplitArgs p) {
             const int c = tid + 256 * i;
             if (c < NCHUNK) {
                 const int part = c & 3, st = (c >> 2) % WIN, rp = (c >> 2) / WIN;
-                *reinterpret_cast<u32x4*>(Xs + rp * ROWPLANE + st * PITCH + part * 8) = stg[i];
+                *reinterpret_cast<u32x4*>(Xs + rp * ROWPLANE + st * PITCH + ((part ^ ((st >> 1) & 3)) * 8)) = stg[i];
             }
         }
     };
 
     const u32x4* wbase = reinterpret_cast<const u32x4*>(p.wp_sp) + lane;
-    const _Float16* xrow = Xs + (wv * NPL) * ROWPLANE + li * PITCH + hk * 8;
-    // weight fragments of step q = (kf * KT + kt) * 2 + half, two steps ahead of the MFMAs (they come from L2:
-    // a step is 6 MFMAs = 192 cycles, the other wave of the SIMD covers as much again)
-    f16x8 wq[2][NCO][NPL];
-    auto load_w = [&](int q, f16x8 (&dst)[NCO][NPL]) {
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const _Float16* xrow = Xs + (wv * NPL) * ROWPLANE;
+    // weight fragments of tap q = kf * KT + kt, two taps ahead of the MFMAs (they come from L2: a tap is 24 MFMAs = 384 cycles,
+    // the other waves of the SIMD cover as much again); the ring's two slots alternate with q, and KT is odd, so the
+    // kernel-row body exists in two versions (first tap in slot 0 / slot 1)
+    f16x8 wq[2][2][NPL];                  // [slot][16-channel tile][plane]
+    auto load_w = [&](int q, f16x8 (&dst)[2][NPL]) {
 #pragma unroll
-        for (int c = 0; c < NCO; ++c)
+        for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int pl = 0; pl < NPL; ++pl)
-                dst[c][pl] = __builtin_bit_cast(f16x8, wbase[(((size_t)q * p.nco + ct + c) * NPL + pl) * 64]);
+                dst[c][pl] = __builtin_bit_cast(f16x8, wbase[((((size_t)q * p.nco + ct) * 2 + c) * NPL + pl) * 64]);
     };
-    constexpr int NQ = KF * KT * 2;
+    constexpr int NQ = KF * KT;
     load_w(0, wq[0]);
     load_w(1, wq[1]);
+    auto tap = [&](int kf, int kt, auto slot_c) {
+        constexpr int slot = decltype(slot_c)::value;
+        const int q = kf * KT + kt;
+        f16x8 wf[2][NPL];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) wf[c][pl] = wq[slot][c][pl];
+        load_w(min(q + 2, NQ - 1), wq[slot]);
+        f16x8 xf[4][NPL];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const int st = tt * 16 + kt + l15;          // staged step of this lane's column
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl)
+                xf[tt][pl] = *reinterpret_cast<const f16x8*>(xrow + pl * ROWPLANE + st * PITCH + ((l4 ^ ((st >> 1) & 3)) * 8));
+        }
+        // the three products of a pair run into one accumulator; plane pair by plane pair across the eight tiles
+#pragma unroll
+        for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt)
+                    acc[c][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[c][pp == 0 ? 1 : 0], xf[tt][pp == 1 ? 1 : 0], acc[c][tt], 0, 0, 0);
+    };
+    auto taps = [&](int kf, auto first_slot) {
+        constexpr int S0 = decltype(first_slot)::value;
+#pragma unroll 1
+        for (int kt = 0; kt + 1 < KT; kt += 2) {
+            tap(kf, kt, std::integral_constant<int, S0>{});
+            tap(kf, kt + 1, std::integral_constant<int, S0 ^ 1>{});
+        }
+        tap(kf, KT - 1, std::integral_constant<int, S0>{});
+    };
 
-    load_rows(0);
-    for (int kf = 0; kf < KF; ++kf) {
+    // KT is odd, so the first tap's ring slot alternates with kf: the kernel rows are walked in pairs (straight-line code for an
+    // even and an odd row; a branch between two versions of the body costs 80 registers at its merge)
+    auto kernel_row = [&](int kf, auto first_slot) {
         store_rows();
         __syncthreads();
         if (kf + 1 < KF) load_rows(kf + 1);
-        if (f < p.fo) {
-#pragma unroll 1
-            for (int kt = 0; kt < KT; ++kt) {
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const int q = (kf * KT + kt) * 2 + half;
-                    f16x8 wf[NCO][NPL];
-#pragma unroll
-                    for (int c = 0; c < NCO; ++c)
-#pragma unroll
-                        for (int pl = 0; pl < NPL; ++pl) wf[c][pl] = wq[half][c][pl];
-                    load_w(min(q + 2, NQ - 1), wq[half]);
-                    f16x8 xf[2][NPL];
-#pragma unroll
-                    for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-                        for (int pl = 0; pl < NPL; ++pl)
-                            xf[tt][pl] = *reinterpret_cast<const f16x8*>(xrow + pl * ROWPLANE + (tt * 32 + kt) * PITCH + half * 16);
-                    // the three products of a pair run into one accumulator; the two time tiles alternate, so that an MFMA
-                    // never waits for the one just issued
-#pragma unroll
-                    for (int pp = 0; pp < 3; ++pp)
-#pragma unroll
-                        for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-                            for (int c = 0; c < NCO; ++c)
-                                acc[c][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[c][pp == 0 ? 1 : 0], xf[tt][pp == 1 ? 1 : 0], acc[c][tt], 0, 0, 0);
-                }
-            }
-        }
+        if (f < p.fo) taps(kf, first_slot);
         __syncthreads();
+    };
+    load_rows(0);
+    static_assert(KF % 2 == 1, "the last kernel row is an even one");
+#pragma unroll 1
+    for (int kf = 0; kf + 1 < KF; kf += 2) {
+        kernel_row(kf, std::integral_constant<int, 0>{});
+        kernel_row(kf + 1, std::integral_constant<int, 1>{});
     }
+    kernel_row(KF - 1, std::integral_constant<int, 0>{});
 
     if (f >= p.fo) return;
-    // ---- epilogue: D[i][j]: i = co (regs), j = lane&31 = time
+    // ---- epilogue: D[i][j] of a 16 x 16 tile: j = lane & 15 = time, i = 4 (lane >> 4) + register = output channel
 #pragma unroll
-    for (int c = 0; c < NCO; ++c)
+    for (int tt = 0; tt < 4; ++tt) {
+        const int t = t0 + tt * 16 + l15;
+        if (t >= p.to) continue;
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            const int t = t0 + tt * 32 + li;
-            if (t >= p.to) continue;
+        for (int c = 0; c < 2; ++c) {
+            float v[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float v[4];
+            for (int q = 0; q < 4; ++q) {
+                const int co = ct * 32 + c * 16 + 4 * l4 + q;
+                float x = (acc[c][tt][q] * (1.f / kConvWScale) + p.bias[co]) * p.bn_a[co] + p.bn_b[co];
+                x = fminf(fmaxf(x, 0.f), 20.f);
+                v[q] = t < olen ? x : 0.f;
+            }
+            if (SPLIT_OUT) {
+                store_split4(p.y_sp, (size_t)b * p.fo + f, p.to, t, c * 16 + 4 * l4, v);
+            } else {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int co = (ct + c) * 32 + q + 8 * g + 4 * hk;
-                    float x = (acc[c][tt][4 * g + q] * (1.f / kConvWScale) + p.bias[co]) * p.bn_a[co] + p.bn_b[co];
-                    x = fminf(fmaxf(x, 0.f), 20.f);
-                    v[q] = t < olen ? x : 0.f;
-                }
-                if (SPLIT_OUT) {
-                    store_split4(p.y_sp, (size_t)b * p.fo + f, p.to, t, 8 * g + 4 * hk, v);
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        p.y[(((size_t)b * CO + (ct + c) * 32 + q + 8 * g + 4 * hk) * p.fo + f) * p.ys + t] = v[q];
-                }
+                for (int q = 0; q < 4; ++q)
+                    p.y[(((size_t)b * CO + ct * 32 + c * 16 + 4 * l4 + q) * p.fo + f) * p.ys + t] = v[q];
             }
         }
+    }
 }
 
 inline uint16_t c_f16_bits(_Float16 h) {
@@ -220,22 +235,22 @@ inline uint16_t c_f16_bits(_Float16 h) {
 
 }  // namespace
 
-// w [co][32][21][11] fp32 -> [kf][kt][half][co-tile][plane][lane][8] fp16 terms (hi, lo) of w * 2^6; lane (i = co in
-// tile, h) element e holds input channel 16*half + 8*h + e.
+// w [co][32][21][11] fp32 -> [kf][kt][32-channel tile][16-channel half][plane][lane][8] fp16 terms (hi, lo) of w * 2^6; lane l
+// (row = l & 15 of the 16-channel half, k chunk l >> 4) element e holds input channel 8 * (l >> 4) + e.
 std::vector<uint16_t> pack_conv_w_split(const float* w, int co_total) {
     const int nco = co_total / 32;
-    std::vector<uint16_t> out((size_t)KF * KT * 2 * nco * NPL * 64 * 8, 0);
+    std::vector<uint16_t> out((size_t)KF * KT * nco * 2 * NPL * 64 * 8, 0);
     for (int kf = 0; kf < KF; ++kf)
         for (int kt = 0; kt < KT; ++kt)
-            for (int half = 0; half < 2; ++half)
-                for (int ct = 0; ct < nco; ++ct)
+            for (int ct = 0; ct < nco; ++ct)
+                for (int c = 0; c < 2; ++c)
                     for (int lane = 0; lane < 64; ++lane)
                         for (int e = 0; e < 8; ++e) {
-                            const int co = ct * 32 + (lane & 31), ci = 16 * half + 8 * (lane >> 5) + e;
+                            const int co = ct * 32 + c * 16 + (lane & 15), ci = 8 * (lane >> 4) + e;
                             const float x = w[(((size_t)co * CI + ci) * KF + kf) * KT + kt] * kConvWScale;
                             const _Float16 h1 = (_Float16)x;
                             const _Float16 h2 = (_Float16)(x - (float)h1);
-                            const size_t base = ((((((size_t)kf * KT + kt) * 2 + half) * nco + ct) * NPL) * 64 + lane) * 8 + e;
+                            const size_t base = ((((((size_t)kf * KT + kt) * nco + ct) * 2 + c) * NPL) * 64 + lane) * 8 + e;
                             out[base] = c_f16_bits(h1); out[base + 512] = c_f16_bits(h2);
                         }
     return out;
@@ -244,7 +259,7 @@ std::vector<uint16_t> pack_conv_w_split(const float* w, int co_total) {
 void launch_conv_split(const ConvSplitLaunch& c, hipStream_t s) {
     ConvSplitArgs a{c.x_sp, c.wp_sp, c.bias, c.bn_a, c.bn_b, c.out_lens_dev, c.y, c.y_sp, c.B, c.fi, c.fo, c.ti, c.to, c.ys, c.co / 32};
     const dim3 grid(ceil_div(c.to, BTT), ceil_div(c.fo, BNF), c.B * a.nco);
-    const size_t lds = (size_t)BNF * NPL * ROWPLANE * 2;   // 47,360 B
+    const size_t lds = (size_t)BNF * NPL * ROWPLANE * 2;   // 37,888 B
     if (c.y_sp) DSMI_LAUNCH((conv_f16x3_kernel<true>), grid, dim3(256), lds, s, c.ev, a);
     else DSMI_LAUNCH((conv_f16x3_kernel<false>), grid, dim3(256), lds, s, c.ev, a);
 }

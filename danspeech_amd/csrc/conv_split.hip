@@ -41,8 +41,9 @@ constexpr int WIN = BTT + KT - 1;      // staged time steps per row: 74
 constexpr int NPL = 2;                 // operand planes: hi, lo
 constexpr int PITCH = 32;              // halfs per staged time step (32 ci = 64 B; chunks swizzled, see above)
 constexpr int ROWPLANE = WIN * PITCH;  // halfs per (row, plane)
-constexpr int NCHUNK = BNF * NPL * WIN * 4;         // 16-byte chunks staged per kf: 2368
-constexpr int CPT = (NCHUNK + 255) / 256;           // chunks per thread: 10
+constexpr int RCHUNK = NPL * WIN * 4;               // 16-byte chunks of one staged input row (both planes): 592
+constexpr int CPR = (RCHUNK + 255) / 256;           // chunks per thread and row: 3
+constexpr int NSLOT = 2 * BNF;                      // staged rows held in LDS: two families of four (see the kernel)
 
 struct ConvSplitArgs {
     const uint16_t* x_sp; const uint16_t* wp_sp; const float* bias; const float* bn_a; const float* bn_b;
@@ -100,38 +101,41 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvSplitArgs p) {
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) acc[c][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // ---- staging: chunk id -> (row, plane, step, 16-byte part); global source is a plain copy
-    u32x4 stg[CPT];
-    auto load_rows = [&](int kf) {
+    // ---- staging.  Kernel row kf needs input rows r0 + kf + 2 w for the four waves w (r0 = SF f0 - PF): rows of kf's parity.
+    // Three of them are the rows kf - 2 used (wave w's row then is wave w - 1's now), so LDS holds two families of four rows (even
+    // and odd kf) as rings, and every kf brings in ONE new row -- for kf + 2, into the slot of the row wave 0 is reading now: the
+    // row is requested at the top of iteration kf, stored at the top of kf + 1 (everybody is past kf's barrier, and kf + 1 reads
+    // the other family) and read from kf + 2 on.  27 rows staged per workgroup instead of 84, one barrier per kernel row.
+    // Family p = kf & 1 holds rows r0 + p + 2 m in slot m & 3; wave w reads m = (kf >> 1) + w.
+    const int r0 = SF * f0 - PF;
+    auto load_row = [&](int fin, u32x4 (&dst)[CPR]) {          // chunk id -> (plane, step, 16-byte part); a plain copy
 #pragma unroll
-        for (int i = 0; i < CPT; ++i) {
+        for (int i = 0; i < CPR; ++i) {
             const int c = tid + 256 * i;
             u32x4 v = {0, 0, 0, 0};
-            if (c < NCHUNK) {
-                const int part = c & 3, st = (c >> 2) % WIN, rp = (c >> 2) / WIN;     // rp = row * NPL + plane
-                const int row = rp / NPL, pl = rp - row * NPL;
-                const int fin = SF * (f0 + row) + kf - PF, tin = t0 - PT + st;
+            if (c < RCHUNK) {
+                const int part = c & 3, st = (c >> 2) % WIN, pl = (c >> 2) / WIN;
+                const int tin = t0 - PT + st;
                 if (fin >= 0 && fin < p.fi && tin >= 0 && tin < p.ti)
                     v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const _Float16*>(p.x_sp) +
                                                         ((((size_t)b * p.fi + fin) * NPL + pl) * p.ti + tin) * 32 + part * 8);
             }
-            stg[i] = v;
+            dst[i] = v;
         }
     };
-    auto store_rows = [&]() {
+    auto store_row = [&](int slot8, const u32x4 (&src)[CPR]) {   // slot8 = family * 4 + slot
 #pragma unroll
-        for (int i = 0; i < CPT; ++i) {
+        for (int i = 0; i < CPR; ++i) {
             const int c = tid + 256 * i;
-            if (c < NCHUNK) {
-                const int part = c & 3, st = (c >> 2) % WIN, rp = (c >> 2) / WIN;
-                *reinterpret_cast<u32x4*>(Xs + rp * ROWPLANE + st * PITCH + ((part ^ ((st >> 1) & 3)) * 8)) = stg[i];
+            if (c < RCHUNK) {
+                const int part = c & 3, st = (c >> 2) % WIN, pl = (c >> 2) / WIN;
+                *reinterpret_cast<u32x4*>(Xs + (slot8 * NPL + pl) * ROWPLANE + st * PITCH + ((part ^ ((st >> 1) & 3)) * 8)) = src[i];
             }
         }
     };
 
     const u32x4* wbase = reinterpret_cast<const u32x4*>(p.wp_sp) + lane;
     const int l15 = lane & 15, l4 = lane >> 4;
-    const _Float16* xrow = Xs + (wv * NPL) * ROWPLANE;
     // weight fragments of tap q = kf * KT + kt, two taps ahead of the MFMAs (they come from L2: a tap is 24 MFMAs = 384 cycles,
     // the other waves of the SIMD cover as much again); the ring's two slots alternate with q, and KT is odd, so the
     // kernel-row body exists in two versions (first tap in slot 0 / slot 1)
@@ -146,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvSplitArgs p) {
     constexpr int NQ = KF * KT;
     load_w(0, wq[0]);
     load_w(1, wq[1]);
-    auto tap = [&](int kf, int kt, auto slot_c) {
+    auto tap = [&](const _Float16* xrow, int kf, int kt, auto slot_c) {
         constexpr int slot = decltype(slot_c)::value;
         const int q = kf * KT + kt;
         f16x8 wf[2][NPL];
@@ -172,26 +176,41 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvSplitArgs p) {
                 for (int tt = 0; tt < 4; ++tt)
                     acc[c][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[c][pp == 0 ? 1 : 0], xf[tt][pp == 1 ? 1 : 0], acc[c][tt], 0, 0, 0);
     };
-    auto taps = [&](int kf, auto first_slot) {
+    auto taps = [&](const _Float16* xrow, int kf, auto first_slot) {
         constexpr int S0 = decltype(first_slot)::value;
 #pragma unroll 1
         for (int kt = 0; kt + 1 < KT; kt += 2) {
-            tap(kf, kt, std::integral_constant<int, S0>{});
-            tap(kf, kt + 1, std::integral_constant<int, S0 ^ 1>{});
+            tap(xrow, kf, kt, std::integral_constant<int, S0>{});
+            tap(xrow, kf, kt + 1, std::integral_constant<int, S0 ^ 1>{});
         }
-        tap(kf, KT - 1, std::integral_constant<int, S0>{});
+        tap(xrow, kf, KT - 1, std::integral_constant<int, S0>{});
     };
 
     // KT is odd, so the first tap's ring slot alternates with kf: the kernel rows are walked in pairs (straight-line code for an
     // even and an odd row; a branch between two versions of the body costs 80 registers at its merge)
+    u32x4 stg[CPR];                       // the row in flight
     auto kernel_row = [&](int kf, auto first_slot) {
-        store_rows();
-        __syncthreads();
-        if (kf + 1 < KF) load_rows(kf + 1);
-        if (f < p.fo) taps(kf, first_slot);
+        const int fam = kf & 1, m0 = kf >> 1;
+        if (kf >= 1 && kf + 1 < KF) store_row(((kf - 1) & 1) * 4 + (((kf - 1) >> 1) & 3), stg);     // requested during kf - 1, for kf + 1
+        if (kf + 2 < KF) load_row(r0 + kf + 8, stg);
+        if (f < p.fo) taps(Xs + ((fam * 4 + ((m0 + wv) & 3)) * NPL) * ROWPLANE, kf, first_slot);
         __syncthreads();
     };
-    load_rows(0);
+    // prologue: the eight rows of kernel rows 0 and 1, four at a time
+    {
+        u32x4 pre[4][CPR];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) load_row(r0 + half * 4 + j, pre[j]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = half * 4 + j;           // row r0 + row: family row & 1, m = row >> 1
+                store_row((row & 1) * 4 + (row >> 1), pre[j]);
+            }
+        }
+    }
+    __syncthreads();
     static_assert(KF % 2 == 1, "the last kernel row is an even one");
 #pragma unroll 1
     for (int kf = 0; kf + 1 < KF; kf += 2) {
@@ -259,7 +278,9 @@ std::vector<uint16_t> pack_conv_w_split(const float* w, int co_total) {
 void launch_conv_split(const ConvSplitLaunch& c, hipStream_t s) {
     ConvSplitArgs a{c.x_sp, c.wp_sp, c.bias, c.bn_a, c.bn_b, c.out_lens_dev, c.y, c.y_sp, c.B, c.fi, c.fo, c.ti, c.to, c.ys, c.co / 32};
     const dim3 grid(ceil_div(c.to, BTT), ceil_div(c.fo, BNF), c.B * a.nco);
-    const size_t lds = (size_t)BNF * NPL * ROWPLANE * 2;   // 37,888 B
+    const size_t lds = (size_t)NSLOT * NPL * ROWPLANE * 2;   // 75,776 B: two workgroups per CU
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_f16x3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_f16x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (c.y_sp) DSMI_LAUNCH((conv_f16x3_kernel<true>), grid, dim3(256), lds, s, c.ev, a);
     else DSMI_LAUNCH((conv_f16x3_kernel<false>), grid, dim3(256), lds, s, c.ev, a);
 }

@@ -344,31 +344,46 @@ __global__ __launch_bounds__(256, 3) void gemm_f16x3_kernel(GemmSplitArgs p, con
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");           // the next tile has landed, for everybody
     }
 
+    // ---- epilogue.  D[i][j] of a 16 x 16 tile: j = lane & 15 (column n), i = 4 (lane >> 4) + register: stored as it stands, a wave
+    // instruction writes sixteen 64-byte pieces.  Each wave turns its tile through its quarter of the (now idle) LDS stage, sixteen
+    // rows at a time, so that a lane holds four consecutive columns of a row and an instruction writes four 256-byte row pieces.
     const int n0 = nt * BN;
     int m0 = mt * BM, bb = 0, t0 = 0;
     if (CONV_ROWS) { bb = mt / p.tiles_per_b; t0 = (mt % p.tiles_per_b) * BM; }
-    auto put = [&](int i, int n, float v) {     // row i of the tile, column n
-        size_t crow;
-        if (CONV_ROWS) {
-            const int t = t0 + i;
-            if (t >= p.T) return;
-            crow = (size_t)t * p.B + bb;
-        } else {
-            if (m0 + i >= p.M) return;
-            crow = (size_t)(m0 + i);
+    constexpr int TP = 68;                      // words per row of the turn buffer: rows 4 apart land 16 banks apart
+    float* turn = reinterpret_cast<float*>(lds) + wid * (16 * TP);
+    const int cn = (lane & 15) * 4, cr = lane >> 4;             // this lane's four columns and its row (+ 4 j) when writing out
+    const int ncol = n0 + wc * 64 + cn;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias && ncol + 3 < p.N) bv = *reinterpret_cast<const f32x4*>(p.bias + ncol);
+    else if (p.bias)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bv[q] = ncol + q < p.N ? p.bias[ncol + q] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) turn[((lane >> 4) * 4 + r) * TP + ni * 16 + (lane & 15)] = acc[mi][ni][r];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // (wave-private region: no barrier)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = wr * 64 + mi * 16 + cr + 4 * j;           // row of the workgroup tile
+            f32x4 v = *reinterpret_cast<const f32x4*>(turn + (cr + 4 * j) * TP + cn);
+            v = v * (1.f / kGemmWScale) + bv;
+            size_t crow;
+            bool ok;
+            if (CONV_ROWS) { ok = t0 + i < p.T; crow = (size_t)(t0 + i) * p.B + bb; }
+            else { ok = m0 + i < p.M; crow = (size_t)(m0 + i); }
+            if (!ok) continue;
+            float* dst = p.c + crow * p.ldc + ncol;
+            if (ncol + 3 < p.N) *reinterpret_cast<f32x4*>(dst) = v;
+            else
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (ncol + q < p.N) dst[q] = v[q];
         }
-        p.c[crow * p.ldc + n] = v;
-    };
-    // D[i][j] of a 16 x 16 tile: j = lane & 15 (column n), i = 4 (lane >> 4) + register
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-        const int n = n0 + wc * 64 + ni * 16 + (lane & 15);
-        if (n >= p.N) continue;
-        const float bv = p.bias ? p.bias[n] : 0.f;
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) put(wr * 64 + mi * 16 + (lane >> 4) * 4 + r, n, acc[mi][ni][r] * (1.f / kGemmWScale) + bv);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the reads are done before the next sixteen rows overwrite them
     }
 }
 

@@ -30,14 +30,16 @@ struct HeadArgs {
     int M, Hs, nq, C, T, B;
 };
 
-// One wave = 32 rows (t,b) x all classes.  A = W_fc tile (row i = class), B = normalised
-// activations (col j = row of the batch), so a lane ends up with 16 classes per tile of ONE
-// row: the softmax needs a single cross-half exchange (lane ^ 32).
+// One workgroup = 32 rows (t,b) x all classes, its four waves taking every fourth 8-deep slice of K (round 3: four times the
+// waves in flight for the same strided row reads -- 95 -> 45 us for cfgA); wave 0 adds the partial tiles and finishes.
+// A = W_fc tile (row i = class), B = normalised activations (col j = row of the batch), so a lane ends up with 16 classes
+// per tile of ONE row: the softmax needs a single cross-half exchange (lane ^ 32).
 template <int NT>
 __global__ __launch_bounds__(256) void head_kernel(HeadArgs p) {
+    __shared__ float part[3][NT][16][64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int li = lane & 31, hk = lane >> 5;
-    const int m = (blockIdx.x * 4 + wv) * 32 + li;
+    const int m = blockIdx.x * 32 + li;
     const bool valid = m < p.M;
     f32x16 acc[NT];
 #pragma unroll
@@ -47,7 +49,7 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs p) {
     const f32x4* wp = reinterpret_cast<const f32x4*>(p.wp) + lane;
     const size_t xoff = (size_t)(valid ? m : 0) * p.Hs;
 
-    for (int q = 0; q < p.nq; ++q) {
+    for (int q = wv; q < p.nq; q += 4) {
         const int k = 8 * q + 4 * hk;
         f32x4 xv = *reinterpret_cast<const f32x4*>(p.x1 + xoff + k);
         if (p.x2) xv += *reinterpret_cast<const f32x4*>(p.x2 + xoff + k);
@@ -61,6 +63,19 @@ __global__ __launch_bounds__(256) void head_kernel(HeadArgs p) {
             for (int c = 0; c < NT; ++c)
                 acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[c][e], xv[e], acc[c], 0, 0, 0);
     }
+    if (wv > 0)
+#pragma unroll
+        for (int c = 0; c < NT; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part[wv - 1][c][r][lane] = acc[c][r];
+    __syncthreads();
+    if (wv > 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w)             // fixed order: the sum does not depend on scheduling
+#pragma unroll
+        for (int c = 0; c < NT; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][r] += part[w][c][r][lane];
     // softmax over classes: this lane holds class = 32c + (r&3) + 8(r>>2) + 4hk of row m
     float mx = -INFINITY;
 #pragma unroll
@@ -99,7 +114,7 @@ void launch_head(const HeadLaunch& h, hipStream_t s) {
     a.x1 = h.x1; a.x2 = h.x2; a.bn_a = h.bn_a; a.bn_b = h.bn_b; a.wp = h.w_packed; a.probs = h.probs;
     a.M = h.T * h.B; a.Hs = round_up(h.H, 8); a.nq = a.Hs / 8; a.C = h.C; a.T = h.T; a.B = h.B;
     const int nt = ceil_div(h.C, 32);
-    dim3 grid(ceil_div(a.M, 128));
+    dim3 grid(ceil_div(a.M, 32));
     switch (nt) {
         case 1: DSMI_LAUNCH(head_kernel<1>, grid, dim3(256), 0, s, h.ev, a); break;
         case 2: DSMI_LAUNCH(head_kernel<2>, grid, dim3(256), 0, s, h.ev, a); break;

@@ -1,3 +1,5 @@
+# RETIRED with the experiment it drove: the DSMI_EXP_* switch it sets existed only in the experiment builds whose kernels are kept
+# under tools/exp/retired/*.hip.inc; kept as the record of how the numbers in profiles/r03_gemm_bounds.txt / r03_duo_slot_stamps.txt were taken.
 # A/B of the six-slot paired-tile recurrent kernel (DSMI_EXP_DUO6) against the four-slot one
 mkdir -p gpurun_out
 for V in 0 1 0 1; do

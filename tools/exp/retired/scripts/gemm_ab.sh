@@ -1,3 +1,5 @@
+# RETIRED with the experiment it drove: the DSMI_EXP_* switch it sets existed only in the experiment builds whose kernels are kept
+# under tools/exp/retired/*.hip.inc; kept as the record of how the numbers in profiles/r03_gemm_bounds.txt / r03_duo_slot_stamps.txt were taken.
 # A/B of the split-fp16 GEMM's experimental shapes (DSMI_EXP_GEMM): alone on the chip, parity, in the pipeline
 mkdir -p gpurun_out
 for V in ${GEMM_AB_SHAPES:-base m256n256 m256n256st3}; do

@@ -1,3 +1,5 @@
+# RETIRED with the experiment it drove: the DSMI_EXP_* switch it sets existed only in the experiment builds whose kernels are kept
+# under tools/exp/retired/*.hip.inc; kept as the record of how the numbers in profiles/r03_gemm_bounds.txt / r03_duo_slot_stamps.txt were taken.
 # Shader clock and MFMA-busy share of the GEMM in each timing experiment: GRBM_GUI_ACTIVE / (end - start), MFMA busy / active
 export TMPDIR=/tmp
 for V in base nodma nolds nomfma m256n256st3; do

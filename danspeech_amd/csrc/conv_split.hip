@@ -16,12 +16,13 @@
 // higher sustained clock, see gemm.hip.)  The input arrives already split and channels-last,
 // [b][f][plane 2][t][32 ci] fp16, written by the previous layer's epilogue, so that a lane's
 // 8-channel B fragment is ONE aligned 16-byte LDS read and staging is a plain copy.  Workgroup =
-// 4 waves = 4 consecutive output rows f x 64 output steps x 32 output channels; per kernel row kf
-// the four input rows it needs (one per wave) are staged in LDS, 64 bytes per time step with the
-// four 16-byte chunks of a step stored at chunk ^ ((step >> 1) & 3) (conflict-free for the
-// ds_read_b128 lane groups at every tap offset), the next kf's rows are in flight in registers
-// during the MFMAs, and the weight fragments of the tap after next are requested before the
-// current one's MFMAs (they come from L2: ~600 cycles).
+// 4 waves = 4 consecutive output rows f x 64 output steps x 32 output channels; the input rows a
+// kernel row kf needs (one per wave) live in LDS as two rings of four rows -- three of them are the
+// rows kf - 2 used, so only ONE new row is staged per kernel row (in flight in registers during the
+// MFMAs) --, 64 bytes per time step with the four 16-byte chunks of a step stored at
+// chunk ^ ((step >> 1) & 3) (conflict-free for the ds_read_b128 lane groups at every tap offset),
+// and the weight fragments of the tap after next are requested before the current one's MFMAs
+// (they come from L2: ~600 cycles).
 #include "common.h"
 #include <type_traits>
 
@@ -66,11 +67,11 @@ __device__ __forceinline__ void store_split4(uint16_t* y_sp, size_t bf_index, in
 }
 
 // One workgroup = one 32-channel output tile (the 96-channel third layer runs its tiles as separate workgroups); one
-// accumulator per MFMA tile, 38 KB of LDS, about 180 registers: two workgroups per CU.
+// accumulator per MFMA tile, 76 KB of LDS (eight staged input rows, see "staging" below), 136 registers: two workgroups per CU.
 template <bool SPLIT_OUT>
 __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvSplitArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char csm[];
-    _Float16* Xs = reinterpret_cast<_Float16*>(csm);  // [4 rows][2 planes][WIN][PITCH]
+    _Float16* Xs = reinterpret_cast<_Float16*>(csm);  // [2 families][4 slots][2 planes][WIN][PITCH]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int t0 = blockIdx.x * BTT, f0 = blockIdx.y * BNF;

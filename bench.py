@@ -148,8 +148,8 @@ def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)     # 10 steps read 3 % low: the fill and drain of the two-deep pipeline
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="cfgA-greedy", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default: the config's 32)")
     ap.add_argument("--hidden", type=int, default=None, help="experiments: another hidden size (the JSON line then names it)")

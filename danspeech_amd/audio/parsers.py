@@ -23,6 +23,18 @@ def _shared_copy_stream(device):
     return _COPY_STREAMS[device]
 
 
+class StagedClips(object):
+    """Host clips on their way to the device: ``SpectrogramAudioParser.stage`` has copied them into a pinned buffer and started
+    the upload on the copy stream; ``parse_batch`` makes the current stream wait for it and runs the spectrograms.  Lets a
+    pipeline start a batch's upload before it has a model handle free for it."""
+
+    def __init__(self, pcm, n_samples, itemsize, done):
+        self.pcm, self.n_samples, self.itemsize, self.done = pcm, n_samples, itemsize, done
+
+    def __len__(self):
+        return len(self.n_samples)
+
+
 class DeviceClips(object):
     """A batch whose clips already lie back to back in GPU memory, longest first: ``pcm`` = 1-D CUDA tensor (int16, float32
     or float64 samples), ``n_samples`` = their lengths.  What an RCCL scatter delivers (``parallel.recognize_sharded``) and
@@ -98,12 +110,10 @@ class SpectrogramAudioParser(AudioParser):
             slot["buf"] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8).pin_memory()
         return slot
 
-    def parse_batch(self, recordings):
-        """list of 1-D arrays -> (features [B,1,F,Tmax] CUDA float32, frames int32[B]); batched extension.
-        Asynchronous: the upload runs on a copy stream, the kernels on the current stream behind it."""
+    def stage(self, recordings):
+        """list of 1-D arrays -> ``StagedClips``: the clips copied back to back into a pinned buffer (two buffers, used
+        alternately) and their upload started on the copy stream.  Touches no stream but the copy stream."""
         import torch
-        if isinstance(recordings, DeviceClips):
-            return self._frontend().features(recordings.pcm, recordings.n_samples)
         recordings = [np.asarray(r) for r in recordings]
         kinds = {r.dtype for r in recordings}
         dtype = kinds.pop() if len(kinds) == 1 and next(iter(kinds)) in self._NATIVE_PCM else np.dtype(np.float64)
@@ -126,7 +136,6 @@ class SpectrogramAudioParser(AudioParser):
             list(self._pool.map(lambda ab: copy(*ab), zip(cut[:-1], cut[1:])))
         else:
             copy(0, len(recordings))
-        main = torch.cuda.current_stream(self.device)
         # the parser's own upload stream, or the one all parsers of the device share (share_copy_stream: set by a pipeline
         # that also keeps a decode stream busy -- see _shared_copy_stream)
         up = _shared_copy_stream(self.device) if getattr(self, "share_copy_stream", False) else self._copy_stream
@@ -134,9 +143,19 @@ class SpectrogramAudioParser(AudioParser):
             pcm = slot["buf"][:total * dtype.itemsize].to("cuda:%d" % self.device, non_blocking=True)
             slot["done"] = torch.cuda.Event()
             slot["done"].record(up)
-        main.wait_event(slot["done"])
-        pcm.record_stream(main)
-        return self._frontend().features(pcm.view({2: torch.int16, 4: torch.float32, 8: torch.float64}[dtype.itemsize]), n)
+        return StagedClips(pcm, n, dtype.itemsize, slot["done"])
+
+    def parse_batch(self, recordings):
+        """list of 1-D arrays (or ``StagedClips`` / ``DeviceClips``) -> (features [B,1,F,Tmax] CUDA float32, frames int32[B]);
+        batched extension.  Asynchronous: the upload runs on a copy stream, the kernels on the current stream behind it."""
+        import torch
+        if isinstance(recordings, DeviceClips):
+            return self._frontend().features(recordings.pcm, recordings.n_samples)
+        staged = recordings if isinstance(recordings, StagedClips) else self.stage(recordings)
+        main = torch.cuda.current_stream(self.device)
+        main.wait_event(staged.done)
+        staged.pcm.record_stream(main)
+        return self._frontend().features(staged.pcm.view({2: torch.int16, 4: torch.float32, 8: torch.float64}[staged.itemsize]), staged.n_samples)
 
     def parse_wav_frames(self, raws, width, channels):
         """Raw PCM WAV frames (``read_wav_frames``; one common sample width / channel count) ->

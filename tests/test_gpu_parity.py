@@ -349,6 +349,9 @@ def test_full_width_variants_vs_oracle(native, kind, H, L, cl, bidir):
 
 @pytest.mark.parametrize("kind,B,why", [("gru", 20, "two tiles per workgroup: deferred signalling"),
                                         ("gru", 40, "three tiles per workgroup: software-pipelined kernel"),
+                                        ("gru", 64, "four tiles: the state requested a whole iteration ahead"),
+                                        ("gru", 104, "seven tiles, an odd number of tile instances"),
+                                        ("rnn", 72, "five tiles, one gate"),
                                         ("lstm", 56, "four tiles, LSTM cell state carried per tile")])
 def test_second_generation_walks_several_tiles_vs_oracle(native, kind, B, why):
     """H = 1024: 64 workgroups x 2 directions leave room for ONE tile group on 256 CUs, so every workgroup of

@@ -167,6 +167,10 @@ extern "C" int dsmi_model_create(const dsmi_model_desc* d, int device, dsmi_mode
         const char* mode = std::getenv("DSMI_RNN_MODE");      // "steps": one launch per time step; "persist8": first-generation persistent kernel
         m->rnn_mode = (mode && std::string(mode) == "steps") ? 0 : 1;
         m->persist_gen = (mode && std::string(mode) == "persist8") ? 1 : 2;
+        // DSMI_RNN_KERNEL=duo: the paired-tile / tile-walking kernels where the ring kernel would run (A/B measurements and the
+        // parity tests of those kernels); =ring: the ring kernel also for a lone batch of up to 32 clips
+        const char* rk = std::getenv("DSMI_RNN_KERNEL");
+        m->rnn_kernel = (rk && std::string(rk) == "duo") ? 1 : ((rk && std::string(rk) == "ring") ? 2 : 0);
         // DSMI_DENSE_MODE=f32: GEMM and conv layers on the plain fp32-MFMA kernels (the round-1 path, and where a model whose
         // weights leave fp16's range ends up by itself); with DSMI_RNN_MODE=steps the whole forward is the second, independent
         // implementation the parity tests compare the default one with
@@ -555,7 +559,23 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
         duo_window = rnn_persist_duo_pairs(m->geom16, B, m->n_cus);
         duo = duo_window >= 1;
     }
-    if (use16 && !duo) {
+    // The ring kernel (rnn_persist_ring.hip): a window = every tile of up to 4..8 on H / 32 workgroups per direction (cfgA: 50 CUs,
+    // ONE gate slot).  With batches in flight a handle's layer is one window on its own slot -- the other slots and the rest of
+    // the chip belong to the other batches; a lone batch of more than 32 clips spreads its tiles over as many windows side by
+    // side as the device holds.  (A lone batch of up to 32 clips keeps the whole-device kernel: the shortest step.)
+    int ring_ntw = 0, ring_nwin = 0;
+    if (use16 && m->rnn_kernel != 1 && (m->inflight >= 2 || B > 32 || m->rnn_kernel == 2)) {
+        const int cap = rnn_persist_ring_tiles(m->geom16, B, m->n_cus / kMaxLanes);
+        if (cap > 0) {
+            const int ntiles = ceil_div(B, 16);
+            const int slots = m->inflight >= 2 ? 1 : kMaxLanes;
+            ring_ntw = std::min(std::max(ceil_div(ntiles, slots), 1), 8);
+            if (m->inflight < 2) ring_ntw = std::max(ring_ntw, std::min(ntiles, 2));
+            ring_nwin = std::min(ceil_div(ntiles, ring_ntw), slots);
+            duo = false;
+        }
+    }
+    if (use16 && !duo && !ring_ntw) {
         if (m->inflight >= 2 && rnn_persist16_half_eligible(m->geom16, B, m->n_cus, &pgroups)) waves = 4;
         else use16 = rnn_persist16_eligible(m->geom16, B, m->n_cus, &pgroups);
     }
@@ -580,7 +600,22 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
         const int total_pairs = (ceil_div(B, 16) + 1) / 2;
         const int window = duo && duo_window > 0 ? duo_window : total_pairs;
         bool ok = true;
-        for (int p0 = 0; p0 < (duo ? total_pairs : 1) && ok; p0 += window) {
+        const int ntiles = ceil_div(B, 16);
+        for (int t0 = 0; ring_ntw && t0 < ntiles && ok; t0 += ring_ntw * ring_nwin) {
+            const int nw = std::min(ring_nwin, ceil_div(ntiles - t0, ring_ntw));
+            const double part = (double)std::min(ring_ntw * nw, ntiles - t0) / ntiles;
+            pl.tile0 = t0; pl.ntw = ring_ntw; pl.nwin = nw;
+            pl.ev = timer_arm(m, KK_PERSIST, true, part * 2.0 * Dd * GH * m->desc.rnn_hidden_size * sumlen,
+                              part * 4.0 * Dd * (GH * m->desc.rnn_hidden_size + (double)To * B * (GH + 2.0 * m->desc.rnn_hidden_size)));
+            PersistGate* gate = persist_gate(m->device);
+            std::lock_guard<std::mutex> lk(gate->mu);
+            const int width = nw == 1 ? 1 : (nw == 2 ? 2 : kMaxLanes);
+            gate_wait(gate, s, m->lane, width);
+            ok = launch_rnn_persist_ring(pl, s);
+            gate_record(gate, s, m->lane, width);
+        }
+        if (ring_ntw && ok) return;
+        for (int p0 = 0; !ring_ntw && p0 < (duo ? total_pairs : 1) && ok; p0 += window) {
             const double part = duo ? (double)std::min(window, total_pairs - p0) / total_pairs : 1.0;
             if (duo) { pl.pair0 = p0; pl.npairs = std::min(window, total_pairs - p0); }
             pl.ev = timer_arm(m, KK_PERSIST, true, part * 2.0 * Dd * GH * m->desc.rnn_hidden_size * sumlen,
@@ -988,7 +1023,12 @@ extern "C" int dsmi_debug_step_stamps(dsmi_model* m, int layer, int B, int To, i
 // ---- diagnostics: accumulated per-wave phase times (100 MHz ticks) of one persistent layer launch;
 // stamps_host[workgroups][8 waves][8]: 0 loop head, 1 wait, 2 h load + MFMA, 3 LDS + barrier, 4 cell (+ publish stores),
 // 5 drain + signal.  Returns the number of workgroups stamped (> 0) or a DSMI_ERR_* code (< 0).
+// DSMI_STAMP_RING=1: the ring kernel (one window of every tile of B <= 128 clips): stamps[workgroup][8 waves][16] (RingArgs::dbg) = M work, M-end waits,
+// C work, barrier behind M, barrier behind C, poll spin (100 MHz ticks), shader cycles in M work, slots.
+static int ring_stamps(dsmi_model* m, int layer, int B, int To, uint64_t* stamps_host, int64_t n_words);
+
 extern "C" int dsmi_debug_persist_stamps(dsmi_model* m, int layer, int B, int To, uint64_t* stamps_host, int64_t n_words) {
+    if (m && m->finalized && std::getenv("DSMI_STAMP_RING")) return ring_stamps(m, layer, B, To, stamps_host, n_words);
     if (!m || !m->finalized || B > 32 || layer < 0 || layer >= m->desc.rnn_layers || !rnn_persist_eligible(m->geom, B, m->n_cus) ||
         m->geom.nwg * m->geom.D > m->n_cus) return DSMI_ERR_INVALID;
     int Tin = To;
@@ -1068,4 +1108,41 @@ extern "C" int dsmi_debug_persist_stamps(dsmi_model* m, int layer, int B, int To
     HIP_OK(m, hipMemcpy(stamps_host, dbg, sizeof(unsigned long long) * need, hipMemcpyDeviceToHost));
     (void)hipFree(dbg);
     return (int)(need / 64);          // number of workgroups stamped
+}
+
+static int ring_stamps(dsmi_model* m, int layer, int B, int To, uint64_t* stamps_host, int64_t n_words) {
+    if (B < 1 || B > 128 || layer < 0 || layer >= m->desc.rnn_layers || !m->have16 ||
+        rnn_persist_ring_tiles(m->geom16, B, m->n_cus) < ceil_div(B, 16)) return DSMI_ERR_INVALID;
+    int Tin = To;
+    while (seq_len(m, Tin) < To) Tin += 1;
+    int rc;
+    if ((rc = dsmi_reserve(m, B, Tin))) return rc;
+    HIP_OK(m, hipSetDevice(m->device));
+    if (!persist_process_lock(m->device)) return fail(m, DSMI_ERR_INVALID, "another process holds this GPU's persistent-kernel lock");
+    PersistGate* stamp_gate = persist_gate(m->device);
+    std::lock_guard<std::mutex> stamp_lk(stamp_gate->mu);
+    HIP_OK(m, hipDeviceSynchronize());
+    const int64_t need = (int64_t)rnn_persist_ring_cus(m->geom16) * 8 * 16;
+    if (n_words < need) return fail(m, DSMI_ERR_INVALID, "stamp buffer too small");
+    unsigned long long* dbg;
+    HIP_OK(m, hipMalloc((void**)&dbg, sizeof(unsigned long long) * need));
+    HIP_OK(m, hipMemset(dbg, 0, sizeof(unsigned long long) * need));
+    std::vector<int32_t> lens(B, To);
+    HIP_OK(m, hipMemcpy(m->lens_dev, lens.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice));
+    HIP_OK(m, hipMemset(m->xp, 0, sizeof(float) * (size_t)To * B * m->geom16.Np));
+    RnnPersist16Launch pl;
+    pl.g = m->geom16;
+    for (int dd = 0; dd < 2; ++dd) { pl.whh16[dd] = m->rnn[layer].whh16_sp[dd]; pl.bhh[dd] = m->rnn[layer].bhh[dd]; pl.out[dd] = m->hbuf[0][dd]; }
+    pl.xp = m->xp; pl.lens_dev = m->lens_dev; pl.hpack16 = m->hpack16; pl.counters = m->pcnt; pl.err = m->perr;
+    pl.B = B; pl.T = To; pl.tile0 = 0; pl.ntw = ceil_div(B, 16); pl.nwin = 1;
+    bool ok = true;
+    for (int rep = 0; rep < 2 && ok; ++rep) {
+        HIP_OK(m, hipMemset(m->pcnt, 0, sizeof(unsigned) * (size_t)m->geom.D * ceil_div(B, 16) * To * kPersist16CntWords));
+        pl.dbg = rep ? dbg : nullptr;
+        ok = launch_rnn_persist_ring(pl, nullptr);
+        HIP_OK(m, hipDeviceSynchronize());
+    }
+    HIP_OK(m, hipMemcpy(stamps_host, dbg, sizeof(unsigned long long) * need, hipMemcpyDeviceToHost));
+    (void)hipFree(dbg);
+    return ok ? (int)(need / 128) : DSMI_ERR_INVALID;
 }

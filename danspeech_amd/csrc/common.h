@@ -167,6 +167,7 @@ struct RnnPersist16Launch {
     int B, T, pgroups;           // pgroups from rnn_persist16_eligible / rnn_persist16_half_eligible
     int waves = 8;               // 8: one workgroup per CU; 4: the half-CU variant (two batches in flight share every CU)
     int pair0 = 0, npairs = 0;   // paired-tile kernel: the window of tile pairs this launch carries (npairs 0: all of them)
+    int tile0 = 0, ntw = 0, nwin = 1;   // ring kernel: nwin windows of ntw tiles each, from tile0, side by side (ntw 0: all tiles in one window)
     unsigned spin_limit = kPersistSpinLimit;
     int drop_wg = -1, drop_step = -1;    // test hook: see DSMI_DEBUG_DROP_SIGNAL in api.hip
     EvPair ev;
@@ -185,6 +186,13 @@ bool launch_rnn_persist16(const RnnPersist16Launch& p, hipStream_t s);
 bool rnn_persist_duo_eligible(const RnnGeom& g16, int B, int n_cus);
 int rnn_persist_duo_pairs(const RnnGeom& g16, int B, int n_cus);     // tile pairs one launch can carry on n_cus CUs (0: not this shape)
 bool launch_rnn_persist_duo(const RnnPersist16Launch& p, hipStream_t s);
+
+// rnn_persist_ring.hip: a workgroup = 32 units of one direction (two adjacent 16-unit groups), walking every tile of its
+// window with the tiles' states staged through an LDS ring (a 64-clip layer of cfgA on 50 CUs); same packed weights,
+// x-projection order, state layout and counters as rnn_persist16.hip.
+int rnn_persist_ring_tiles(const RnnGeom& g16, int B, int n_cus);    // tiles one window can walk (0: not this shape)
+int rnn_persist_ring_cus(const RnnGeom& g16);                        // CUs one window occupies
+bool launch_rnn_persist_ring(const RnnPersist16Launch& p, hipStream_t s);
 
 // head.hip
 //   lookahead: y[t][b][h] = clip(sum_k w[h][k] * x[t+k][b][h], 0, 20)

@@ -1,0 +1,155 @@
+"""GPU tests of the ring kernel (rnn_persist_ring.hip): one workgroup = 32 hidden units of one direction walking every
+16-clip tile of its window, the tiles' packed states staged through an LDS ring by LDS-DMA.  Reference semantics:
+``BatchRNN.forward`` (danspeech/deepspeech/model.py:114-122) through the whole ``DeepSpeech.forward`` (:496-515); the
+checker is oracle/torch_port.py (itself pinned to the reference's goldens, tests/test_oracle_torch_port.py)."""
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+from danspeech_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def native():
+    from danspeech_amd import _native
+    assert torch.cuda.is_available()
+    _native.lib()
+    return _native
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _cfg(H, L, kind="gru", cl=2):
+    return dict(conv_layers=cl, rnn_type=kind, rnn_hidden_size=H, rnn_layers=L, bidirectional=True, context=20)
+
+
+def _batch(B=5, T=161, seed=3):
+    lens = np.sort(np.random.default_rng(seed).integers(T // 2, T + 1, size=B))[::-1].astype(np.int32)
+    lens[0] = T
+    x = syn.make_features(B, T, seed=seed)
+    for b, L in enumerate(lens):
+        x[b, :, :, L:] = 0
+    return x, lens
+
+
+class _env:
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        os.environ.update(self.kv)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+# (kind, H, B, inflight): inflight 2 = one window on the handle's own gate slot; inflight 1 with more than 32 clips = the
+# tiles spread over up to four windows side by side.  B 64 = two 32-clip batches in one launch (four real tiles); 17 / 32 =
+# one or two real tiles padded with phantom ones; 40 / 72 = a partial last tile; 128 = eight tiles in one window;
+# H 800 / 896 = seven k-blocks per wave (the benchmarked shape and the widest); 48 units = an odd number of 16-unit groups
+# (the last workgroup's second half idle); H 16 = one k-block, two waves of a half without any.
+CASES = [("gru", 800, 64, 2), ("gru", 800, 32, 2), ("gru", 64, 17, 2), ("lstm", 512, 48, 2), ("rnn", 96, 64, 2),
+         ("gru", 896, 40, 2), ("lstm", 64, 32, 2), ("gru", 800, 128, 2), ("gru", 800, 72, 1), ("gru", 800, 128, 1),
+         ("gru", 48, 70, 2), ("gru", 16, 33, 2), ("rnn", 160, 100, 1)]
+
+
+@pytest.mark.parametrize("kind,H,B,inflight", CASES)
+def test_ring_kernel_equals_oracle_and_the_older_kernels(native, kind, H, B, inflight):
+    from oracle import torch_port as tp
+    cfg = _cfg(H, 2, kind=kind)
+    sd = syn.make_state_dict(2, kind, H, 2, seed=71, **syn.TALKATIVE)
+    x, lens = _batch(B=B, T=181, seed=72)
+    ref, ol_ref = tp.forward(sd, cfg, x, lens)
+    m = native.NativeModel(cfg, sd)
+    m.set_inflight(inflight)
+    m.set_profiling(2)
+    p, ol = m.forward(_dev(x), lens)
+    assert np.array_equal(ol, ol_ref) and m.recompute_count() == 0
+    ring = p.cpu().numpy()
+    m.close()
+    with _env(DSMI_RNN_KERNEL="duo"):
+        m = native.NativeModel(cfg, sd)
+    m.set_inflight(inflight)
+    p, ol = m.forward(_dev(x), lens)
+    old = p.cpu().numpy()
+    m.close()
+    for b in range(B):
+        np.testing.assert_allclose(ring[b, :ol_ref[b]], ref[b, :ol_ref[b]], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(ring[b, :ol_ref[b]], old[b, :ol_ref[b]], rtol=0, atol=5e-5)
+
+
+def test_ring_kernel_is_what_runs(native):
+    """Two batches in flight, cfgA's width: one launch per layer on H / 32 x 2 = 50 workgroups."""
+    cfg = _cfg(800, 2)
+    sd = syn.make_state_dict(2, "gru", 800, 2, seed=73)
+    x, lens = _batch(B=64, T=101, seed=74)
+    m = native.NativeModel(cfg, sd)
+    m.set_inflight(2)
+    m.set_profiling(2)
+    m.forward(_dev(x), lens)
+    ks = m.kernel_stats()["rnn_layer_persistent"]
+    assert ks["launches"] == 2, ks
+    m.close()
+
+
+def test_ring_kernel_timeout_is_recomputed(native):
+    """A workgroup that never signals one step of chain 0: the poll of that step times out, the error word is raised, the
+    forward's status reports it and the SAME batch is recomputed on the per-step path (api.hip collect_oldest)."""
+    from oracle import torch_port as tp
+    cfg = _cfg(64, 2)
+    sd = syn.make_state_dict(2, "gru", 64, 2, seed=75, **syn.TALKATIVE)
+    x, lens = _batch(B=56, T=161, seed=76)
+    ref, _ = tp.forward(sd, cfg, x, lens)
+    with _env(DSMI_DEBUG_DROP_SIGNAL="1:1:9", DSMI_DEBUG_SPIN_LIMIT="3000"):
+        m = native.NativeModel(cfg, sd)
+    m.set_inflight(2)
+    with warnings.catch_warnings(record=True):
+        warnings.simplefilter("always")
+        p, ol = m.forward(_dev(x), lens, check=False)
+        assert m.status() is True
+    assert m.recompute_count() == 1
+    pn = p.cpu().numpy()
+    for b in range(56):
+        np.testing.assert_allclose(pn[b, :ol[b]], ref[b, :ol[b]], rtol=0, atol=1e-4)
+    m.close()
+
+
+def test_four_ring_layers_in_flight_on_four_handles(native):
+    """Four handles with batches in flight: each layer is one window on the handle's own gate slot, four side by side."""
+    from oracle import torch_port as tp
+    cfg = _cfg(800, 2)
+    sd = syn.make_state_dict(2, "gru", 800, 2, seed=77, **syn.TALKATIVE)
+    models = [native.NativeModel(cfg, sd) for _ in range(4)]
+    for m in models:
+        m.set_inflight(2)
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    batches = [_batch(B=B, T=T, seed=80 + k) for k, (B, T) in enumerate([(64, 201), (32, 257), (48, 181), (20, 301)])]
+    refs = [tp.forward(sd, cfg, x, lens)[0] for x, lens in batches]
+    xs = [_dev(x) for x, _ in batches]
+    torch.cuda.synchronize()
+    for rep in range(3):
+        outs = []
+        for k in range(4):
+            with torch.cuda.stream(streams[k]):
+                outs.append(models[k].forward(xs[k], batches[k][1], check=False))
+        for k in range(4):
+            assert models[k].status() is False
+            p, ol = outs[k]
+            pn = p.cpu().numpy()
+            for b in range(pn.shape[0]):
+                np.testing.assert_allclose(pn[b, :ol[b]], refs[k][b, :ol[b]], rtol=0, atol=1e-4)
+    for m in models:
+        assert m.recompute_count() == 0
+        m.close()

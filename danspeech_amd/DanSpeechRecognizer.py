@@ -152,6 +152,12 @@ class DanSpeechRecognizer(object):
         model = model or self.model
         if isinstance(recordings, DeviceClips):             # already on the device, longest first
             order = np.arange(len(recordings))
+            # the clips were produced on whatever stream was current when the batch was handed over (an RCCL scatter, a widening
+            # copy, a slicing kernel): the stream this batch runs on waits for that point, and the allocator learns of the use
+            here = torch.cuda.current_stream(self._device_index())
+            if isinstance(staged, torch.cuda.Event):
+                here.wait_event(staged)
+            recordings.pcm.record_stream(here)
             feats, frames = (parser or self.audio_parser).parse_batch(recordings)
         else:
             if staged is not None:
@@ -245,7 +251,12 @@ class DanSpeechRecognizer(object):
         def fetch(parser):
             nxt = next(source, end)
             ahead = None
-            if nxt is not end and len(nxt) and not isinstance(nxt, DeviceClips) and hasattr(parser, "stage"):
+            if nxt is not end and len(nxt) and isinstance(nxt, DeviceClips):
+                # device-resident clips: ordered behind whatever produced them on the caller's stream (every second batch runs on
+                # the side stream, which nothing else orders behind the caller's)
+                ahead = torch.cuda.Event()
+                ahead.record(streams[0])
+            elif nxt is not end and len(nxt) and hasattr(parser, "stage"):
                 ahead = self._stage_batch(nxt, parser)
             return nxt, ahead
 

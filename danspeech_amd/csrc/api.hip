@@ -569,7 +569,7 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
         if (cap > 0) {
             const int ntiles = ceil_div(B, 16);
             const int slots = m->inflight >= 2 ? 1 : kMaxLanes;
-            ring_ntw = std::min(std::max(ceil_div(ntiles, slots), 1), 8);
+            ring_ntw = std::min(std::max(ceil_div(ntiles, slots), 1), cap);
             if (m->inflight < 2) ring_ntw = std::max(ring_ntw, std::min(ntiles, 2));
             ring_nwin = std::min(ceil_div(ntiles, ring_ntw), slots);
             duo = false;
@@ -1111,7 +1111,7 @@ extern "C" int dsmi_debug_persist_stamps(dsmi_model* m, int layer, int B, int To
 }
 
 static int ring_stamps(dsmi_model* m, int layer, int B, int To, uint64_t* stamps_host, int64_t n_words) {
-    if (B < 1 || B > 128 || layer < 0 || layer >= m->desc.rnn_layers || !m->have16 ||
+    if (B < 1 || B > 64 || layer < 0 || layer >= m->desc.rnn_layers || !m->have16 ||
         rnn_persist_ring_tiles(m->geom16, B, m->n_cus) < ceil_div(B, 16)) return DSMI_ERR_INVALID;
     int Tin = To;
     while (seq_len(m, Tin) < To) Tin += 1;

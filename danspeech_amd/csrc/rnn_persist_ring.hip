@@ -32,6 +32,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 namespace dsmi {
 
@@ -41,9 +42,8 @@ constexpr int RNT = 512;               // 8 waves: two halves of four (K-split i
 constexpr int RU = 16;                 // hidden units per half
 constexpr int RB = 16;                 // clips per batch tile
 constexpr int RRP = 20;                // row pitch (words) of the reduce buffers
-constexpr int RMAXT = 8;               // tiles one launch can walk
-constexpr int RMINT = 4;               // schedule length in tiles: fewer real tiles are padded with phantom ones (the poll of an
-                                       // item comes 2 * NT - 3 slots after its M slot, the signal 3: NT >= 4)
+constexpr int RMINT = 4;               // schedule length in tiles = tiles a window walks at most: fewer real tiles are padded with phantom
+                                       // ones (the poll of an item comes 2 * NT - 3 slots after its M slot, the signal 3: NT >= 4)
 
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
@@ -58,6 +58,8 @@ struct RingArgs {
     int tile0, ntw, tile_end;  // window z (blockIdx.z) walks tiles tile0 + z * ntw .. + ntw - 1, below tile_end
     unsigned spin_limit;
     int drop_wg, drop_step;
+    int skip;                  // timing experiments only (DSMI_DEBUG_RING_SKIP; results are garbage): 1 no state DMA, 2 no MFMAs, 4 no polls,
+                               // 8 no x-projection requests, 16 no output / publish stores
     unsigned long long* dbg;   // diagnostics build only: per wave, 100 MHz ticks: [0] M work, [1] M-end waits, [2] C work, [3] barrier
                                // behind M, [4] barrier behind C, [5] poll spin; [7] slots; shader cycles: [6] M work, [8] M head (to the
                                // first operands' arrival), [9] MFMA loop, [10] partial tiles -> LDS, [11] DMA requests, [12] reduce + cell,
@@ -69,7 +71,8 @@ struct RingArgs {
         if (STAMP) {                                                                       \
             __builtin_amdgcn_sched_barrier(0);                                             \
             const unsigned long long now_ = __builtin_amdgcn_s_memtime();                  \
-            tacc[k] += now_ - clast; clast = now_;                                         \
+            if ((threadIdx.x & 63) == 0) tacc[k] += now_ - clast;                          \
+            clast = now_;                                                                  \
             __builtin_amdgcn_sched_barrier(0);                                             \
         }                                                                                  \
     } while (0)
@@ -81,20 +84,27 @@ __device__ __forceinline__ void ring_dma(const void* gbase, unsigned voff, unsig
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1" :: "s"(lds_addr), "v"(voff), "s"(gbase) : "memory");
 }
 
+// The schedule is RMINT = 4 tiles long and unrolled over the tiles: which ring slot, which neighbour items a slot signals,
+// polls, requests and prefetches for are compile-time, and what depends on the tile alone (chain, counters, row blocks)
+// is computed once; a slot's scalar work is a handful of additions.
 template <int KIND, int NKW, bool STAMP = false>
 __global__ __launch_bounds__(RNT, 2) void rnn_persist_ring_kernel(RingArgs p) {
-    unsigned long long tacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long clast = 0;
     constexpr int NG = KIND == DSMI_RNN_GRU ? 3 : (KIND == DSMI_RNN_LSTM ? 4 : 1);
+    constexpr int NT = RMINT;
     extern __shared__ __attribute__((aligned(16))) unsigned char rlds[];
     const int sbytes = p.nkb * 2048;
     unsigned char* sbuf = rlds;                                                   // [2 ring slots][nkb][2 planes][1024]
     float* red_all = reinterpret_cast<float*>(rlds + 2 * sbytes);                 // [2 halves][4 waves][NG][16 units][RRP]
-    float* st_h = red_all + 2 * 4 * NG * 16 * RRP;                               // [RMAXT][512] own previous state per (tile, thread)
-    float* st_c = st_h + RMAXT * RNT;                                             // LSTM only: [RMAXT][512]
-    unsigned short* stg = reinterpret_cast<unsigned short*>(st_c + (KIND == DSMI_RNN_LSTM ? RMAXT * RNT : 0));   // [8 waves][128]
+    float* st_h = red_all + 2 * 4 * NG * 16 * RRP;                               // [NT][512] own previous state per (tile, thread)
+    float* st_c = st_h + NT * RNT;                                                // LSTM only: [NT][512]
+    unsigned short* stg = reinterpret_cast<unsigned short*>(st_c + (KIND == DSMI_RNN_LSTM ? NT * RNT : 0));   // [8 waves][128]
     float* xgl = reinterpret_cast<float*>(stg + 8 * 128);                         // [2 halves][NG][256] x-projection of the half's next cell item
-    int* st_len = reinterpret_cast<int*>(xgl + 2 * NG * 256);                     // [RMAXT][16]
-    int* sync = st_len + RMAXT * 16;                                              // [0] dead flag, [8] drained-waves counter
+    int* st_len = reinterpret_cast<int*>(xgl + 2 * NG * 256);                     // [NT][16]
+    int* sync = st_len + NT * 16;                                                 // [0] dead flag, [8] drained-waves counter
+    // diagnostics build: the accumulated stamps live in LDS (sixteen 8-byte words per wave) -- in registers they cost the kernel 32
+    // of the 256 it is built around, and a stamped build that spills measures the spills
+    unsigned long long* tacc = reinterpret_cast<unsigned long long*>(sync + 32) + (STAMP ? (threadIdx.x >> 6) * 16 : 0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int v = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hx = v >> 2, vh = v & 3;
@@ -102,16 +112,16 @@ __global__ __launch_bounds__(RNT, 2) void rnn_persist_ring_kernel(RingArgs p) {
     const int ln = lane & 15, lg = lane >> 4;
     const int w32 = blockIdx.x, d = blockIdx.y;
     const int tile0 = p.tile0 + (int)blockIdx.z * p.ntw;
-    const int nt = min(p.ntw, p.tile_end - tile0);
+    const int nt = min(min(p.ntw, p.tile_end - tile0), NT);
     const int w16 = 2 * w32 + hx;
     const bool half_ok = w16 < p.nwg16;
     const int nwg32 = (p.nwg16 + 1) >> 1;
     const int GU = NG * RU;
-    const size_t xcol = (size_t)d * p.nwg16 * GU + (size_t)w16 * GU;
     float* red = red_all + hx * (4 * NG * 16 * RRP);
-    for (int i = tid; i < RMAXT * RNT; i += RNT) { st_h[i] = 0.f; if (KIND == DSMI_RNN_LSTM) st_c[i] = 0.f; }
+    for (int i = tid; i < NT * RNT; i += RNT) { st_h[i] = 0.f; if (KIND == DSMI_RNN_LSTM) st_c[i] = 0.f; }
     if (tid < 32) sync[tid] = 0;
-    if (tid < RMAXT * 16) {
+    if (STAMP && lane < 16) tacc[lane] = 0;
+    if (tid < NT * 16) {
         const int tl = tid >> 4, eb = (tile0 + tl) * RB + (tid & 15);
         st_len[tid] = (tl < nt && eb < p.B) ? p.lens[eb] : 0;
     }
@@ -130,11 +140,25 @@ __global__ __launch_bounds__(RNT, 2) void rnn_persist_ring_kernel(RingArgs p) {
                 for (int pl = 0; pl < 2; ++pl) wv[i][g][pl] = __builtin_bit_cast(f16x8, wp[(((size_t)kb * NG + g) * 2 + pl) * 64]);
         }
     }
-    const size_t hp_par = (size_t)p.D * p.ntiles * p.nkb * 2048;     // bytes per parity
+    const unsigned hp_par = (unsigned)((size_t)p.D * p.ntiles * p.nkb * 2048);     // bytes per parity
     const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.hpack, 0, (int)(2 * hp_par), 0x00020000);
+    float* outd = p.out[d];
+    asm volatile("" : "+s"(outd));          // held in registers: indexed by d, the compiler would re-load it from the kernel arguments per slot
     const unsigned lds_sbuf = (unsigned)(size_t)sbuf;
+    const unsigned lane16 = (unsigned)lane * 16u;
+    const unsigned char* sbr = sbuf + lane16 + kb0 * 2048;       // this lane's fragment of its wave's first k-block, ring slot 0
 
-    // cell role inside the half: thread -> (unit cu = 8 * (tidh >> 7) + (tidh & 7), clip cj = (tidh >> 3) & 15)
+    // ---- what depends on the tile alone is affine in the tile index (uniform): base of tile 0 + J * stride, J compile-time
+    const int chain0 = d * p.ntiles + tile0;
+    unsigned hch0 = (unsigned)chain0 * (unsigned)(p.nkb * 2048), hchs_ = (unsigned)(p.nkb * 2048);      // state bytes of a chain
+    unsigned cnt0 = (unsigned)chain0 * (unsigned)p.T * kPersist16CntWords, cnts_ = (unsigned)p.T * kPersist16CntWords;   // counter words
+    unsigned orow0 = (unsigned)tile0 * RB * p.Hs, orows_ = (unsigned)(RB * p.Hs);      // elements inside a step's [B][Hs] block
+    unsigned xrow0 = (unsigned)tile0 * RB * p.Np, xrows_ = (unsigned)(RB * p.Np);
+unsigned hchs = hchs_, cnts = cnts_, orows = orows_, xrows = xrows_;
+#define TOK(J) ((J) < nt)
+
+    // ---- cell role inside the half: thread -> (unit cu = 8 * (tidh >> 7) + (tidh & 7), clip cj = (tidh >> 3) & 15); everything a
+    // thread needs per item is a uniform base plus one of these per-thread constants
     const int cuh = tidh >> 7, ce = tidh & 7, cj = (tidh >> 3) & 15;
     const int cu = 8 * cuh + ce;
     const int cunit = w16 * RU + cu;
@@ -142,210 +166,298 @@ __global__ __launch_bounds__(RNT, 2) void rnn_persist_ring_kernel(RingArgs p) {
     float bh[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g) bh[g] = cunit_ok ? p.bhh[d][g * p.H + cunit] : 0.f;
+    const int nb_last = p.B - (tile0 + nt - 1) * RB;                                   // clips of the window's last real tile (may exceed 16)
+    unsigned actbits = 0;                                                              // bit j: this thread's (unit, clip) exists in tile j
+#pragma unroll
+    for (int j = 0; j < NT; ++j) actbits |= (unsigned)(cunit_ok && j < nt && (j < nt - 1 || cj < nb_last)) << j;
+    unsigned o_el = (unsigned)(cj * p.Hs + (half_ok ? cunit : 0));               // element of an out row block [16 clips][Hs]
+    const unsigned xcol = half_ok ? (unsigned)((d * p.nwg16 + w16) * GU + cu) : 0u;
+    unsigned x_by = ((unsigned)cj * p.Np + xcol) * 4u;                          // byte offset inside an x-projection row block
+    unsigned x_by_last = ((unsigned)min(cj, nb_last - 1) * p.Np + xcol) * 4u;   // ... clamped to the last tile's clips
+    const float* redr = red + cu * RRP + cj;
+    unsigned pub_off = (unsigned)(w16 >> 1) * 2048u + (unsigned)(2 * (w16 & 1) + cuh) * 256u + (unsigned)cj * 16u;   // hi plane; lo at + 1024
     const unsigned shard = (unsigned)(w32 & (kPersist16Shards - 1)) * 64u;
-    const int nte = max(nt, RMINT);
-    const int NQ = p.T * nte;
-
-    // x-projection operands of a cell item (step s, tile j), clamped so that the requests are always legal: by LDS-DMA, 4 bytes
-    // per lane, into this thread's own words of xgl -- no register is held across the MFMA slot in between, and the compiler,
-    // which does not see the requests, puts no wait for them in front of anything
+    const unsigned need = (unsigned)((nwg32 + kPersist16Shards - 1 - (lane & (kPersist16Shards - 1))) / kPersist16Shards);
     const unsigned lds_xg = (unsigned)(size_t)xgl + (unsigned)((hx * NG * 256 + vh * 64) * 4);
     const float* xgr = xgl + hx * NG * 256 + tidh;
-    auto load_xg = [&](int s, int j) {
-        const int eb = min((tile0 + min(j, nt - 1)) * RB + cj, p.B - 1);
-        const int t = d == 0 ? s : p.T - 1 - s;
-        const float* xr = p.xp + ((size_t)t * p.B + eb) * p.Np + (half_ok ? xcol : 0) + cu;
+    unsigned pollv = 0;             // B's wave 0: the counter shard this lane read at the start of its MFMA slot
+
+    // x-projection operands of a cell item of tile J, from the step whose rows start at xstep: by LDS-DMA, 4 bytes per lane, into
+    // this thread's own words of xgl -- no register is held across the MFMA slot in between, and the compiler, which does not
+    // see the requests, waits for nothing
+    auto xg_request = [&](auto jc, const float* xstep) {
+        constexpr int J = decltype(jc)::value;
+        const float* row = xstep + (xrow0 + min(J, nt - 1) * xrows);       // (a phantom tile's request is clamped into the batch)
+        const unsigned by = J >= nt - 1 ? x_by_last : x_by;
+        if (p.skip & 8) return;
+        const unsigned lx = lds_xg;         // (a local copy: an asm operand inside a generic lambda does not capture by itself)
 #pragma unroll
         for (int g = 0; g < NG; ++g)
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" :: "s"(lds_xg + g * 1024), "v"(xr + g * RU) : "memory");
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" :: "s"(lx + g * 1024), "v"(by + g * RU * 4), "s"(row) : "memory");
     };
-    load_xg(0, 0);
-    unsigned pollv = 0;             // B's wave 0: the counter shard this lane read at the start of its MFMA slot
+
+    // MFMAs of an item of tile J at step s (B operands from ring slot J & 1), partial tiles -> LDS
+    auto mfma_item = [&](auto jc, int s) {
+        constexpr int J = decltype(jc)::value;
+        if (!TOK(J)) return;
+        const bool no_mfma = p.skip & 2;
+        f32x4 acc[NG], acl[NG];        // hi.hi ; (hi.lo + lo.hi) * 2^11
+#pragma unroll
+        for (int g = 0; g < NG; ++g) { acc[g] = f32x4{0.f, 0.f, 0.f, 0.f}; acl[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        if (s > 0 && !no_mfma) {
+            const unsigned char* sb = sbr + (J & 1) * sbytes;
+            f16x8 bc[2], bn[2];
+            bc[0] = *reinterpret_cast<const f16x8*>(sb);
+            bc[1] = *reinterpret_cast<const f16x8*>(sb + 1024);
+            if (STAMP) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); RSTAMP(8); }
+#pragma unroll
+            for (int i = 0; i < NKW; ++i) {
+                if (i + 1 < NKW) {          // (a wave with NKW - 1 blocks reads its neighbour's first one here and does not use it)
+                    bn[0] = *reinterpret_cast<const f16x8*>(sb + (i + 1) * 2048);
+                    bn[1] = *reinterpret_cast<const f16x8*>(sb + (i + 1) * 2048 + 1024);
+                }
+                __builtin_amdgcn_sched_barrier(0);     // the next block's operands are requested BEFORE this block's MFMAs
+                if (i + 1 < NKW || kb0 + i < kb1) {
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) acl[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[i][g][1], bc[0], acl[g], 0, 0, 0);
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[i][g][0], bc[0], acc[g], 0, 0, 0);
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) acl[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[i][g][0], bc[1], acl[g], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                bc[0] = bn[0]; bc[1] = bn[1];
+            }
+            RSTAMP(9);
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                red[((vh * NG + g) * 16 + 4 * lg + r) * RRP + ln] = acc[g][r] + acl[g][r] * kLoInv;
+        if (STAMP) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); RSTAMP(10); }
+    };
+
+    // B's DMA requests for an item of tile J whose chain's previous step lies at parity offset `par`: each wave brings the k-blocks
+    // it will multiply, into ring slot J & 1, in four groups (G = 0..3) placed between the parts of the cell -- the texture path
+    // takes a 1-KiB piece per ~80 cycles, and a wave that asks faster stands at the request instead of working.  One base (M0, scalar
+    // address) serves two k-blocks: the instruction offset applies to the global AND the LDS address (tools/exp/dma_off_probe.hip).
+    auto dma_group = [&](auto jc, auto gc, bool on, unsigned par) {
+        constexpr int J = decltype(jc)::value, G = decltype(gc)::value;
+        constexpr int i = 2 * G;
+        if (i >= NKW || !on || !TOK(J) || (p.skip & 1)) return;
+        const unsigned char* gsrc = reinterpret_cast<const unsigned char*>(p.hpack) + (par + hch0 + J * hchs + (unsigned)(kb0 + i) * 2048u);
+        const unsigned ldst = lds_sbuf + (unsigned)((J & 1) * sbytes) + (unsigned)(kb0 + i) * 2048u;
+        const unsigned l16 = lane16;
+        if (i + 1 < NKW || kb0 + i < kb1)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024 sc1"
+                         :: "s"(ldst), "v"(l16), "s"(gsrc) : "memory");
+        if (i + 1 < NKW && (i + 2 < NKW || kb0 + i + 1 < kb1))
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:2048 sc1\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072 sc1"
+                         :: "s"(ldst), "v"(l16), "s"(gsrc) : "memory");
+    };
+
+    // Cell of an item of tile J: K-split reduction (fixed order), cell, own state, output row, publish -- one (unit, clip) pair per
+    // thread.  t: time index; ostep: the step's output rows; parw: parity offset the new state is written at.  DJ / don / dpar:
+    // the item B requests meanwhile (dma_group).  The slot is a chain of latencies in ONE wave per SIMD (the partner multiplies), so
+    // it is kept short: every LDS read goes out first, and the publish needs no LDS -- the eight lanes of a clip hand their
+    // (hi | lo << 16) words to the clip's first lane by DPP row shifts, which stores both planes' 16 bytes.
+    auto cell_item = [&](auto jc, int t, float* ostep, unsigned parw, auto djc, bool don, unsigned dpar) {
+        constexpr int J = decltype(jc)::value;
+        constexpr std::integral_constant<int, 0> G0; constexpr std::integral_constant<int, 1> G1;
+        constexpr std::integral_constant<int, 2> G2; constexpr std::integral_constant<int, 3> G3;
+        if (!TOK(J)) { dma_group(djc, G0, don, dpar); dma_group(djc, G1, don, dpar); dma_group(djc, G2, don, dpar); dma_group(djc, G3, don, dpar); return; }
+        float rv[NG][4], xg[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rv[g][k] = redr[(k * NG + g) * 16 * RRP];
+            xg[g] = xgr[g * 256];
+        }
+        const int mylen = st_len[J * 16 + cj];
+        const float hprev = st_h[J * RNT + tid];
+        float cprev = KIND == DSMI_RNN_LSTM ? st_c[J * RNT + tid] : 0.f;
+        __builtin_amdgcn_sched_barrier(0);
+        dma_group(djc, G0, don, dpar);
+        dma_group(djc, G1, don, dpar);
+        RSTAMP(11);
+        __builtin_amdgcn_sched_barrier(0);
+        float hg[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) hg[g] = ((rv[g][0] + rv[g][1]) + rv[g][2]) + rv[g][3] + bh[g];
+        const bool act = (actbits >> J) & 1u;
+        float hn = rnn_cell<KIND, true>(xg, hg, hprev, cprev, t < mylen);
+        hn = act ? hn : 0.f;
+        st_h[J * RNT + tid] = hn;
+        if (KIND == DSMI_RNN_LSTM) st_c[J * RNT + tid] = cprev;
+        const _Float16 h1 = (_Float16)hn;
+        const _Float16 h2 = (_Float16)((hn - (float)h1) * kLoScale);
+        const unsigned pk = (unsigned)__builtin_bit_cast(unsigned short, h1) | ((unsigned)__builtin_bit_cast(unsigned short, h2) << 16);
+        unsigned u[8];
+        u[0] = pk;
+        u[1] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pk, 0x101, 0xF, 0xF, false);      // row_shl:n: lane i receives lane i + n's word
+        u[2] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pk, 0x102, 0xF, 0xF, false);
+        u[3] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pk, 0x103, 0xF, 0xF, false);
+        u[4] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pk, 0x104, 0xF, 0xF, false);
+        u[5] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pk, 0x105, 0xF, 0xF, false);
+        u[6] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pk, 0x106, 0xF, 0xF, false);
+        u[7] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pk, 0x107, 0xF, 0xF, false);
+        u32x4 phi, plo;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            phi[m] = __builtin_amdgcn_perm(u[2 * m + 1], u[2 * m], 0x05040100u);     // low halves: units 2m, 2m + 1 of the hi plane
+            plo[m] = __builtin_amdgcn_perm(u[2 * m + 1], u[2 * m], 0x07060302u);     // high halves: the lo plane
+        }
+        RSTAMP(12);
+        __builtin_amdgcn_sched_barrier(0);
+        dma_group(djc, G2, don, dpar);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(p.skip & 16)) {
+            if (ce == 0 && half_ok) {
+                __builtin_amdgcn_raw_buffer_store_b128(phi, hrs, pub_off, parw + hch0 + J * hchs, 16);
+                __builtin_amdgcn_raw_buffer_store_b128(plo, hrs, pub_off + 1024u, parw + hch0 + J * hchs, 16);
+            }
+            if (act) ((__attribute__((address_space(1))) float*)(ostep + (orow0 + J * orows)))[o_el] = hn;      // (a global_, not a flat_ store)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        dma_group(djc, G3, don, dpar);
+    };
+
+    // end of an MFMA slot: everything this wave requested in its last cell slot -- publish stores (drained), B's DMA (landed),
+    // x-projection (arrived)
+    auto m_end_wait = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0x0F70);      // the same wait where the compiler sees it: nothing of this wave's is in flight
+    };
+    // B, at the start of its cell slot: step `ss` of tile J's chain is published by this workgroup -- both halves' stores of that item
+    // were drained before the barrier that opened this slot (A's a slot earlier)
+    auto signal_item = [&](auto jc, int ss, bool on) {
+        constexpr int J = decltype(jc)::value;
+        if (vh == 0 && on && TOK(J)) {
+            const bool drop = d == 0 && tile0 + J == 0 && w32 == p.drop_wg && ss == p.drop_step;
+            if (lane == 0 && !drop)
+                __hip_atomic_fetch_add(p.cnt + (cnt0 + J * cnts + (unsigned)ss * kPersist16CntWords + shard), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    // B's wave 0: has step `sp` of tile J's chain been published by every workgroup?  Asked at the start of the MFMA slot (the raw
+    // word only, at ONE place per slot: a select there, or a second request site, makes the compiler wait for the load, and with it
+    // for every request of the wave's last cell slot, in front of the MFMAs), answered behind it.
+    auto poll_issue = [&](auto jc, int sp, bool on) {
+        constexpr int J = decltype(jc)::value;
+        if (on && TOK(J) && vh == 0 && lane < kPersist16Shards && !(p.skip & 4))
+            pollv = __hip_atomic_load(p.cnt + (cnt0 + J * cnts + (unsigned)sp * kPersist16CntWords + lane * 64), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto poll_finish = [&](auto jc, int sp, bool on) {
+        constexpr int J = decltype(jc)::value;
+        if (on && TOK(J) && vh == 0 && !sync[0] && !(p.skip & 4)) {
+            unsigned long long tp_ = 0;
+            if (STAMP) tp_ = __builtin_amdgcn_s_memrealtime();
+            const unsigned* cp = p.cnt + (cnt0 + J * cnts + (unsigned)sp * kPersist16CntWords + (lane & (kPersist16Shards - 1)) * 64);
+            unsigned spins = 0;
+            unsigned got = lane < kPersist16Shards ? pollv : need;
+            while (__builtin_amdgcn_ballot_w64(got < need) != 0) {
+                __builtin_amdgcn_s_sleep(1);
+                ++spins;
+                if ((spins & 1023u) == 0 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { sync[0] = 1; break; }
+                if (spins > p.spin_limit) { atomicExch(p.err, 1u); sync[0] = 1; break; }
+                got = lane < kPersist16Shards ? __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need;
+            }
+            if (STAMP && lane == 0) tacc[5] += __builtin_amdgcn_s_memrealtime() - tp_;
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // (free here: every poll has been consumed) no load is pending at the loop's back edge
+    };
+
+    if (hx == 0) xg_request(std::integral_constant<int, 0>{}, p.xp + (size_t)(d == 0 ? 0 : p.T - 1) * p.B * p.Np);
     // through the builtin, so that the compiler knows the prologue's loads (W_hh, biases, lengths) have arrived: told by inline
     // assembly it would wait for them at their first use INSIDE the loop, where vmcnt(0) also waits for that slot's requests
     __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     ring_barrier();
 
-    const int nslots = 2 * NQ + 1;
-    for (int gs = 0; gs < nslots; ++gs) {
-        const bool mrole = (gs & 1) == hx;
-        const int q = mrole ? (gs - hx) >> 1 : (gs - 1 - hx) >> 1;
-        const bool q_ok = q >= 0 && q < NQ;
-        const int s = q_ok ? q / nte : 0, j = q_ok ? q - s * nte : 0;
-        const bool tile_ok = q_ok && j < nt;
-        unsigned long long t0_ = 0, c0_ = 0, t1_ = 0, t2_ = 0, clast = 0;
-        if (STAMP) { __builtin_amdgcn_sched_barrier(0); t0_ = __builtin_amdgcn_s_memrealtime(); c0_ = __builtin_amdgcn_s_memtime(); clast = c0_; __builtin_amdgcn_sched_barrier(0); }
-        if (mrole) {
-            // ---- B's wave 0 asks whether item q + 2's chain has finished its previous step; the answer is read behind the MFMAs
-            const int qp = q + 2;
-            const int sp = qp / nte, jp = qp - sp * nte;
-            const bool poll = hx == 1 && vh == 0 && qp < NQ && sp >= 1 && jp < nt;
-            const unsigned* cp = p.cnt + ((size_t)(d * p.ntiles + tile0 + (poll ? jp : 0)) * p.T + (poll ? sp - 1 : 0)) * kPersist16CntWords +
-                                 (lane & (kPersist16Shards - 1)) * 64;
-            const unsigned need = (unsigned)((nwg32 + kPersist16Shards - 1 - (lane & (kPersist16Shards - 1))) / kPersist16Shards);
-            if (poll) {
-                pollv = lane < kPersist16Shards ? __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need;
-                __builtin_amdgcn_sched_barrier(0);
+    // Stamps (diagnostics build): [0] M work, [1] M-end waits, [2] C work, [3] barrier behind M, [4] barrier behind C in 100 MHz ticks
+    unsigned long long tm0 = 0, tm1 = 0;
+#define RT_BEGIN() do { if (STAMP) { __builtin_amdgcn_sched_barrier(0); tm0 = __builtin_amdgcn_s_memrealtime(); clast = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#define RT_MARK(k) do { if (STAMP) { __builtin_amdgcn_sched_barrier(0); tm1 = __builtin_amdgcn_s_memrealtime(); if ((threadIdx.x & 63) == 0) tacc[k] += tm1 - tm0; tm0 = tm1; __builtin_amdgcn_sched_barrier(0); } } while (0)
+
+    const size_t ostride = (size_t)p.B * p.Hs, xstride = (size_t)p.B * p.Np;
+    for (int s = 0; s < p.T; ++s) {
+        const int t = d == 0 ? s : p.T - 1 - s;
+        float* ostep = outd + (size_t)t * ostride;
+        const float* xstep = p.xp + (size_t)t * xstride;
+        const unsigned parw = (unsigned)(s & 1) * hp_par;            // parity offset this step's cells write h_s at
+        const unsigned parr = hp_par - parw;                          // ... and its MFMAs read h_(s-1) from (= where step s + 1 writes)
+        const bool more = s + 1 < p.T;
+        // opaque per step: what is derived from these (a dozen addresses per unrolled tile and half) is recomputed where it is
+        // used -- an addition -- instead of being hoisted out of the loop into registers the kernel does not have
+        asm volatile("" : "+s"(hch0), "+s"(cnt0), "+s"(orow0), "+s"(xrow0), "+s"(hchs), "+s"(cnts), "+s"(orows), "+s"(xrows));
+        asm volatile("" : "+v"(o_el), "+v"(x_by), "+v"(x_by_last), "+v"(pub_off));
+        const int tn = d == 0 ? s + 1 : p.T - 2 - s;
+        const float* xnext = p.xp + (size_t)(more ? tn : t) * xstride;
+        auto slots = [&](auto jc) {
+            constexpr int J = decltype(jc)::value;
+            constexpr std::integral_constant<int, (J + 1) % NT> JN;          // next item's tile
+            constexpr std::integral_constant<int, (J + NT - 1) % NT> JP;     // previous item's tile
+            constexpr std::integral_constant<int, (J + 2) % NT> JQ;          // tile of the item two ahead
+            // ---------------- even slot 2q: A multiplies item (s, J); B finishes item q - 1 and requests item q + 1's state
+            RT_BEGIN();
+            if (hx == 0) {
+                mfma_item(jc, s);
+                RT_MARK(0);
+                m_end_wait();
+                RT_MARK(1);
+            } else {
+                // item q - 2, whose stores B drained at the end of the slot before this one: (s, J - 2), or (s - 1, J + 2)
+                if (J >= 2) signal_item(JQ, s, true); else signal_item(JQ, s - 1, s >= 1);
+                // item q + 1 = (s, J + 1) reads h_(s-1) [needs s >= 1], or (s + 1, 0) reads h_s
+                const bool don = J + 1 < NT ? s >= 1 : more;
+                const unsigned dpar = J + 1 < NT ? parr : parw;
+                if (J >= 1) cell_item(JP, t, ostep, parw, JN, don, dpar);
+                else if (s >= 1) cell_item(JP, d == 0 ? t - 1 : t + 1, d == 0 ? ostep - ostride : ostep + ostride, parr, JN, don, dpar);
+                else { constexpr std::integral_constant<int, 0> G0; constexpr std::integral_constant<int, 1> G1;
+                       constexpr std::integral_constant<int, 2> G2; constexpr std::integral_constant<int, 3> G3;
+                       dma_group(JN, G0, don, dpar); dma_group(JN, G1, don, dpar); dma_group(JN, G2, don, dpar); dma_group(JN, G3, don, dpar); }
+                xg_request(jc, xstep);          // B's next cell item: q = (s, J)
+                RSTAMP(13);
+                RT_MARK(2);
             }
-            if (tile_ok) {
-                f32x4 acc[NG], acl[NG];        // hi.hi ; (hi.lo + lo.hi) * 2^11
-#pragma unroll
-                for (int g = 0; g < NG; ++g) { acc[g] = f32x4{0.f, 0.f, 0.f, 0.f}; acl[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-                if (s > 0) {
-                    const unsigned char* sb = sbuf + (q & 1) * sbytes + lane * 16;
-                    f16x8 bc[2], bn[2];
-                    bc[0] = *reinterpret_cast<const f16x8*>(sb + (kb0 * 2) * 1024);
-                    bc[1] = *reinterpret_cast<const f16x8*>(sb + (kb0 * 2 + 1) * 1024);
-                    if (STAMP) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); RSTAMP(8); }
-#pragma unroll
-                    for (int i = 0; i < NKW; ++i) {
-                        if (i + 1 < NKW) {
-                            const int kbn = min(kb0 + i + 1, max(kb1 - 1, kb0));
-                            bn[0] = *reinterpret_cast<const f16x8*>(sb + (kbn * 2) * 1024);
-                            bn[1] = *reinterpret_cast<const f16x8*>(sb + (kbn * 2 + 1) * 1024);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);     // the next block's operands are requested BEFORE this block's MFMAs
-                        if (i + 1 < NKW || kb0 + i < kb1) {
-#pragma unroll
-                            for (int g = 0; g < NG; ++g) acl[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[i][g][1], bc[0], acl[g], 0, 0, 0);
-#pragma unroll
-                            for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[i][g][0], bc[0], acc[g], 0, 0, 0);
-#pragma unroll
-                            for (int g = 0; g < NG; ++g) acl[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[i][g][0], bc[1], acl[g], 0, 0, 0);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                        bc[0] = bn[0]; bc[1] = bn[1];
-                    }
-                    RSTAMP(9);
-                }
-#pragma unroll
-                for (int g = 0; g < NG; ++g)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        red[((vh * NG + g) * 16 + 4 * lg + r) * RRP + ln] = acc[g][r] + acl[g][r] * kLoInv;
-                if (STAMP) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); RSTAMP(10); }
+            ring_barrier();
+            RT_MARK(3 + hx);
+            // ---------------- odd slot 2q + 1: A finishes item q; B multiplies it and polls for item q + 2
+            if (hx == 0) {
+                cell_item(jc, t, ostep, parw, jc, false, 0u);
+                if (J + 1 < NT) xg_request(JN, xstep); else if (more) xg_request(JN, xnext);
+                RSTAMP(13);
+                RT_MARK(2);
+            } else {
+                // item q + 2 = (s, J + 2): its chain's step s - 1 [s >= 1]; or (s + 1, J - 2): its chain's step s
+                const bool pon = J + 2 < NT ? s >= 1 : more;
+                const int psp = J + 2 < NT ? s - 1 : s;
+                poll_issue(JQ, psp, pon);
+                mfma_item(jc, s);
+                RT_MARK(0);
+                m_end_wait();
+                poll_finish(JQ, psp, pon);
+                RT_MARK(1);
             }
-            if (STAMP) { __builtin_amdgcn_sched_barrier(0); t1_ = __builtin_amdgcn_s_memrealtime(); tacc[6] += __builtin_amdgcn_s_memtime() - c0_; __builtin_amdgcn_sched_barrier(0); }
-            // ---- everything this wave requested in its last cell slot: publish stores (drained), B's DMA (landed), x-projection
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_waitcnt(0x0F70);      // the same wait where the compiler sees it: nothing of this wave's is in flight
-            if (hx == 1) {
-                // the wave that drains last signals item q - 1 for the whole workgroup (A's stores of it drained a slot ago)
-                int old = 0;
-                if (lane == 0) old = __hip_atomic_fetch_add(&sync[8], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                old = __builtin_amdgcn_readfirstlane(old);
-                const int qs = q - 1;
-                if ((old & 3) == 3 && qs >= 0 && qs < NQ) {
-                    const int ss = qs / nte, js = qs - ss * nte;
-                    const int chain = d * p.ntiles + tile0 + js;
-                    const bool drop = chain == 0 && w32 == p.drop_wg && ss == p.drop_step;
-                    if (js < nt && lane == 0 && !drop)
-                        __hip_atomic_fetch_add(&p.cnt[((size_t)chain * p.T + ss) * kPersist16CntWords + shard], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                if (poll && !sync[0]) {
-                    unsigned long long tp_ = 0;
-                    if (STAMP) tp_ = __builtin_amdgcn_s_memrealtime();
-                    unsigned spins = 0;
-                    unsigned got = pollv;
-                    while (__builtin_amdgcn_ballot_w64(got < need) != 0) {
-                        __builtin_amdgcn_s_sleep(1);
-                        ++spins;
-                        if ((spins & 1023u) == 0 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { sync[0] = 1; break; }
-                        if (spins > p.spin_limit) { atomicExch(p.err, 1u); sync[0] = 1; break; }
-                        got = lane < kPersist16Shards ? __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need;
-                    }
-                    if (STAMP) tacc[5] += __builtin_amdgcn_s_memrealtime() - tp_;
-                }
-                __builtin_amdgcn_s_waitcnt(0x0F70);  // (free here: every poll has been consumed) no load is pending at the loop's back edge
-            }
-        } else {
-            // ---- B: DMA requests for item q + 2 into the ring slot its last readers left two barriers ago (its chain's
-            // previous step was found complete in the slot before this one); each wave brings the k-blocks it will multiply
-            if (hx == 1) {
-                const int qd = q + 2;
-                const int sd = qd / nte, jd = qd - sd * nte;
-                if (qd < NQ && sd >= 1 && jd < nt) {
-                    const unsigned char* gsrc = reinterpret_cast<const unsigned char*>(p.hpack) + (size_t)((sd - 1) & 1) * hp_par +
-                                                (size_t)(d * p.ntiles + tile0 + jd) * p.nkb * 2048;
-                    const unsigned ldst = lds_sbuf + (unsigned)((qd & 1) * sbytes);
-#pragma unroll
-                    for (int i = 0; i < NKW; ++i)
-                        if (i + 1 < NKW || kb0 + i < kb1) {
-#pragma unroll
-                            for (int pl = 0; pl < 2; ++pl) {
-                                const unsigned po = (unsigned)((kb0 + i) * 2 + pl) * 1024u;
-                                ring_dma(gsrc + po, (unsigned)lane * 16u, ldst + po);      // piece offset on the scalar side: one address register
-                            }
-                        }
-                }
-            }
-            RSTAMP(11);
-            if (tile_ok) {
-                // ---- K-split reduction (fixed order) + cell + publish, one (unit, clip) pair per thread
-                const int t = d == 0 ? s : p.T - 1 - s;
-                const int tile = tile0 + j;
-                const int eb = tile * RB + cj;
-                const bool eact = cunit_ok && eb < p.B;
-                const int mylen = st_len[j * 16 + cj];
-                float hn = 0.f;
-                if (eact) {
-                    float hg[NG];
-#pragma unroll
-                    for (int g = 0; g < NG; ++g) {
-                        float sum = 0.f;
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) sum += red[((k * NG + g) * 16 + cu) * RRP + cj];
-                        hg[g] = sum + bh[g];
-                    }
-                    float cprev = KIND == DSMI_RNN_LSTM ? st_c[j * RNT + tid] : 0.f;
-                    float xg[NG];
-#pragma unroll
-                    for (int g = 0; g < NG; ++g) xg[g] = xgr[g * 256];
-                    hn = rnn_cell<KIND>(xg, hg, st_h[j * RNT + tid], cprev, t < mylen);
-                    st_h[j * RNT + tid] = hn;
-                    if (KIND == DSMI_RNN_LSTM) st_c[j * RNT + tid] = cprev;
-                    p.out[d][((size_t)t * p.B + eb) * p.Hs + cunit] = hn;
-                } else if (half_ok && eb < p.B && cunit < p.Hs) {
-                    p.out[d][((size_t)t * p.B + eb) * p.Hs + cunit] = 0.f;     // padding units of the last workgroup
-                }
-                RSTAMP(12);
-                // publish: the wave's 8 clips x 8 units x 2 planes -> 256 bytes of LDS -> one 16-byte sc1 store for each of 16 lanes
-                const _Float16 h1 = (_Float16)hn;
-                const _Float16 h2 = (_Float16)((hn - (float)h1) * kLoScale);
-                unsigned short* sw = stg + v * 128;
-                sw[(lane >> 3) * 8 + ce] = __builtin_bit_cast(unsigned short, h1);
-                sw[64 + (lane >> 3) * 8 + ce] = __builtin_bit_cast(unsigned short, h2);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // same wave, LDS in order: the 16-byte rows are complete
-                if (lane < 16 && half_ok) {
-                    const u32x4 row = *reinterpret_cast<const u32x4*>(sw + lane * 8);
-                    const unsigned off = (unsigned)((s & 1) * hp_par) + (unsigned)((size_t)(d * p.ntiles + tile) * p.nkb * 2048) +
-                                         (unsigned)(w16 >> 1) * 2048u + (unsigned)(2 * (w16 & 1) + cuh) * 256u +
-                                         (unsigned)((vh & 1) * 8 + (lane & 7)) * 16u + (unsigned)(lane >> 3) * 1024u;
-                    __builtin_amdgcn_raw_buffer_store_b128(row, hrs, off, 0, 16);
-                }
-            }
-            // ---- x-projection of this half's next cell item, consumed two slots from now
-            if (q + 1 >= 0 && q + 1 < NQ) {
-                const int sn = (q + 1) / nte, jn = (q + 1) - sn * nte;
-                load_xg(sn, jn);
-            }
-            RSTAMP(13);
-        }
-        if (STAMP) {
-            __builtin_amdgcn_sched_barrier(0);
-            t2_ = __builtin_amdgcn_s_memrealtime();
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        ring_barrier();
-        if (STAMP) {
-            __builtin_amdgcn_sched_barrier(0);
-            const unsigned long long t3_ = __builtin_amdgcn_s_memrealtime();
-            if (mrole) { tacc[0] += t1_ - t0_; tacc[1] += t2_ - t1_; tacc[3] += t3_ - t2_; }
-            else { tacc[2] += t2_ - t0_; tacc[4] += t3_ - t2_; }
-            tacc[7] += 1;
-        }
+            ring_barrier();
+            RT_MARK(4 - hx);
+        };
+        slots(std::integral_constant<int, 0>{});
+        slots(std::integral_constant<int, 1>{});
+        slots(std::integral_constant<int, 2>{});
+        slots(std::integral_constant<int, 3>{});
+        if (STAMP && lane == 0) tacc[7] += 1;
     }
+    // ---------------- last slot: B finishes item (T - 1, NT - 1)
+    if (hx == 1) {
+        const int t = d == 0 ? p.T - 1 : 0;
+        constexpr std::integral_constant<int, NT - 1> JL;
+        cell_item(JL, t, outd + (size_t)t * ostride, (unsigned)((p.T - 1) & 1) * hp_par, JL, false, 0u);
+    }
+    ring_barrier();
+#undef TOK
+#undef RT_BEGIN
+#undef RT_MARK
     if (STAMP && lane == 0) {
         unsigned long long* o = p.dbg + ((size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + v) * 16;
         for (int k = 0; k < 16; ++k) o[k] = tacc[k];
@@ -354,8 +466,8 @@ __global__ __launch_bounds__(RNT, 2) void rnn_persist_ring_kernel(RingArgs p) {
 
 size_t ring_lds_bytes(int kind, int nkb) {
     const int NG = kind == DSMI_RNN_GRU ? 3 : (kind == DSMI_RNN_LSTM ? 4 : 1);
-    return (size_t)2 * nkb * 2048 + (size_t)2 * 4 * NG * 16 * RRP * 4 + (size_t)RMAXT * RNT * 4 * (kind == DSMI_RNN_LSTM ? 2 : 1) +
-           8 * 128 * 2 + (size_t)2 * NG * 256 * 4 + RMAXT * 16 * 4 + 32 * 4;
+    return (size_t)2 * nkb * 2048 + (size_t)2 * 4 * NG * 16 * RRP * 4 + (size_t)RMINT * RNT * 4 * (kind == DSMI_RNN_LSTM ? 2 : 1) +
+           8 * 128 * 2 + (size_t)2 * NG * 256 * 4 + RMINT * 16 * 4 + 32 * 4 + 8 * 16 * 8;
 }
 
 template <int KIND>
@@ -404,7 +516,7 @@ int rnn_persist_ring_tiles(const RnnGeom& g16, int B, int n_cus) {
     if (nkw > (g16.kind == DSMI_RNN_LSTM ? 4 : 7)) return 0;
     if (ring_lds_bytes(g16.kind, nkb) > 160 * 1024) return 0;
     if (((g16.nwg + 1) / 2) * g16.D > n_cus) return 0;
-    return std::min(ceil_div(B, RB), RMAXT);
+    return std::min(ceil_div(B, RB), RMINT);
 }
 
 int rnn_persist_ring_cus(const RnnGeom& g16) { return ((g16.nwg + 1) / 2) * g16.D; }
@@ -417,8 +529,10 @@ bool launch_rnn_persist_ring(const RnnPersist16Launch& p, hipStream_t s) {
     a.ntiles = ceil_div(p.B, RB); a.D = p.g.D;
     a.tile0 = p.tile0; a.ntw = p.ntw > 0 ? p.ntw : a.ntiles - p.tile0;
     a.tile_end = std::min(a.ntiles, a.tile0 + a.ntw * std::max(p.nwin, 1));
-    if (a.ntw < 1 || a.ntw > RMAXT || a.tile_end <= a.tile0) return false;
+    if (a.ntw < 1 || a.ntw > RMINT || a.tile_end <= a.tile0) return false;
     a.spin_limit = p.spin_limit; a.drop_wg = p.drop_wg; a.drop_step = p.drop_step; a.dbg = p.dbg;
+    static const int skip = std::getenv("DSMI_DEBUG_RING_SKIP") ? std::atoi(std::getenv("DSMI_DEBUG_RING_SKIP")) : 0;
+    a.skip = skip;
     switch (p.g.kind) {
         case DSMI_RNN_GRU: return launch_ring<DSMI_RNN_GRU>(a, s, p.ev);
         case DSMI_RNN_LSTM: return launch_ring<DSMI_RNN_LSTM>(a, s, p.ev);

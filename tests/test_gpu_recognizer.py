@@ -88,6 +88,31 @@ def test_device_resident_clips_equal_host_arrays():
         DeviceClips(pcm[:-1], n)
 
 
+def test_device_clips_batches_wait_for_their_producer():
+    """Device-resident clips are produced by asynchronous work on the caller's stream (an RCCL scatter, a widening copy): every
+    second batch of the pipeline runs on a side stream, which must wait for that producer.  Here the producer is a slow chain
+    of kernels that ends by writing the real samples over a garbage buffer; batch 1 (the side stream's) read garbage before the
+    pipeline ordered itself behind the caller's stream."""
+    from danspeech_amd import Recognizer
+    from danspeech_amd.audio.parsers import DeviceClips
+    model, sd, cfg = _model("small", 64, 3, seed=12)
+    rec = Recognizer(model=model)
+    clips = [syn.make_clip(i, n) for i, n in enumerate([40000, 40000, 23456, 16000, 8000])]
+    want = rec.recognize_batch(clips)
+    n = np.array([len(c) for c in clips], dtype=np.int64)
+    good = torch.from_numpy(np.concatenate(clips)).cuda()
+    spin = torch.randn(4096, 4096, device="cuda")
+    for rep in range(3):
+        bufs = [torch.full_like(good, 1e4) for _ in range(4)]
+        torch.cuda.synchronize()
+        for _ in range(40):                    # ~tens of milliseconds of queued work in front of the copies
+            spin = torch.tanh(spin @ spin * 1e-3)
+        for b in bufs:
+            b.copy_(good, non_blocking=True)
+        got = list(rec.recognize_batches([DeviceClips(b, n) for b in bufs]))
+        assert got == [want] * 4, rep
+
+
 def test_config3_beam_with_lm_through_recognizer(tmp_path, capsys):
     """cfgA (2 conv, 5 x BiGRU 800) + synthetic 3-gram, alpha=1.3 beta=0.2 beam=64 (engine defaults)."""
     from danspeech_amd import Recognizer

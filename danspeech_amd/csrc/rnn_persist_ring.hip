@@ -400,6 +400,9 @@ unsigned hchs = hchs_, cnts = cnts_, orows = orows_, xrows = xrows_;
             constexpr std::integral_constant<int, (J + 2) % NT> JQ;          // tile of the item two ahead
             // ---------------- even slot 2q: A multiplies item (s, J); B finishes item q - 1 and requests item q + 1's state
             RT_BEGIN();
+            // the cell slot is a short chain of dependent vector and LDS instructions, the MFMA slot a long stream that only needs
+            // the matrix pipe kept fed: the cell wave goes first wherever both want the SIMD's issue port
+            if (!(p.skip & 32)) { if (hx == 0) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3); }
             if (hx == 0) {
                 mfma_item(jc, s);
                 RT_MARK(0);
@@ -423,6 +426,7 @@ unsigned hchs = hchs_, cnts = cnts_, orows = orows_, xrows = xrows_;
             ring_barrier();
             RT_MARK(3 + hx);
             // ---------------- odd slot 2q + 1: A finishes item q; B multiplies it and polls for item q + 2
+            if (!(p.skip & 32)) { if (hx == 0) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }
             if (hx == 0) {
                 cell_item(jc, t, ostep, parw, jc, false, 0u);
                 if (J + 1 < NT) xg_request(JN, xstep); else if (more) xg_request(JN, xnext);

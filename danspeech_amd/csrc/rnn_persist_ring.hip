@@ -87,8 +87,10 @@ __device__ __forceinline__ void ring_dma(const void* gbase, unsigned voff, unsig
 // The schedule is RMINT = 4 tiles long and unrolled over the tiles: which ring slot, which neighbour items a slot signals,
 // polls, requests and prefetches for are compile-time, and what depends on the tile alone (chain, counters, row blocks)
 // is computed once; a slot's scalar work is a handful of additions.
-template <int KIND, int NKW, bool STAMP = false>
+template <int KIND, int NKW, bool STAMP = false, bool SKIPS = false>
 __global__ __launch_bounds__(RNT, 2) void rnn_persist_ring_kernel(RingArgs p) {
+    const int skipf = SKIPS ? p.skip : 0;          // timing experiments only (DSMI_DEBUG_RING_SKIP): the production build carries none of the tests
+    unsigned long long clast = 0;
     constexpr int NG = KIND == DSMI_RNN_GRU ? 3 : (KIND == DSMI_RNN_LSTM ? 4 : 1);
     constexpr int NT = RMINT;
     extern __shared__ __attribute__((aligned(16))) unsigned char rlds[];
@@ -157,9 +159,7 @@ unsigned hchs = hchs_, cnts = cnts_, orows = orows_, xrows = xrows_;
 #define TOK(J) ((J) < nt)
 
     // ---- cell role inside the half: thread -> (unit cu = 8 * (tidh >> 7) + (tidh & 7), clip cj = (tidh >> 3) & 15); everything a
-    // thread needs per item is a uniform base plus one of these per-thread constants.  Stores are unconditional instructions: a
-    // lane that has nothing to store carries an offset beyond the buffer's range and the hardware drops it (no branch in the cell).
-    constexpr unsigned OOR = 0x80000000u;      // beyond every buffer here (their sizes are checked to be below 2 GiB), also after + 1024
+    // thread needs per item is a uniform base plus one of these per-thread constants
     const int cuh = tidh >> 7, ce = tidh & 7, cj = (tidh >> 3) & 15;
     const int cu = 8 * cuh + ce;
     const int cunit = w16 * RU + cu;
@@ -168,256 +168,301 @@ unsigned hchs = hchs_, cnts = cnts_, orows = orows_, xrows = xrows_;
 #pragma unroll
     for (int g = 0; g < NG; ++g) bh[g] = cunit_ok ? p.bhh[d][g * p.H + cunit] : 0.f;
     const int nb_last = p.B - (tile0 + nt - 1) * RB;                                   // clips of the window's last real tile (may exceed 16)
-    const bool act_last = cunit_ok && cj < nb_last;
-    unsigned o_by = cunit_ok ? (unsigned)(cj * p.Hs + cunit) * 4u : OOR;               // byte offset inside an out row block [16 clips][Hs]
-    unsigned o_by_last = act_last ? (unsigned)(cj * p.Hs + cunit) * 4u : OOR;          // ... in the window's last tile
+    unsigned actbits = 0;                                                              // bit j: this thread's (unit, clip) exists in tile j
+#pragma unroll
+    for (int j = 0; j < NT; ++j) actbits |= (unsigned)(cunit_ok && j < nt && (j < nt - 1 || cj < nb_last)) << j;
+    // Stores are unconditional instructions: a lane that has nothing to store carries an offset beyond the buffer's range and the
+    // hardware drops it (no branch in the cell).  OOR lies beyond every buffer here (sizes checked below 2 GiB), also after + 1024.
+    constexpr unsigned OOR = 0x80000000u;
+    unsigned o_by = (unsigned)(cj * p.Hs + (half_ok ? cunit : 0)) * 4u;          // byte offset inside an out row block [16 clips][Hs]
     const unsigned xcol = half_ok ? (unsigned)((d * p.nwg16 + w16) * GU + cu) : 0u;
-    unsigned x_by = ((unsigned)cj * p.Np + xcol) * 4u;                                // byte offset inside an x-projection row block
-    unsigned x_by_last = ((unsigned)min(cj, nb_last - 1) * p.Np + xcol) * 4u;         // ... clamped to the last tile's clips
+    unsigned x_by = ((unsigned)cj * p.Np + xcol) * 4u;                          // byte offset inside an x-projection row block
+    unsigned x_by_last = ((unsigned)min(cj, nb_last - 1) * p.Np + xcol) * 4u;   // ... clamped to the last tile's clips
     const float* redr = red + cu * RRP + cj;
-    unsigned pub_by = (ce == 0 && half_ok) ? (unsigned)(w16 >> 1) * 2048u + (unsigned)(2 * (w16 & 1) + cuh) * 256u + (unsigned)cj * 16u : OOR;   // hi plane; lo at + 1024
+    unsigned pub_off = (ce == 0 && half_ok) ? (unsigned)(w16 >> 1) * 2048u + (unsigned)(2 * (w16 & 1) + cuh) * 256u + (unsigned)cj * 16u : OOR;   // hi plane; lo at + 1024
     const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)outd, 0, (int)((size_t)p.T * p.B * p.Hs * 4), 0x00020000);
     const unsigned shard = (unsigned)(w32 & (kPersist16Shards - 1)) * 64u;
     const unsigned need = (unsigned)((nwg32 + kPersist16Shards - 1 - (lane & (kPersist16Shards - 1))) / kPersist16Shards);
     const unsigned lds_xg = (unsigned)(size_t)xgl + (unsigned)((hx * NG * 256 + vh * 64) * 4);
     const float* xgr = xgl + hx * NG * 256 + tidh;
+    unsigned pollv = 0;             // B's wave 0: the counter shard this lane read at the start of its MFMA slot
 
-    // x-projection operands of the cell item of tile J, from the step whose rows start at xstep: by LDS-DMA, 4 bytes per lane, into
-    // this thread's own words of xgl -- no register is held across the phases, and the compiler, which does not see the requests,
-    // waits for nothing
+    // x-projection operands of a cell item of tile J, from the step whose rows start at xstep: by LDS-DMA, 4 bytes per lane, into
+    // this thread's own words of xgl -- no register is held across the MFMA slot in between, and the compiler, which does not
+    // see the requests, waits for nothing
     auto xg_request = [&](auto jc, const float* xstep) {
         constexpr int J = decltype(jc)::value;
-        if (p.skip & 8) return;
         const float* row = xstep + (xrow0 + min(J, nt - 1) * xrows);       // (a phantom tile's request is clamped into the batch)
         const unsigned by = J >= nt - 1 ? x_by_last : x_by;
+        if (skipf & 8) return;
         const unsigned lx = lds_xg;         // (a local copy: an asm operand inside a generic lambda does not capture by itself)
 #pragma unroll
         for (int g = 0; g < NG; ++g)
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" :: "s"(lx + g * 1024), "v"(by + g * RU * 4), "s"(row) : "memory");
     };
 
-    // DMA requests for the state an item of tile J multiplies (its chain's previous step, at parity offset `par`), into ring slot
-    // J & 1: every wave brings ONE plane (half A the hi, half B the lo plane) of the k-blocks it multiplies.  One base (M0, scalar
-    // address) serves two k-blocks: the instruction offset applies to the global AND the LDS address (tools/exp/dma_off_probe.hip).
-    auto dma_item = [&](auto jc, bool on, unsigned par) {
+    // MFMAs of an item of tile J at step s (B operands from ring slot J & 1), partial tiles -> LDS
+    auto mfma_item = [&](auto jc, int s) {
         constexpr int J = decltype(jc)::value;
-        if (!on || !TOK(J) || (p.skip & 1)) return;
-        const unsigned l16 = lane16;
+        if (!TOK(J)) return;
+        const bool no_mfma = skipf & 2;
+        f32x4 acc[NG], acl[NG];        // hi.hi ; (hi.lo + lo.hi) * 2^11
 #pragma unroll
-        for (int i = 0; i < NKW; i += 2) {
-            const unsigned po = (unsigned)(kb0 + i) * 2048u + (unsigned)hx * 1024u;
-            const unsigned char* gsrc = reinterpret_cast<const unsigned char*>(p.hpack) + (par + hch0 + J * hchs + po);
-            const unsigned ldst = lds_sbuf + (unsigned)((J & 1) * sbytes) + po;
-            if (i + 2 < NKW || (i + 1 < NKW && kb0 + i + 1 < kb1))
-                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1\n\tglobal_load_lds_dwordx4 %1, %2 offset:2048 sc1"
-                             :: "s"(ldst), "v"(l16), "s"(gsrc) : "memory");
-            else if (i + 1 < NKW || kb0 + i < kb1)
-                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1" :: "s"(ldst), "v"(l16), "s"(gsrc) : "memory");
+        for (int g = 0; g < NG; ++g) { acc[g] = f32x4{0.f, 0.f, 0.f, 0.f}; acl[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        if (s > 0 && !no_mfma) {
+            const unsigned char* sb = sbr + (J & 1) * sbytes;
+            f16x8 bc[2], bn[2];
+            bc[0] = *reinterpret_cast<const f16x8*>(sb);
+            bc[1] = *reinterpret_cast<const f16x8*>(sb + 1024);
+            if (STAMP) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); RSTAMP(8); }
+#pragma unroll
+            for (int i = 0; i < NKW; ++i) {
+                if (i + 1 < NKW) {          // (a wave with NKW - 1 blocks reads its neighbour's first one here and does not use it)
+                    bn[0] = *reinterpret_cast<const f16x8*>(sb + (i + 1) * 2048);
+                    bn[1] = *reinterpret_cast<const f16x8*>(sb + (i + 1) * 2048 + 1024);
+                }
+                __builtin_amdgcn_sched_barrier(0);     // the next block's operands are requested BEFORE this block's MFMAs
+                if (i + 1 < NKW || kb0 + i < kb1) {
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) acl[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[i][g][1], bc[0], acl[g], 0, 0, 0);
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[i][g][0], bc[0], acc[g], 0, 0, 0);
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) acl[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[i][g][0], bc[1], acl[g], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                bc[0] = bn[0]; bc[1] = bn[1];
+            }
+            RSTAMP(9);
         }
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                red[((vh * NG + g) * 16 + 4 * lg + r) * RRP + ln] = acc[g][r] + acl[g][r] * kLoInv;
+        if (STAMP) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); RSTAMP(10); }
     };
 
-    // One lane: step `ss` of tile J's chain is published by this workgroup (both halves' stores of that item were drained before
-    // the barrier that opened this phase)
+    // B's DMA requests for an item of tile J whose chain's previous step lies at parity offset `par`: each wave brings the k-blocks
+    // it will multiply, into ring slot J & 1, in four groups (G = 0..3) placed between the parts of the cell -- the texture path
+    // takes a 1-KiB piece per ~80 cycles, and a wave that asks faster stands at the request instead of working.  One base (M0, scalar
+    // address) serves two k-blocks: the instruction offset applies to the global AND the LDS address (tools/exp/dma_off_probe.hip).
+    auto dma_group = [&](auto jc, auto gc, bool on, unsigned par) {
+        constexpr int J = decltype(jc)::value, G = decltype(gc)::value;
+        constexpr int i = 2 * G;
+        if (i >= NKW || !on || !TOK(J) || (skipf & 1)) return;
+        const unsigned char* gsrc = reinterpret_cast<const unsigned char*>(p.hpack) + (par + hch0 + J * hchs + (unsigned)(kb0 + i) * 2048u);
+        const unsigned ldst = lds_sbuf + (unsigned)((J & 1) * sbytes) + (unsigned)(kb0 + i) * 2048u;
+        const unsigned l16 = lane16;
+        if (i + 1 < NKW || kb0 + i < kb1)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024 sc1"
+                         :: "s"(ldst), "v"(l16), "s"(gsrc) : "memory");
+        if (i + 1 < NKW && (i + 2 < NKW || kb0 + i + 1 < kb1))
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:2048 sc1\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072 sc1"
+                         :: "s"(ldst), "v"(l16), "s"(gsrc) : "memory");
+    };
+
+    // Cell of an item of tile J: K-split reduction (fixed order), cell, own state, output row, publish -- one (unit, clip) pair per
+    // thread.  t: time index; osoff: byte offset of the step's output rows; parw: parity offset the new state is written at.  DJ / don / dpar:
+    // the item B requests meanwhile (dma_group).  The slot is a chain of latencies in ONE wave per SIMD (the partner multiplies), so
+    // it is kept short: every LDS read goes out first, and the publish needs no LDS -- the eight lanes of a clip hand their
+    // (hi | lo << 16) words to the clip's first lane by DPP row shifts, which stores both planes' 16 bytes.
+    auto cell_item = [&](auto jc, int t, unsigned osoff, unsigned parw, auto djc, bool don, unsigned dpar) {
+        constexpr int J = decltype(jc)::value;
+        constexpr std::integral_constant<int, 0> G0; constexpr std::integral_constant<int, 1> G1;
+        constexpr std::integral_constant<int, 2> G2; constexpr std::integral_constant<int, 3> G3;
+        if (!TOK(J)) { dma_group(djc, G0, don, dpar); dma_group(djc, G1, don, dpar); dma_group(djc, G2, don, dpar); dma_group(djc, G3, don, dpar); return; }
+        float rv[NG][4], xg[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rv[g][k] = redr[(k * NG + g) * 16 * RRP];
+            xg[g] = xgr[g * 256];
+        }
+        const int mylen = st_len[J * 16 + cj];
+        const float hprev = st_h[J * RNT + tid];
+        float cprev = KIND == DSMI_RNN_LSTM ? st_c[J * RNT + tid] : 0.f;
+        __builtin_amdgcn_sched_barrier(0);
+        dma_group(djc, G0, don, dpar);
+        dma_group(djc, G1, don, dpar);
+        RSTAMP(11);
+        __builtin_amdgcn_sched_barrier(0);
+        float hg[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) hg[g] = ((rv[g][0] + rv[g][1]) + rv[g][2]) + rv[g][3] + bh[g];
+        const bool act = (actbits >> J) & 1u;
+        float hn = rnn_cell<KIND, true>(xg, hg, hprev, cprev, t < mylen);
+        hn = act ? hn : 0.f;
+        st_h[J * RNT + tid] = hn;
+        if (KIND == DSMI_RNN_LSTM) st_c[J * RNT + tid] = cprev;
+        const _Float16 h1 = (_Float16)hn;
+        const _Float16 h2 = (_Float16)((hn - (float)h1) * kLoScale);
+        const unsigned pk = (unsigned)__builtin_bit_cast(unsigned short, h1) | ((unsigned)__builtin_bit_cast(unsigned short, h2) << 16);
+        unsigned u[8];
+        u[0] = pk;
+        u[1] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pk, 0x101, 0xF, 0xF, false);      // row_shl:n: lane i receives lane i + n's word
+        u[2] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pk, 0x102, 0xF, 0xF, false);
+        u[3] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pk, 0x103, 0xF, 0xF, false);
+        u[4] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pk, 0x104, 0xF, 0xF, false);
+        u[5] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pk, 0x105, 0xF, 0xF, false);
+        u[6] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pk, 0x106, 0xF, 0xF, false);
+        u[7] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pk, 0x107, 0xF, 0xF, false);
+        u32x4 phi, plo;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            phi[m] = __builtin_amdgcn_perm(u[2 * m + 1], u[2 * m], 0x05040100u);     // low halves: units 2m, 2m + 1 of the hi plane
+            plo[m] = __builtin_amdgcn_perm(u[2 * m + 1], u[2 * m], 0x07060302u);     // high halves: the lo plane
+        }
+        RSTAMP(12);
+        __builtin_amdgcn_sched_barrier(0);
+        dma_group(djc, G2, don, dpar);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(skipf & 16)) {
+            __builtin_amdgcn_raw_buffer_store_b128(phi, hrs, pub_off, parw + hch0 + J * hchs, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(plo, hrs, pub_off + 1024u, parw + hch0 + J * hchs, 16);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, hn), ors, act ? o_by : OOR, osoff + (orow0 + J * orows) * 4u, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        dma_group(djc, G3, don, dpar);
+    };
+
+    // end of an MFMA slot: everything this wave requested in its last cell slot -- publish stores (drained), B's DMA (landed),
+    // x-projection (arrived)
+    auto m_end_wait = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0x0F70);      // the same wait where the compiler sees it: nothing of this wave's is in flight
+    };
+    // B, at the start of its cell slot: step `ss` of tile J's chain is published by this workgroup -- both halves' stores of that item
+    // were drained before the barrier that opened this slot (A's a slot earlier)
     auto signal_item = [&](auto jc, int ss, bool on) {
         constexpr int J = decltype(jc)::value;
-        if (v == 0 && on && TOK(J)) {
+        if (vh == 0 && on && TOK(J)) {
             const bool drop = d == 0 && tile0 + J == 0 && w32 == p.drop_wg && ss == p.drop_step;
             if (lane == 0 && !drop)
                 __hip_atomic_fetch_add(p.cnt + (cnt0 + J * cnts + (unsigned)ss * kPersist16CntWords + shard), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     };
-    // Wave 4: has step `sp` of tile J's chain been published by every workgroup?  Spins (bounded) until it has.
-    auto poll_item = [&](auto jc, int sp, bool on) {
+    // B's wave 0: has step `sp` of tile J's chain been published by every workgroup?  Asked at the start of the MFMA slot (the raw
+    // word only, at ONE place per slot: a select there, or a second request site, makes the compiler wait for the load, and with it
+    // for every request of the wave's last cell slot, in front of the MFMAs), answered behind it.
+    auto poll_issue = [&](auto jc, int sp, bool on) {
         constexpr int J = decltype(jc)::value;
-        if (v == 4 && on && TOK(J) && !sync[0] && !(p.skip & 4)) {
+        if (on && TOK(J) && vh == 0 && lane < kPersist16Shards && !(skipf & 4))
+            pollv = __hip_atomic_load(p.cnt + (cnt0 + J * cnts + (unsigned)sp * kPersist16CntWords + lane * 64), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto poll_finish = [&](auto jc, int sp, bool on) {
+        constexpr int J = decltype(jc)::value;
+        if (on && TOK(J) && vh == 0 && !sync[0] && !(skipf & 4)) {
             unsigned long long tp_ = 0;
             if (STAMP) tp_ = __builtin_amdgcn_s_memrealtime();
             const unsigned* cp = p.cnt + (cnt0 + J * cnts + (unsigned)sp * kPersist16CntWords + (lane & (kPersist16Shards - 1)) * 64);
             unsigned spins = 0;
-            while (true) {
-                const unsigned got = lane < kPersist16Shards ? __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need;
-                if (__builtin_amdgcn_ballot_w64(got < need) == 0) break;
+            unsigned got = lane < kPersist16Shards ? pollv : need;
+            while (__builtin_amdgcn_ballot_w64(got < need) != 0) {
                 __builtin_amdgcn_s_sleep(1);
                 ++spins;
                 if ((spins & 1023u) == 0 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { sync[0] = 1; break; }
                 if (spins > p.spin_limit) { atomicExch(p.err, 1u); sync[0] = 1; break; }
+                got = lane < kPersist16Shards ? __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need;
             }
             if (STAMP && lane == 0) tacc[5] += __builtin_amdgcn_s_memrealtime() - tp_;
         }
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // (free here: every poll has been consumed) no load is pending at the loop's back edge
     };
 
-    // Stamps (diagnostics build), 100 MHz ticks per wave: [0] cell inputs + duties, [1] barrier 2, [2] DMA requests + cell, [3] MFMAs +
-    // partial tiles, [4] x-projection request + poll + end wait, [6] barrier 1
-    unsigned long long tm0 = 0, tm1 = 0;
-#define RT_BEGIN() do { if (STAMP) { __builtin_amdgcn_sched_barrier(0); tm0 = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
-#define RT_MARK(k) do { if (STAMP) { __builtin_amdgcn_sched_barrier(0); tm1 = __builtin_amdgcn_s_memrealtime(); if ((threadIdx.x & 63) == 0) tacc[k] += tm1 - tm0; tm0 = tm1; __builtin_amdgcn_sched_barrier(0); } } while (0)
-
-    // ONE PHASE, the same for every wave (the halves differ in their 16 units and in the plane they fetch):
-    //   cell inputs of the PREVIOUS item (tile CJ) -> barrier 2 (nobody overwrites the partial tiles before everybody has read them)
-    //   -> DMA requests for the NEXT item (tile DJ) -> cell of the previous item (a chain of dependent vector instructions: two waves
-    //   per SIMD run it side by side) -> MFMAs of this item (tile J; two waves per SIMD keep the matrix pipe full) -> partial tiles
-    //   -> x-projection request for this item's cell, poll for the item after next -> everything requested has arrived -> barrier 1.
-    // mon / con: this phase has an MFMA item / a cell item.  ct, csoff, cparw: the cell item's time index, output row offset (bytes),
-    // parity offset its new state is written at.
-    auto phase = [&](auto jc, auto cjc, auto djc, int s, bool mon, bool con, int ct, unsigned csoff, unsigned cparw,
-                     bool don, unsigned dpar, const float* xstep) {
-        constexpr int J = decltype(jc)::value, CJ = decltype(cjc)::value;
-        RT_BEGIN();
-        const bool cv = con && TOK(CJ);
-        float rv[NG][4], xg[NG], hprev = 0.f, cprev = 0.f;
-        int mylen = 0;
-#pragma unroll
-        for (int g = 0; g < NG; ++g) { xg[g] = 0.f; for (int k = 0; k < 4; ++k) rv[g][k] = 0.f; }
-        if (cv) {
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) rv[g][k] = redr[(k * NG + g) * 16 * RRP];
-                xg[g] = xgr[g * 256];
-            }
-            mylen = st_len[CJ * 16 + cj];
-            hprev = st_h[CJ * RNT + tid];
-            if (KIND == DSMI_RNN_LSTM) cprev = st_c[CJ * RNT + tid];
-        }
-        RT_MARK(0);
-        ring_barrier();
-        RT_MARK(1);
-        dma_item(djc, don, dpar);
-        if (mon) xg_request(jc, xstep);          // this item's cell runs in the next phase; xgl's last values were read before barrier 2
-        auto cell_part = [&]() {
-        if (cv) {
-            float hg[NG];
-#pragma unroll
-            for (int g = 0; g < NG; ++g) hg[g] = ((rv[g][0] + rv[g][1]) + rv[g][2]) + rv[g][3] + bh[g];
-            float hn = rnn_cell<KIND, true>(xg, hg, hprev, cprev, ct < mylen);
-            const unsigned oby = CJ >= nt - 1 ? o_by_last : o_by;
-            hn = oby != OOR ? hn : 0.f;
-            st_h[CJ * RNT + tid] = hn;
-            if (KIND == DSMI_RNN_LSTM) st_c[CJ * RNT + tid] = cprev;
-            // publish: the eight lanes of a clip hand their (hi | lo << 16) words to the clip's first lane by DPP row shifts; that
-            // lane stores 16 bytes of each plane (one whole 128-byte line per plane and wave instruction)
-            const _Float16 h1 = (_Float16)hn;
-            const _Float16 h2 = (_Float16)((hn - (float)h1) * kLoScale);
-            const unsigned pk = (unsigned)__builtin_bit_cast(unsigned short, h1) | ((unsigned)__builtin_bit_cast(unsigned short, h2) << 16);
-            unsigned u[8];
-            u[0] = pk;
-            u[1] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pk, 0x101, 0xF, 0xF, false);      // row_shl:n: lane i receives lane i + n's word
-            u[2] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pk, 0x102, 0xF, 0xF, false);
-            u[3] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pk, 0x103, 0xF, 0xF, false);
-            u[4] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pk, 0x104, 0xF, 0xF, false);
-            u[5] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pk, 0x105, 0xF, 0xF, false);
-            u[6] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pk, 0x106, 0xF, 0xF, false);
-            u[7] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pk, 0x107, 0xF, 0xF, false);
-            u32x4 phi, plo;
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                phi[m] = __builtin_amdgcn_perm(u[2 * m + 1], u[2 * m], 0x05040100u);     // low halves: units 2m, 2m + 1 of the hi plane
-                plo[m] = __builtin_amdgcn_perm(u[2 * m + 1], u[2 * m], 0x07060302u);     // high halves: the lo plane
-            }
-            if (!(p.skip & 16)) {
-                __builtin_amdgcn_raw_buffer_store_b128(phi, hrs, pub_by, cparw + hch0 + CJ * hchs, 16);
-                __builtin_amdgcn_raw_buffer_store_b128(plo, hrs, pub_by + 1024u, cparw + hch0 + CJ * hchs, 16);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, hn), ors, oby, csoff + (orow0 + CJ * orows) * 4u, 0);
-            }
-        }
-        };
-        auto mfma_part = [&]() {
-        if (mon && TOK(J)) {
-            f32x4 acc[NG], acl[NG];        // hi.hi ; (hi.lo + lo.hi) * 2^11
-#pragma unroll
-            for (int g = 0; g < NG; ++g) { acc[g] = f32x4{0.f, 0.f, 0.f, 0.f}; acl[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-            if (s > 0 && !(p.skip & 2)) {
-                const unsigned char* sb = sbr + (J & 1) * sbytes;
-                f16x8 bc[2], bn[2];
-                bc[0] = *reinterpret_cast<const f16x8*>(sb);
-                bc[1] = *reinterpret_cast<const f16x8*>(sb + 1024);
-#pragma unroll
-                for (int i = 0; i < NKW; ++i) {
-                    if (i + 1 < NKW) {          // (a wave with NKW - 1 blocks reads its neighbour's first one here and does not use it)
-                        bn[0] = *reinterpret_cast<const f16x8*>(sb + (i + 1) * 2048);
-                        bn[1] = *reinterpret_cast<const f16x8*>(sb + (i + 1) * 2048 + 1024);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);     // the next block's operands are requested BEFORE this block's MFMAs
-                    if (i + 1 < NKW || kb0 + i < kb1) {
-#pragma unroll
-                        for (int g = 0; g < NG; ++g) acl[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[i][g][1], bc[0], acl[g], 0, 0, 0);
-#pragma unroll
-                        for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[i][g][0], bc[0], acc[g], 0, 0, 0);
-#pragma unroll
-                        for (int g = 0; g < NG; ++g) acl[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[i][g][0], bc[1], acl[g], 0, 0, 0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    bc[0] = bn[0]; bc[1] = bn[1];
-                }
-            }
-#pragma unroll
-            for (int g = 0; g < NG; ++g)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    red[((vh * NG + g) * 16 + 4 * lg + r) * RRP + ln] = acc[g][r] + acl[g][r] * kLoInv;
-        }
-        };
-        // the halves take the two parts in opposite order: on every SIMD one wave is on the vector side while its partner feeds the matrix pipe
-        if (hx == 0 || (p.skip & 64)) { cell_part(); RT_MARK(2); mfma_part(); } else { mfma_part(); RT_MARK(3); cell_part(); }
-        RT_MARK(3);
-    };
-    // the tail of a phase: the poll for the item after next (wave 4), then everything this wave requested has arrived -- publish
-    // stores (drained), DMA (landed), x-projection
-    auto phase_end = [&](auto pjc, int psp, bool pon) {
-        poll_item(pjc, psp, pon);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_waitcnt(0x0F70);      // the same wait where the compiler sees it: nothing of this wave's is in flight
-        RT_MARK(4);
-        ring_barrier();
-        RT_MARK(6);
-    };
-
+    if (hx == 0) xg_request(std::integral_constant<int, 0>{}, p.xp + (size_t)(d == 0 ? 0 : p.T - 1) * p.B * p.Np);
     // through the builtin, so that the compiler knows the prologue's loads (W_hh, biases, lengths) have arrived: told by inline
-    // assembly it would wait for them at their first use INSIDE the loop, where vmcnt(0) also waits for that phase's requests
+    // assembly it would wait for them at their first use INSIDE the loop, where vmcnt(0) also waits for that slot's requests
     __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     ring_barrier();
+
+    // Stamps (diagnostics build): [0] M work, [1] M-end waits, [2] C work, [3] barrier behind M, [4] barrier behind C in 100 MHz ticks
+    unsigned long long tm0 = 0, tm1 = 0;
+#define RT_BEGIN() do { if (STAMP) { __builtin_amdgcn_sched_barrier(0); tm0 = __builtin_amdgcn_s_memrealtime(); clast = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#define RT_MARK(k) do { if (STAMP) { __builtin_amdgcn_sched_barrier(0); tm1 = __builtin_amdgcn_s_memrealtime(); if ((threadIdx.x & 63) == 0) tacc[k] += tm1 - tm0; tm0 = tm1; __builtin_amdgcn_sched_barrier(0); } } while (0)
 
     const size_t xstride = (size_t)p.B * p.Np;
     const unsigned ostride_by = (unsigned)((size_t)p.B * p.Hs * 4);
     for (int s = 0; s < p.T; ++s) {
         const int t = d == 0 ? s : p.T - 1 - s;
-        const int tprev = d == 0 ? t - 1 : t + 1;
         const unsigned osoff = (unsigned)t * ostride_by;              // this step's output rows (bytes)
         const float* xstep = p.xp + (size_t)t * xstride;
         const unsigned parw = (unsigned)(s & 1) * hp_par;            // parity offset this step's cells write h_s at
         const unsigned parr = hp_par - parw;                          // ... and its MFMAs read h_(s-1) from (= where step s + 1 writes)
         const bool more = s + 1 < p.T;
-        // opaque per step: what is derived from these (a dozen addresses per unrolled tile) is recomputed where it is used -- an
-        // addition -- instead of being hoisted out of the loop into registers the kernel does not have
+        // opaque per step: what is derived from these (a dozen addresses per unrolled tile and half) is recomputed where it is
+        // used -- an addition -- instead of being hoisted out of the loop into registers the kernel does not have
         asm volatile("" : "+s"(hch0), "+s"(cnt0), "+s"(orow0), "+s"(xrow0), "+s"(hchs), "+s"(cnts), "+s"(orows), "+s"(xrows));
-        asm volatile("" : "+v"(o_by), "+v"(o_by_last), "+v"(x_by), "+v"(x_by_last), "+v"(pub_by));
-        constexpr std::integral_constant<int, 0> T0; constexpr std::integral_constant<int, 1> T1;
-        constexpr std::integral_constant<int, 2> T2; constexpr std::integral_constant<int, 3> T3;
-        // item (s, 0): cell of (s - 1, 3), state of (s, 1), signal (s - 1, 2), poll for (s, 2): its chain's step s - 1
-        signal_item(T2, s - 1, s >= 1);
-        phase(T0, T3, T1, s, true, s >= 1, tprev, (unsigned)tprev * ostride_by, parr, s >= 1, parr, xstep);
-        phase_end(T2, s - 1, s >= 1);
-        // item (s, 1): cell of (s, 0), state of (s, 2), signal (s - 1, 3), poll for (s, 3)
-        signal_item(T3, s - 1, s >= 1);
-        phase(T1, T0, T2, s, true, true, t, osoff, parw, s >= 1, parr, xstep);
-        phase_end(T3, s - 1, s >= 1);
-        // item (s, 2): cell of (s, 1), state of (s, 3), signal (s, 0), poll for (s + 1, 0): its chain's step s
-        signal_item(T0, s, true);
-        phase(T2, T1, T3, s, true, true, t, osoff, parw, s >= 1, parr, xstep);
-        phase_end(T0, s, more);
-        // item (s, 3): cell of (s, 2), state of (s + 1, 0) = h_s of chain 0, signal (s, 1), poll for (s + 1, 1)
-        signal_item(T1, s, true);
-        phase(T3, T2, T0, s, true, true, t, osoff, parw, more, parw, xstep);
-        phase_end(T1, s, more);
+        asm volatile("" : "+v"(o_by), "+v"(x_by), "+v"(x_by_last), "+v"(pub_off));
+        const int tn = d == 0 ? s + 1 : p.T - 2 - s;
+        const float* xnext = p.xp + (size_t)(more ? tn : t) * xstride;
+        auto slots = [&](auto jc) {
+            constexpr int J = decltype(jc)::value;
+            constexpr std::integral_constant<int, (J + 1) % NT> JN;          // next item's tile
+            constexpr std::integral_constant<int, (J + NT - 1) % NT> JP;     // previous item's tile
+            constexpr std::integral_constant<int, (J + 2) % NT> JQ;          // tile of the item two ahead
+            // ---------------- even slot 2q: A multiplies item (s, J); B finishes item q - 1 and requests item q + 1's state
+            RT_BEGIN();
+            // the cell slot is a short chain of dependent vector and LDS instructions, the MFMA slot a long stream that only needs
+            // the matrix pipe kept fed: the cell wave goes first wherever both want the SIMD's issue port
+            if (!(skipf & 32)) { if (hx == 0) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3); }
+            if (hx == 0) {
+                mfma_item(jc, s);
+                RT_MARK(0);
+                m_end_wait();
+                RT_MARK(1);
+            } else {
+                // item q - 2, whose stores B drained at the end of the slot before this one: (s, J - 2), or (s - 1, J + 2)
+                if (J >= 2) signal_item(JQ, s, true); else signal_item(JQ, s - 1, s >= 1);
+                // item q + 1 = (s, J + 1) reads h_(s-1) [needs s >= 1], or (s + 1, 0) reads h_s
+                const bool don = J + 1 < NT ? s >= 1 : more;
+                const unsigned dpar = J + 1 < NT ? parr : parw;
+                if (J >= 1) cell_item(JP, t, osoff, parw, JN, don, dpar);
+                else if (s >= 1) cell_item(JP, d == 0 ? t - 1 : t + 1, d == 0 ? osoff - ostride_by : osoff + ostride_by, parr, JN, don, dpar);
+                else { constexpr std::integral_constant<int, 0> G0; constexpr std::integral_constant<int, 1> G1;
+                       constexpr std::integral_constant<int, 2> G2; constexpr std::integral_constant<int, 3> G3;
+                       dma_group(JN, G0, don, dpar); dma_group(JN, G1, don, dpar); dma_group(JN, G2, don, dpar); dma_group(JN, G3, don, dpar); }
+                xg_request(jc, xstep);          // B's next cell item: q = (s, J)
+                RSTAMP(13);
+                RT_MARK(2);
+            }
+            ring_barrier();
+            RT_MARK(3 + hx);
+            // ---------------- odd slot 2q + 1: A finishes item q; B multiplies it and polls for item q + 2
+            if (!(skipf & 32)) { if (hx == 0) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }
+            if (hx == 0) {
+                cell_item(jc, t, osoff, parw, jc, false, 0u);
+                if (J + 1 < NT) xg_request(JN, xstep); else if (more) xg_request(JN, xnext);
+                RSTAMP(13);
+                RT_MARK(2);
+            } else {
+                // item q + 2 = (s, J + 2): its chain's step s - 1 [s >= 1]; or (s + 1, J - 2): its chain's step s
+                const bool pon = J + 2 < NT ? s >= 1 : more;
+                const int psp = J + 2 < NT ? s - 1 : s;
+                poll_issue(JQ, psp, pon);
+                mfma_item(jc, s);
+                RT_MARK(0);
+                m_end_wait();
+                poll_finish(JQ, psp, pon);
+                RT_MARK(1);
+            }
+            ring_barrier();
+            RT_MARK(4 - hx);
+        };
+        slots(std::integral_constant<int, 0>{});
+        slots(std::integral_constant<int, 1>{});
+        slots(std::integral_constant<int, 2>{});
+        slots(std::integral_constant<int, 3>{});
         if (STAMP && lane == 0) tacc[7] += 1;
     }
-    {   // the last cell: item (T - 1, 3)
-        constexpr std::integral_constant<int, 0> T0; constexpr std::integral_constant<int, 3> T3;
+    // ---------------- last slot: B finishes item (T - 1, NT - 1)
+    if (hx == 1) {
         const int t = d == 0 ? p.T - 1 : 0;
-        phase(T0, T3, T0, p.T, false, true, t, (unsigned)t * ostride_by, (unsigned)((p.T - 1) & 1) * hp_par, false, 0u, p.xp);
-        phase_end(T0, 0, false);
+        constexpr std::integral_constant<int, NT - 1> JL;
+        cell_item(JL, t, (unsigned)t * ostride_by, (unsigned)((p.T - 1) & 1) * hp_par, JL, false, 0u);
     }
+    ring_barrier();
 #undef TOK
 #undef RT_BEGIN
 #undef RT_MARK
@@ -446,6 +491,16 @@ bool launch_ring(const RingArgs& a, hipStream_t s, const EvPair& ev) {
     } while (0)
     if (a.dbg) {
         if constexpr (KIND == DSMI_RNN_GRU) { if (nkw == 7) { LAUNCH_R(7, true); return true; } }
+        return false;
+    }
+    if (a.skip) {           // timing experiments (DSMI_DEBUG_RING_SKIP): cfgA's shape only
+        if constexpr (KIND == DSMI_RNN_GRU) {
+            if (nkw == 7) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rnn_persist_ring_kernel<KIND, 7, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                DSMI_LAUNCH((rnn_persist_ring_kernel<KIND, 7, false, true>), grid, block, lds, s, ev, a);
+                return true;
+            }
+        }
         return false;
     }
     // NKW exact: every wave owns NKW or NKW - 1 k-blocks, so only the last block of the unrolled loops is conditional

@@ -14,13 +14,17 @@ buf = np.zeros((256, 8, 16), dtype=np.uint64)
 n = _native.lib().dsmi_debug_persist_stamps(m._h, 1, B, T, buf.ctypes.data_as(C.c_void_p), buf.size)
 assert n > 0, n
 raw = buf[:n].astype(np.float64)
-nte = 4
+nte = max((B + 15) // 16, 4)
 items = T * nte
-names = ["cell inputs + signal", "barrier 2", "requests + cell", "MFMAs + partial tiles", "poll + end wait", "poll spin", "barrier 1"]
-cols = [0, 1, 2, 3, 4, 5, 6]
-print("B %d: %d workgroups, %d phases; us per phase (median over workgroups)" % (B, n, items))
-for wv in (0, 1, 3, 4, 5, 7):
-    c = raw[:, wv, :]
-    us = c[:, cols] * 10.0 / 1000.0 / items
-    tot = np.median(us[:, 0] + us[:, 1] + us[:, 2] + us[:, 3] + us[:, 4] + us[:, 6])
-    print("wave %d: " % wv + " | ".join("%s %.3f" % (names[k], np.median(us[:, k])) for k in range(7)) + " | sum %.3f -> %.2f us per step" % (tot, tot * nte))
+names = ["M work", "M-end waits", "C work", "barrier after M", "barrier after C", "poll spin"]
+print("B %d: %d workgroups, %d items per half; us per item (median over workgroups); total per step = sum x %d tiles" % (B, n, items, nte))
+for half in (0, 1):
+    for wv in (0, 1, 3):
+        c = raw[:, 4 * half + wv, :]
+        us = c[:, :6] * 10.0 / 1000.0 / items
+        tot = np.median(us[:, 0] + us[:, 1] + us[:, 2] + us[:, 3] + us[:, 4])
+        print("half %s wave %d: " % ("AB"[half], wv) + " | ".join("%s %.3f" % (names[k], np.median(us[:, k])) for k in range(6)) +
+              " | sum %.3f -> %.2f us per step | M clock %.0f MHz" % (tot, tot * nte, np.median(c[:, 6] / np.maximum(c[:, 0], 1)) * 100.0))
+        cyc = c[:, 8:14] / items
+        print("      cycles per item: M head %.0f | MFMA loop %.0f | partials %.0f || DMA requests %.0f | reduce + cell %.0f | publish + xg %.0f" %
+              tuple(np.median(cyc[:, k]) for k in range(6)))

@@ -57,6 +57,16 @@ class _StreamingSession(object):
         return piece
 
 
+class _UnmergedDeviceClips(object):
+    """Device-resident batches on their way into one forward: merged on the stream that runs it."""
+
+    def __init__(self, batches):
+        self.batches = batches
+
+    def __len__(self):
+        return sum(len(b) for b in self.batches)
+
+
 class _BatchJob(object):
     """One batch between enqueue and decode."""
     __slots__ = ("order", "probs", "sizes", "count", "model", "ticket", "slot", "collected", "recomputed")
@@ -86,7 +96,7 @@ class DanSpeechRecognizer(object):
         self.model = self.model_name = self.labels = self.audio_config = self.audio_parser = None
         self._session = None
         self._side_streams = {}
-        self._replica = None
+        self._replicas = []
         if model_name:
             self.update_model(model_name)
         if lm_name:
@@ -103,7 +113,7 @@ class DanSpeechRecognizer(object):
         self.audio_config = model.audio_conf
         self.model = model.to(self.device)
         self.model.eval()
-        self._replica = None
+        self._replicas = []
         self.audio_parser = SpectrogramAudioParser(self.audio_config, device=self._device_index())
         # a new model may bring a new alphabet: the decoder follows
         self.update_decoder(labels=self.model.labels)
@@ -151,7 +161,8 @@ class DanSpeechRecognizer(object):
         import torch
         model = model or self.model
         if isinstance(recordings, DeviceClips):             # already on the device, longest first
-            order = np.arange(len(recordings))
+            order = getattr(recordings, "order", None)
+            order = np.arange(len(recordings)) if order is None else order      # (a merged batch remembers where its clips came from)
             # the clips were produced on whatever stream was current when the batch was handed over (an RCCL scatter, a widening
             # copy, a slicing kernel): the stream this batch runs on waits for that point, and the allocator learns of the use
             here = torch.cuda.current_stream(self._device_index())
@@ -214,82 +225,133 @@ class DanSpeechRecognizer(object):
             return []
         return self._finish_batch(self._enqueue_batch(recordings), show_all)
 
-    def transcribe_batches(self, batches, show_all=False):
-        """Generator over ``transcribe_batch(b)`` for every ``b`` of ``batches``, software-pipelined with TWO batches in
-        flight: batch i+1 is staged, uploaded (pinned double buffer, copy stream) and enqueued on the model's replica
-        -- its own stream and workspaces -- while batch i computes, so the latency-bound recurrent layers of the two
-        batches share the CUs and the dense kernels of one fill the other's waits; the decoder of a finished batch runs
-        on a side stream.  Results come out in order, one list per batch.  ``batches`` is read ONE batch ahead of the one being
-        enqueued (host clips are copied to pinned memory and uploaded before the loop waits for the GPU)."""
+    # how `transcribe_batches` fills the GPU: forwards in flight (each on a model handle, stream and persistent-kernel gate slot of
+    # its own) and clips per forward (consecutive batches are merged up to this many: the recurrent kernel walks up to four
+    # 16-clip tiles per workgroup, and its cost per clip falls with the tiles it walks)
+    pipeline_lanes = 4
+    pipeline_merge_clips = 64
+
+    def _lanes(self, count):
+        """The model handles, parsers and streams of the pipeline's forwards in flight: the engine's own and `count - 1` replicas."""
         import torch
-        if self._replica is None and hasattr(self.model, "replica"):
-            # the second batch in flight has its own model handle AND its own parser (frontend scratch, staging buffers)
-            self._replica = (self.model.replica(), SpectrogramAudioParser(self.audio_config, device=self._device_index()))
-        handles = [self.model, self._replica[0] if self._replica else self.model]
+        while len(self._replicas) < count - 1 and hasattr(self.model, "replica"):
+            # every forward in flight has its own model handle AND its own parser (frontend scratch, staging buffers)
+            self._replicas.append((self.model.replica(), SpectrogramAudioParser(self.audio_config, device=self._device_index())))
+        handles = [self.model] + [r[0] for r in self._replicas[:count - 1]]
+        parsers = [self.audio_parser] + [r[1] for r in self._replicas[:count - 1]]
+        streams = [torch.cuda.current_stream(self._device_index())] + [self._side_stream("lane %d" % k) for k in range(1, len(handles))]
+        return handles, parsers, streams
+
+    def transcribe_batches(self, batches, show_all=False, lanes=None, merge_clips=None):
+        """Generator over ``transcribe_batch(b)`` for every ``b`` of ``batches``, software-pipelined: consecutive batches are
+        merged into forwards of up to ``merge_clips`` clips (per-clip results do not depend on the batch they run in), and up to
+        ``lanes`` forwards are in flight, each on a model handle, stream and workspaces of its own -- the latency-bound
+        recurrent layers of several forwards run side by side on disjoint compute units while the dense kernels of the others
+        fill the rest of the chip; the decoder of a finished forward runs on a side stream.  Results come out in order, one
+        list per batch.  ``batches`` is read AHEAD of the results: up to ``merge_clips`` clips for the forward being put
+        together, plus one forward more (host clips are copied to pinned memory and uploaded before the loop waits for the
+        GPU) -- a source that produces a batch only after it has seen an earlier batch's result must pass ``lanes=1,
+        merge_clips=0``."""
+        import torch
+        import collections
+        lanes = self.pipeline_lanes if lanes is None else max(1, int(lanes))
+        merge_clips = self.pipeline_merge_clips if merge_clips is None else int(merge_clips)
+        handles, parsers, streams = self._lanes(lanes)
+        lanes = len(handles)
         for h in handles:
             if hasattr(h, "set_inflight"):
-                h.set_inflight(2)
-        parsers = [self.audio_parser, self._replica[1] if self._replica else self.audio_parser]
-        for ps in parsers:
-            ps.share_copy_stream = hasattr(self.decoder, "decode_enqueue")     # a search kernel on the decode stream: fewer streams
-        streams = [torch.cuda.current_stream(self._device_index()), self._side_stream("second batch")]
-        # Depth of the pipeline.  Greedy decoding is a short host-synchronous step: two batches in flight.  A beam search is a
-        # kernel of its own that starts when its forward ends: with two batches in flight the host would wait for batch b's
-        # search before it enqueues b + 2, and only ONE forward would be running meanwhile; with three (two forwards and the
-        # oldest batch's search) the GPU always has two forwards (config 3: 13.1 -> 9.9 ms per batch, tools/run_configs.py).
-        import collections
+                h.set_inflight(max(2, lanes) if lanes > 1 else 1)
         searching = hasattr(self.decoder, "decode_enqueue")
-        depth = 3 if searching else 2
+        for ps in parsers:
+            ps.share_copy_stream = searching     # a search kernel on the decode stream: fewer streams
+        # Depth of the pipeline in forwards.  Greedy decoding is a short host-synchronous step.  A beam search is a kernel of its
+        # own that starts when its forward ends: one more job in flight (the oldest forward's search) keeps every lane's forward
+        # running while the host waits for that search.
+        depth = lanes + 1 if searching else lanes
         pending, turn, count, job, done = collections.deque(), 0, 0, None, None
-        # Host clips are staged ONE BATCH AHEAD: pinned copy and upload need no model handle, and started only when the loop gets to
-        # the batch they would stand between the wait for the GPU below and the enqueue -- 3 ms of staging and PCIe per batch during
-        # which only one forward runs (9.2 -> 8.3 ms per step for 32 x 10 s of float64).  So the loop reads one batch ahead of the
-        # one it enqueues and stages it before it waits for anything.
         end = object()
         source = iter(batches)
+        held = [end, False]                      # a batch read from the source that did not fit the group being put together
+
+        def next_batch():
+            if held[1]:
+                held[1] = False
+                return held[0]
+            return next(source, end)
 
         def fetch(parser):
-            nxt = next(source, end)
-            ahead = None
-            if nxt is not end and len(nxt) and isinstance(nxt, DeviceClips):
-                # device-resident clips: ordered behind whatever produced them on the caller's stream (every second batch runs on
-                # the side stream, which nothing else orders behind the caller's)
+            """The next forward: consecutive batches of one kind (host clips / device-resident clips) up to merge_clips clips.
+            -> (parts, merged recordings, what _enqueue_batch needs of the staging) or None at the end of the source."""
+            first = next_batch()
+            if first is end:
+                return None
+            parts, total, on_device = [first], len(first), isinstance(first, DeviceClips)
+            while total and total < merge_clips:
+                nxt = next_batch()
+                if nxt is end:
+                    break
+                if isinstance(nxt, DeviceClips) != on_device or total + len(nxt) > merge_clips:
+                    held[0], held[1] = nxt, True
+                    break
+                parts.append(nxt)
+                total += len(nxt)
+            live = [b for b in parts if len(b)]
+            if not live:
+                return parts, [], None
+            if on_device:
+                # device-resident clips: ordered behind whatever produced them on the caller's stream (the lanes' streams are
+                # ordered behind nothing else); merged into one longest-first buffer on the LANE's stream, behind that point
                 ahead = torch.cuda.Event()
                 ahead.record(streams[0])
-            elif nxt is not end and len(nxt) and hasattr(parser, "stage"):
-                ahead = self._stage_batch(nxt, parser)
-            return nxt, ahead
+                return parts, (live[0] if len(live) == 1 else _UnmergedDeviceClips(live)), ahead
+            merged = live[0] if len(live) == 1 else [clip for b in live for clip in b]
+            return parts, merged, (self._stage_batch(merged, parser) if hasattr(parser, "stage") else None)
+
+        def results_of(done):
+            """A finished forward -> one result list per batch it was merged from."""
+            parts, job = done
+            res = self._finish_batch(job, show_all) if job is not None else []
+            out, lo = [], 0
+            for b in parts:
+                out.append(res[lo:lo + len(b)])
+                lo += len(b)
+            return out
 
         try:
-            recordings, staged = fetch(parsers[0])
-            while recordings is not end:
+            group = fetch(parsers[0])
+            while group is not None:
+                parts, merged, staged = group
                 job = None
-                enqueued = len(recordings) > 0
-                if enqueued:
-                    for older in pending:            # this batch's model handle gives back its previous forward first
-                        if isinstance(older, _BatchJob) and older.model is handles[turn]:
-                            older.collect_forward()
+                if len(merged):
+                    for older in pending:            # this forward's model handle gives back its previous forward first
+                        if older[1] is not None and older[1].model is handles[turn]:
+                            older[1].collect_forward()
                     with torch.cuda.stream(streams[turn]):
-                        job = self._enqueue_batch(recordings, handles[turn], parsers[turn], decode_slot=count % depth, staged=staged)
-                    turn ^= 1
+                        if isinstance(merged, _UnmergedDeviceClips):
+                            streams[turn].wait_event(staged)
+                            merged = DeviceClips.merge(merged.batches)
+                        job = self._enqueue_batch(merged, handles[turn], parsers[turn], decode_slot=count % depth, staged=staged)
+                    turn = (turn + 1) % lanes
                     count += 1
-                pending.append(job if job is not None else "empty")
+                pending.append((parts, job))
                 job = None
-                recordings, staged = fetch(parsers[turn])       # the next batch: staged now, before the waits below
+                group = fetch(parsers[turn])         # the next forward: staged now, before the waits below
                 while len(pending) >= depth:
                     done = pending.popleft()
-                    res = self._finish_batch(done, show_all) if done != "empty" else []
+                    res = results_of(done)
                     done = None
-                    yield res
+                    for r in res:
+                        yield r
             while pending:
                 done = pending.popleft()
-                res = self._finish_batch(done, show_all) if done != "empty" else []
+                res = results_of(done)
                 done = None
-                yield res
+                for r in res:
+                    yield r
         finally:
             # the caller stopped early, or a batch raised: whatever is still enqueued gives its forward and its beam-search
             # ticket back, otherwise the decoder handle stays "not collected" and every later call on this engine fails
-            for left in [done, job] + list(pending):
+            for left in [done[1] if done else None, job] + [pj[1] for pj in pending]:
                 if isinstance(left, _BatchJob):
                     self._abandon(left)
             for h in handles:

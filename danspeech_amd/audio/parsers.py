@@ -57,6 +57,21 @@ class DeviceClips(object):
         offs = np.concatenate(([0], np.cumsum(self.n_samples)))
         return DeviceClips(self.pcm[int(offs[lo]):int(offs[hi])], self.n_samples[lo:hi])
 
+    @staticmethod
+    def merge(batches):
+        """Several batches (one sample type) as one, longest first (a stable merge: every batch is ordered already); one gather on
+        the current stream."""
+        import torch
+        n = np.concatenate([b.n_samples for b in batches])
+        order = np.argsort(-n, kind="stable")
+        pieces, k = [], 0
+        for b in batches:
+            offs = np.concatenate(([0], np.cumsum(b.n_samples)))
+            pieces += [b.pcm[int(offs[i]):int(offs[i + 1])] for i in range(len(b))]
+        merged = DeviceClips(torch.cat([pieces[i] for i in order]), n[order])
+        merged.order = order            # merged clip i is clip order[i] of the batches laid end to end
+        return merged
+
 
 class AudioParser(object):
     def __init__(self, audio_config=None):

@@ -187,17 +187,19 @@ def test_tiny_weights_and_saturating_gates(native, kind):
     m.close(); m1.close()
 
 
-@pytest.mark.parametrize("variant", ["paired", "half", "whole"])
+@pytest.mark.parametrize("variant", ["ring", "paired", "half", "whole"])
 def test_two_batches_in_flight_on_two_handles(native, variant):
     """Two handles, two streams, forwards enqueued back to back without waiting.  The kernel variant follows from what the
     caller says (set_inflight) and the batch: two batches in flight of 17+ clips -> the paired-tile kernel, each batch on its
     own half of the chip; of at most 16 clips -> half-CU workgroups, the two batches' kernels co-resident on the same CUs;
-    one batch in flight -> whole-CU workgroups, which the gate chains.  Either way both batches must equal the oracle,
-    repeatedly."""
+    one batch in flight -> whole-CU workgroups, which the gate chains.  Since round 4 batches in flight run the ring kernel, each
+    on its own gate slot ("ring"); DSMI_RNN_KERNEL=duo keeps the older kernels reachable ("paired", "half").  Either way both
+    batches must equal the oracle, repeatedly."""
     from oracle import torch_port as tp
     cfg = _cfg(800, 2)
     sd = syn.make_state_dict(2, "gru", 800, 2, seed=31, **syn.TALKATIVE)
-    models = [native.NativeModel(cfg, sd) for _ in range(2)]
+    with _env(**({} if variant in ("ring", "whole") else dict(DSMI_RNN_KERNEL="duo"))):
+        models = [native.NativeModel(cfg, sd) for _ in range(2)]
     for m in models:
         m.set_inflight(1 if variant == "whole" else 2)
     streams = [torch.cuda.Stream() for _ in range(2)]
@@ -237,7 +239,8 @@ def test_paired_tile_kernel_equals_oracle_and_the_single_tile_kernels(native, ki
     ref, ol_ref = tp.forward(sd, cfg, x, lens)
     outs = []
     for inflight in (2, 1):
-        m = native.NativeModel(cfg, sd)
+        with _env(DSMI_RNN_KERNEL="duo"):          # (batches in flight run the ring kernel by default: tests/test_gpu_ring.py)
+            m = native.NativeModel(cfg, sd)
         m.set_inflight(inflight)
         p, ol = m.forward(_dev(x), lens)
         assert np.array_equal(ol, ol_ref) and m.recompute_count() == 0
@@ -248,21 +251,26 @@ def test_paired_tile_kernel_equals_oracle_and_the_single_tile_kernels(native, ki
         np.testing.assert_allclose(outs[0][b, :ol_ref[b]], outs[1][b, :ol_ref[b]], rtol=0, atol=5e-5)
 
 
-def test_paired_tile_kernel_timeout_is_recomputed(native):
+@pytest.mark.parametrize("H,B,drop", [(64, 24, "1:2:9"), (800, 96, "1:3:11")])
+def test_paired_tile_kernel_timeout_is_recomputed(native, H, B, drop):
+    """The paired-tile kernel's own hand-off timeout (DSMI_RNN_KERNEL=duo, two batches in flight): one pair on the handle's lane,
+    and H = 800 with 96 clips = three tile pairs in two windows, several launches sharing one error word and one counter array."""
     from oracle import torch_port as tp
-    cfg = _cfg(64, 2)
-    sd = syn.make_state_dict(2, "gru", 64, 2, seed=63, **syn.TALKATIVE)
-    x, lens = _batch(B=24, T=161, seed=64)
+    cfg = _cfg(H, 2)
+    sd = syn.make_state_dict(2, "gru", H, 2, seed=63, **syn.TALKATIVE)
+    x, lens = _batch(B=B, T=161, seed=64)
     ref, _ = tp.forward(sd, cfg, x, lens)
-    with _env(DSMI_DEBUG_DROP_SIGNAL="1:2:9", DSMI_DEBUG_SPIN_LIMIT="3000"):
+    with _env(DSMI_DEBUG_DROP_SIGNAL=drop, DSMI_DEBUG_SPIN_LIMIT="3000", DSMI_RNN_KERNEL="duo"):
         m = native.NativeModel(cfg, sd)
+    m.set_inflight(2)
+    m.set_profiling(2)
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
         p, ol = m.forward(_dev(x), lens, check=False)
         assert m.status() is True
     assert m.recompute_count() == 1
     pn = p.cpu().numpy()
-    for b in range(24):
+    for b in range(B):
         np.testing.assert_allclose(pn[b, :ol[b]], ref[b, :ol[b]], rtol=0, atol=1e-4)
     m.close()
 
@@ -291,7 +299,7 @@ def test_pipelined_beam_search_survives_a_recomputed_batch(native, tmp_path):
             warnings.simplefilter("always")
             got = list(rec2.recognize_batches(batches, show_all=True))
     assert got == want
-    handles = [eng.model._native] + ([eng._replica[0]._native] if eng._replica else [])
+    handles = [eng.model._native] + [r[0]._native for r in eng._replicas]
     assert sum(h.recompute_count() for h in handles) >= 1 and any("timed out" in str(x.message) for x in w)
     assert rec2.recognize_batch(batches[0], show_all=True) == want[0]
 

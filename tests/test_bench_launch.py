@@ -29,6 +29,18 @@ def test_bench_starts_its_own_ranks_dry_run():
     assert line["config"]["parallelism"] == "utterance-dp2"
 
 
+def test_bench_eight_ranks_dry_run():
+    """What the driver's scaling run invokes, `python bench.py --gpus 8 ...`: eight fresh rank processes, one line, every rank's
+    transcripts gathered on rank 0 in every step."""
+    r = _run(["--gpus", "8", "--dry-run", "--steps", "2", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["scaling"] == "weak" and line["config"]["parallelism"] == "utterance-dp8"
+    assert line["transcripts_gathered"] == 8 * line["config"]["clips_per_gpu"]
+
+
 def test_bench_single_rank_dry_run_has_the_same_line_shape():
     r = _run(["--dry-run", "--steps", "2", "--warmup", "0"])
     assert r.returncode == 0, r.stderr[-2000:]

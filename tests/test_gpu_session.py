@@ -158,9 +158,10 @@ def test_c_host_example_equals_python_surface(tmp_path):
     assert len(want) >= 10 and r.stdout.splitlines() == [want, want]
 
 
-def test_comm_two_ranks_over_mock_transport(tmp_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_comm_two_ranks_over_mock_transport(tmp_path, world):
     """The N > 1 loops of comm.hip (plan, slice offsets, grouped sends / receives, gather rows, fewer clips than ranks) with
-    TWO rank processes on this box's single GPU.  RCCL refuses two ranks on one device, so the transport is
+    two and FOUR rank processes on this box's single GPU.  RCCL refuses two ranks on one device, so the transport is
     tests/mock_rccl.c -- same entry points, messages as files -- loaded through DSMI_RCCL_LIBRARY; everything above it
     (device buffers, staging, the session's device-resident path) is the product code."""
     import os
@@ -178,8 +179,8 @@ def test_comm_two_ranks_over_mock_transport(tmp_path):
     # (one process per GPU gets the persistent kernels: both ranks on the per-step path, so that every transcript comes
     # from the same arithmetic whichever rank computed it)
     env = dict(os.environ, DSMI_RCCL_LIBRARY=mock, MOCK_RCCL_DIR=str(work), DSMI_RNN_MODE="steps")
-    procs = [subprocess.Popen([sys.executable, os.path.join(here, "_comm_rank.py"), str(r), "2", str(work)], env=env,
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(here, "_comm_rank.py"), str(r), str(world), str(work)], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = [p.communicate(timeout=900)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert (work / "ok").exists()

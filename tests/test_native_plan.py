@@ -18,6 +18,26 @@ def test_native_plan_equals_python_plan(n, world, seed):
     assert sorted(np.concatenate(shards).tolist() if n else []) == list(range(n))
 
 
+def test_config5_shaped_plan_is_balanced_over_eight_ranks():
+    """BASELINE.json configs[4]: 1024 ragged clips of up to 30 s over 8 ranks.  Every rank gets 128 clips, longest first, and a
+    share of the samples within 2 % of the mean (longest-first round-robin dealing: rank r gets the clips of rank r, r + 8, ...
+    in length order), from both plans."""
+    from danspeech_amd import _native, parallel
+    rng = np.random.default_rng(55)
+    lengths = (rng.uniform(4.0, 30.0, size=1024) * 16000).astype(np.int64)
+    lengths[:8] = 480000
+    rank_of, slot_of = _native.plan_shards(lengths, 8)
+    shards = parallel.plan_shards(lengths, 8)
+    totals = []
+    for r, idx in enumerate(shards):
+        assert len(idx) == 128
+        assert all(rank_of[i] == r and slot_of[i] == k for k, i in enumerate(idx))
+        assert all(lengths[idx[j]] >= lengths[idx[j + 1]] for j in range(len(idx) - 1))
+        totals.append(int(lengths[idx].sum()))
+    mean = float(np.mean(totals))
+    assert max(abs(t - mean) for t in totals) < 0.02 * mean, totals
+
+
 def test_native_plan_rejects_bad_arguments():
     from danspeech_amd import _native
     with pytest.raises(_native.DsmiError):

@@ -35,21 +35,26 @@ def run(name, rec, B, seconds, reps=3):
         out = rec.recognize_batch(clips)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
-    for _ in rec.recognize_batches([clips] * 6):       # (the pipeline's own buffers: replica handles, decoder slots, allocator)
-        pass
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    n = 0
-    for _ in rec.recognize_batches([clips] * (4 * reps + 2)):
-        n += 1
-    torch.cuda.synchronize()
-    dp = (time.perf_counter() - t0) / n
-    print("%-58s one call %7.1f ms = %7.0f audio-s/s | stream of batches %7.1f ms/batch = %7.0f audio-s/s"
-          % (name, dt * 1e3, B * seconds / dt, dp * 1e3, B * seconds / dp), flush=True)
+    streams = []
+    nb = max(4 * reps + 2, 1024 // B)
+    for lanes in (2, 4):
+        rec.danspeech_recognizer.pipeline_lanes = lanes
+        for _ in rec.recognize_batches([clips] * max(6, 512 // B)):   # (the pipeline's own buffers: replica handles, decoder slots, allocator)
+            pass
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 0
+        for res in rec.recognize_batches([clips] * nb):
+            n += 1
+            assert res == out
+        torch.cuda.synchronize()
+        streams.append((time.perf_counter() - t0) / n)
+    print("%-58s one call %7.1f ms = %7.0f audio-s/s | stream of %d batches, 2 / 4 forwards in flight %7.1f / %7.1f ms per batch = %7.0f audio-s/s"
+          % (name, dt * 1e3, B * seconds / dt, nb, streams[0] * 1e3, streams[1] * 1e3, B * seconds / min(streams)), flush=True)
     return out
 
 
-which = [int(a) for a in sys.argv[1:]] or [2, 3, 4, 5, 6]
+which = ([int(a) for a in sys.argv[1:]] or [2, 3, 4, 5, 6]) if __name__ == "__main__" else []
 if 2 in which:
     run("config 2: cfgA greedy B=32 x 10 s", build(800, 5), 32, 10.0)
 if 3 in which:

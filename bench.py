@@ -158,6 +158,8 @@ def main(argv=None):
     ap.add_argument("--hidden", type=int, default=None, help="experiments: another hidden size (the JSON line then names it)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle run (and with it the parity check)")
     ap.add_argument("--no-side-paths", action="store_true", help="skip device_resident, abi_path and f32_strict")
+    ap.add_argument("--timed-input", default="host", choices=["host", "device"],
+                    help="profiling only: time the device-resident entry instead of the metric's host-array entry (the line says so)")
     ap.add_argument("--strict-f32-child", action="store_true", help=argparse.SUPPRESS)     # the f32_strict side run (a fresh process)
     ap.add_argument("--no-kernel-sampling", action="store_true")
     ap.add_argument("--dry-run", action="store_true", help="CPU only: launch, scatter, gather and the JSON line with a stand-in engine")
@@ -225,6 +227,8 @@ def main(argv=None):
     # what the metric's entry takes: float64 HOST arrays, as load_audio returns them (reference Recognizer.py:82-95, resources.py:640);
     # at N > 1 every rank times the same entry on the shard it received
     host_clips = [row for row in pcm.view(B, -1).cpu().numpy()] if not dry else clips
+    if args.timed_input == "device":
+        host_clips = clips
     cap = max((n_samples // 160 + 1 + 1) // 2, 16)   # a transcript is never longer than the OUTPUT frame count (time stride 2)
     positions = np.arange(rank * B, (rank + 1) * B)
 
@@ -320,8 +324,9 @@ def main(argv=None):
             "data": "synthetic" if not dry else "dry-run (CPU stand-in engine: NOT a measurement)",
             "config": {"workload": "BASELINE.json configs[1]: 2conv + 5xBiGRU%d (DanSpeechPrimary per BASELINE), greedy CTC, "
                                    "batch=%d x %.0f s 16 kHz clips per GPU, STFT+forward+decode" % (c["rnn_hidden_size"], B, c["seconds"]),
-                       "entry": "Recognizer.recognize_batches: float64 HOST arrays -> strings on the host (pinned staging and the PCIe "
-                                "upload inside the timed region); the caller hands over batches of %d clips" % B,
+                       "entry": ("Recognizer.recognize_batches: float64 HOST arrays -> strings on the host (pinned staging and the PCIe "
+                                 "upload inside the timed region); the caller hands over batches of %d clips" % B) if args.timed_input == "host"
+                                else "PROFILING RUN, not the metric's entry: Recognizer.recognize_batches(DeviceClips), float64 PCM resident in HBM",
                        "clips_per_gpu": B, "clip_seconds": n_samples / 16000.0, "parallelism": "utterance-dp%d" % world,
                        "forwards_in_flight": P, "clips_per_forward": merge_clips,
                        "batches_in_flight": P * max(merge_clips // B, 1)},

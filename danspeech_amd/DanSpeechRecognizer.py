@@ -180,16 +180,21 @@ class DanSpeechRecognizer(object):
         probs, sizes = model.enqueue(feats, torch.from_numpy(frames.astype(np.int32)))
         job = _BatchJob(order, probs, sizes, len(recordings), model)
         if decode_slot is not None and hasattr(self.decoder, "decode_enqueue"):
-            # the beam search is a kernel: launched now, behind this forward, on a stream of its own, so that the host
-            # never waits for it while it could be feeding the next batch
-            side = self._side_stream("decode")           # one decode stream for both slots: see audio/parsers.py on hardware queues
-            done = torch.cuda.Event()
-            done.record(torch.cuda.current_stream(self._device_index()))
-            side.wait_event(done)
-            probs.record_stream(side)
             job.slot = decode_slot
-            with torch.cuda.stream(side):
+            if getattr(self.decoder, "on_lane", False):
+                # greedy decoding: a short kernel and three small copies, queued right behind the forward on its own stream -- the
+                # host never stands in a busy device's copy queue while the stream it should be feeding runs dry
                 job.ticket = self.decoder.decode_enqueue(probs, sizes, slot=decode_slot)
+            else:
+                # the beam search is a kernel: launched now, behind this forward, on a stream of its own, so that the host
+                # never waits for it while it could be feeding the next batch
+                side = self._side_stream("decode")           # one decode stream for all slots: see audio/parsers.py on hardware queues
+                done = torch.cuda.Event()
+                done.record(torch.cuda.current_stream(self._device_index()))
+                side.wait_event(done)
+                probs.record_stream(side)
+                with torch.cuda.stream(side):
+                    job.ticket = self.decoder.decode_enqueue(probs, sizes, slot=decode_slot)
         return job
 
     def _finish_batch(self, job, show_all, warn=True):
@@ -261,7 +266,7 @@ class DanSpeechRecognizer(object):
         for h in handles:
             if hasattr(h, "set_inflight"):
                 h.set_inflight(max(2, lanes) if lanes > 1 else 1)
-        searching = hasattr(self.decoder, "decode_enqueue")
+        searching = hasattr(self.decoder, "decode_enqueue") and not getattr(self.decoder, "on_lane", False)
         for ps in parsers:
             ps.share_copy_stream = searching     # a search kernel on the decode stream: fewer streams
         # Depth of the pipeline in forwards.  Greedy decoding is a short host-synchronous step.  A beam search is a kernel of its
@@ -330,13 +335,15 @@ class DanSpeechRecognizer(object):
                         if isinstance(merged, _UnmergedDeviceClips):
                             streams[turn].wait_event(staged)
                             merged = DeviceClips.merge(merged.batches)
-                        job = self._enqueue_batch(merged, handles[turn], parsers[turn], decode_slot=count % depth, staged=staged)
+                        job = self._enqueue_batch(merged, handles[turn], parsers[turn], decode_slot=count % (depth + 1), staged=staged)
                     turn = (turn + 1) % lanes
                     count += 1
                 pending.append((parts, job))
                 job = None
                 group = fetch(parsers[turn])         # the next forward: staged now, before the waits below
-                while len(pending) >= depth:
+                # (one more than `depth` may be pending for a moment: the oldest forward has been waited for above -- it ran on the
+                # lane that was just refilled -- and only its strings are still to be made, while every lane is busy again)
+                while len(pending) > depth:
                     done = pending.popleft()
                     res = results_of(done)
                     done = None

@@ -93,6 +93,8 @@ _PROTOS = {
     "dsmi_conv_stack": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
     "dsmi_rnn_layer": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
     "dsmi_greedy": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
+    "dsmi_greedy_enqueue": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp]),
+    "dsmi_greedy_collect": (C.c_int, [_vp, _vp, _vp, _vp]),
     "dsmi_set_profiling": (C.c_int, [_vp, C.c_int]),
     "dsmi_stage_time_us": (C.c_double, [_vp, C.c_int]),
     "dsmi_kernel_stats": (C.c_int, [_vp, C.c_int, _i64p, _i64p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
@@ -533,6 +535,22 @@ class NativeDecoder:
         sz = None if sizes is None else np.ascontiguousarray(sizes, dtype=np.int32)
         self._check(lib().dsmi_greedy(self._h, probs.data_ptr(), None if sz is None else _np_ptr(sz), B, T,
                                       _np_ptr(ids), _np_ptr(offs), _np_ptr(n), _stream(self.device)))
+        return [(ids[b, :n[b]].copy(), offs[b, :n[b]].copy()) for b in range(B)]
+
+    def greedy_enqueue(self, probs, sizes=None):
+        """Launch the greedy decode and the copies of its results on the current stream and return at once."""
+        B, T = probs.shape[0], probs.shape[1]
+        sz = None if sizes is None else np.ascontiguousarray(sizes, dtype=np.int32)
+        self._check(lib().dsmi_greedy_enqueue(self._h, probs.data_ptr(), None if sz is None else _np_ptr(sz), B, T, _stream(self.device)))
+        self._greedy_pending = (probs, B, T)                     # keeps the probabilities alive until the collect
+
+    def greedy_collect(self):
+        _, B, T = self._greedy_pending
+        self._greedy_pending = None
+        ids = np.empty((B, T), dtype=np.int32)
+        offs = np.empty((B, T), dtype=np.int32)
+        n = np.empty(B, dtype=np.int32)
+        self._check(lib().dsmi_greedy_collect(self._h, _np_ptr(ids), _np_ptr(offs), _np_ptr(n)))
         return [(ids[b, :n[b]].copy(), offs[b, :n[b]].copy()) for b in range(B)]
 
     def beam(self, probs, sizes=None, beam_width=64, cutoff_top_n=40, cutoff_prob=1.0):

@@ -9,6 +9,7 @@
 // algorithm, oracle/beam_flat.py the kernel's own formulation of it (implicit prefix trie held on chip, edge tuples, one-pass
 // histogram selection); the parity tests compare with both.  DESIGN.md 4 "Beam search" describes the frame's six phases.
 #include "common.h"
+#include <cstring>
 #include "lm.h"
 #include "lm.cpp.inc"
 #include "lm_klm.cpp.inc"
@@ -31,6 +32,8 @@ struct dsmi_decoder {
     // greedy scratch
     size_t greedy_cap = 0;
     int32_t *g_raw = nullptr, *g_ids = nullptr, *g_offs = nullptr, *g_nout = nullptr, *g_sizes = nullptr;
+    // dsmi_greedy_enqueue / _collect: pinned host images of the results and of the sizes, the event behind the last copy
+    int32_t* gh = nullptr; size_t gh_cap = 0; hipEvent_t g_done = nullptr; bool greedy_pending = false; int gp_B = 0, gp_T = 0;
     // LM
     bool has_lm = false;
     HostLM lm;
@@ -90,6 +93,8 @@ extern "C" void dsmi_decoder_destroy(dsmi_decoder* d) {
     if (d && d->beam_done) { (void)hipEventDestroy(d->beam_done); d->beam_done = nullptr; }
     if (d && d->copy_stream) { (void)hipStreamDestroy(d->copy_stream); d->copy_stream = nullptr; }
     if (d && d->pin_sz) { (void)hipHostFree(d->pin_sz); d->pin_sz = nullptr; }
+    if (d && d->gh) { (void)hipSetDevice(d->device); (void)hipDeviceSynchronize(); (void)hipHostFree(d->gh); d->gh = nullptr; }
+    if (d && d->g_done) { (void)hipEventDestroy(d->g_done); d->g_done = nullptr; }
     if (!d) return;
     (void)hipSetDevice(d->device);
     (void)hipDeviceSynchronize();
@@ -136,12 +141,7 @@ extern "C" int dsmi_decoder_set_lm(dsmi_decoder* d, const char* path, double alp
     return DSMI_OK;
 }
 
-extern "C" int dsmi_greedy(dsmi_decoder* d, const float* probs, const int32_t* sizes, int B, int To,
-                           int32_t* ids, int32_t* offsets, int32_t* n_out, void* stream) {
-    if (!d) return DSMI_ERR_INVALID;
-    if (!probs || !ids || !offsets || !n_out || B < 1 || To < 1) { d->err = "bad greedy arguments"; return DSMI_ERR_INVALID; }
-    DEC_HIP(d, hipSetDevice(d->device));
-    hipStream_t s = (hipStream_t)stream;
+static int greedy_reserve(dsmi_decoder* d, int B, int To) {
     if ((size_t)B * To > d->greedy_cap) {
         DEC_HIP(d, hipDeviceSynchronize());
         for (void* p : {(void*)d->g_raw, (void*)d->g_ids, (void*)d->g_offs, (void*)d->g_nout, (void*)d->g_sizes}) if (p) (void)hipFree(p);
@@ -152,6 +152,17 @@ extern "C" int dsmi_greedy(dsmi_decoder* d, const float* probs, const int32_t* s
         DEC_HIP(d, hipMalloc((void**)&d->g_nout, sizeof(int32_t) * d->greedy_cap));
         DEC_HIP(d, hipMalloc((void**)&d->g_sizes, sizeof(int32_t) * d->greedy_cap));
     }
+    return DSMI_OK;
+}
+
+extern "C" int dsmi_greedy(dsmi_decoder* d, const float* probs, const int32_t* sizes, int B, int To,
+                           int32_t* ids, int32_t* offsets, int32_t* n_out, void* stream) {
+    if (!d) return DSMI_ERR_INVALID;
+    if (!probs || !ids || !offsets || !n_out || B < 1 || To < 1) { d->err = "bad greedy arguments"; return DSMI_ERR_INVALID; }
+    DEC_HIP(d, hipSetDevice(d->device));
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if ((rc = greedy_reserve(d, B, To))) return rc;
     if (sizes) DEC_HIP(d, hipMemcpyAsync(d->g_sizes, sizes, sizeof(int32_t) * B, hipMemcpyHostToDevice, s));
     launch_greedy(probs, sizes ? d->g_sizes : nullptr, B, To, (int)d->labels.size(), d->blank, d->g_raw, d->g_ids, d->g_offs, d->g_nout, s);
     DEC_HIP(d, hipMemcpyAsync(ids, d->g_ids, sizeof(int32_t) * (size_t)B * To, hipMemcpyDeviceToHost, s));
@@ -159,6 +170,56 @@ extern "C" int dsmi_greedy(dsmi_decoder* d, const float* probs, const int32_t* s
     DEC_HIP(d, hipMemcpyAsync(n_out, d->g_nout, sizeof(int32_t) * B, hipMemcpyDeviceToHost, s));
     DEC_HIP(d, hipStreamSynchronize(s));
     DEC_HIP(d, hipGetLastError());
+    return DSMI_OK;
+}
+
+// The same in two halves for a caller that keeps batches in flight: _enqueue launches the kernel and the copies of its results
+// (into pinned memory of the handle's own) on `stream` -- behind the forward that writes `probs` -- and returns at once;
+// _collect waits for them and hands the arrays over.  The host never stands in a copy queue of a busy device while a stream it
+// could be feeding runs dry.
+extern "C" int dsmi_greedy_enqueue(dsmi_decoder* d, const float* probs, const int32_t* sizes, int B, int To, void* stream) {
+    if (!d) return DSMI_ERR_INVALID;
+    if (!probs || B < 1 || To < 1) { d->err = "bad greedy arguments"; return DSMI_ERR_INVALID; }
+    if (d->greedy_pending) { d->err = "the previous greedy decode has not been collected"; return DSMI_ERR_INVALID; }
+    DEC_HIP(d, hipSetDevice(d->device));
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if ((rc = greedy_reserve(d, B, To))) return rc;
+    const size_t rows = (size_t)B * To, need = 2 * rows + 2 * (size_t)B;         // ids, offsets, n_out, sizes
+    if (need > d->gh_cap) {
+        DEC_HIP(d, hipDeviceSynchronize());
+        if (d->gh) (void)hipHostFree(d->gh);
+        d->gh = nullptr;
+        DEC_HIP(d, hipHostMalloc((void**)&d->gh, sizeof(int32_t) * need, hipHostMallocDefault));
+        d->gh_cap = need;
+    }
+    if (!d->g_done) DEC_HIP(d, hipEventCreateWithFlags(&d->g_done, hipEventDisableTiming));
+    int32_t *h_ids = d->gh, *h_offs = d->gh + rows, *h_n = d->gh + 2 * rows, *h_sz = d->gh + 2 * rows + B;
+    if (sizes) {
+        std::memcpy(h_sz, sizes, sizeof(int32_t) * B);
+        DEC_HIP(d, hipMemcpyAsync(d->g_sizes, h_sz, sizeof(int32_t) * B, hipMemcpyHostToDevice, s));
+    }
+    launch_greedy(probs, sizes ? d->g_sizes : nullptr, B, To, (int)d->labels.size(), d->blank, d->g_raw, d->g_ids, d->g_offs, d->g_nout, s);
+    DEC_HIP(d, hipMemcpyAsync(h_ids, d->g_ids, sizeof(int32_t) * rows, hipMemcpyDeviceToHost, s));
+    DEC_HIP(d, hipMemcpyAsync(h_offs, d->g_offs, sizeof(int32_t) * rows, hipMemcpyDeviceToHost, s));
+    DEC_HIP(d, hipMemcpyAsync(h_n, d->g_nout, sizeof(int32_t) * B, hipMemcpyDeviceToHost, s));
+    DEC_HIP(d, hipEventRecord(d->g_done, s));
+    DEC_HIP(d, hipGetLastError());
+    d->greedy_pending = true; d->gp_B = B; d->gp_T = To;
+    return DSMI_OK;
+}
+
+extern "C" int dsmi_greedy_collect(dsmi_decoder* d, int32_t* ids, int32_t* offsets, int32_t* n_out) {
+    if (!d) return DSMI_ERR_INVALID;
+    if (!d->greedy_pending) { d->err = "no greedy decode to collect"; return DSMI_ERR_INVALID; }
+    if (!ids || !offsets || !n_out) { d->err = "bad greedy arguments"; return DSMI_ERR_INVALID; }
+    d->greedy_pending = false;
+    DEC_HIP(d, hipSetDevice(d->device));
+    DEC_HIP(d, hipEventSynchronize(d->g_done));
+    const size_t rows = (size_t)d->gp_B * d->gp_T;
+    std::memcpy(ids, d->gh, sizeof(int32_t) * rows);
+    std::memcpy(offsets, d->gh + rows, sizeof(int32_t) * rows);
+    std::memcpy(n_out, d->gh + 2 * rows, sizeof(int32_t) * d->gp_B);
     return DSMI_OK;
 }
 

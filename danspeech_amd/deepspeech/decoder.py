@@ -102,6 +102,26 @@ class GreedyDecoder(Decoder):
         offsets = [[torch.from_numpy(off.astype(np.int32))] for _, off in res]
         return strings, offsets
 
+    # the same in two halves for the batch pipeline (DanSpeechRecognizer.transcribe_batches): the kernel and the copies of its
+    # results are queued right behind the forward, on the forward's own stream (on_lane: no side stream), `slot` = one native
+    # handle per forward in flight
+    on_lane = True
+
+    def decode_enqueue(self, probs, sizes=None, slot=0):
+        import torch
+        probs = self._on_gpu(probs)
+        dec = self._dec(probs.device.index or 0, slot)
+        sz = None if sizes is None else np.asarray(torch.as_tensor(sizes).cpu()).astype(np.int32)
+        dec.greedy_enqueue(probs, sz)
+        return dec
+
+    def decode_collect(self, ticket):
+        import torch
+        res = ticket.greedy_collect()
+        strings = [[self._to_string(ids)] for ids, _ in res]
+        offsets = [[torch.from_numpy(off.astype(np.int32))] for _, off in res]
+        return strings, offsets
+
 
 class BeamCTCDecoder(Decoder):
     """decoder.py:91-144.  ``lm_path`` may be an ARPA text model; ``num_processes`` is accepted for

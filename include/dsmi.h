@@ -216,6 +216,12 @@ const char* dsmi_decoder_last_error(const dsmi_decoder* d);
  * ids_host/offsets_host: [B][T_out] int32, first n_out_host[b] entries valid.  Synchronises. */
 int dsmi_greedy(dsmi_decoder* d, const float* probs_dev, const int32_t* sizes_host, int B, int T_out,
                 int32_t* ids_host, int32_t* offsets_host, int32_t* n_out_host, void* stream);
+/* The same call in two halves for a host that keeps batches in flight (no reference counterpart: GreedyDecoder.decode is a
+ * host loop, decoder.py:166-198).  _enqueue launches the kernel and the copies of its results on `stream` -- behind the
+ * dsmi_forward that writes probs_dev -- and returns at once; _collect waits for them and fills the arrays of dsmi_greedy.
+ * One decode per handle at a time. */
+int dsmi_greedy_enqueue(dsmi_decoder* d, const float* probs_dev, const int32_t* sizes_host, int B, int T_out, void* stream);
+int dsmi_greedy_collect(dsmi_decoder* d, int32_t* ids_host, int32_t* offsets_host, int32_t* n_out_host);
 
 /* ---- measurement hooks (no reference counterpart; SURVEY 5 "tracing/profiling": none).
  * level 0: off.  level 1: per-stage hipEvents around the last dsmi_forward (synchronises).

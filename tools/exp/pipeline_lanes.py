@@ -16,11 +16,13 @@ host = [syn.make_clip(i, N) for i in range(B)]
 pcm = torch.from_numpy(np.stack(host)).cuda()
 clips = DeviceClips(pcm.view(-1), np.full(B, N, dtype=np.int64))
 want = None
-combos = [(2, 64), (3, 64), (4, 64), (4, 32)] if not os.environ.get("DSMI_RNN_KERNEL") else [(2, 32), (2, 64), (4, 32)]
+combos = [(4, 64), (5, 64), (6, 64), (8, 64)] if not os.environ.get("DSMI_RNN_KERNEL") else [(2, 32), (2, 64), (4, 32)]
 for lanes, merge in combos:
     eng = rec.danspeech_recognizer
+    host16 = [h.astype(np.int16) for h in host]
+    host32 = [h.astype(np.float32) for h in host]
     for kind, src in (("device", lambda: (clips for _ in range(steps))), ("host", lambda: (host for _ in range(steps)))):
-        for res in eng.transcribe_batches((clips if kind == "device" else host for _ in range(8)), lanes=lanes, merge_clips=merge):
+        for res in eng.transcribe_batches((src() if False else (clips if kind == "device" else {"host": host, "host16": host16, "host32": host32}[kind]) for _ in range(16)), lanes=lanes, merge_clips=merge):
             pass
         torch.cuda.synchronize()
         t0 = time.perf_counter()

@@ -267,11 +267,11 @@ unsigned hchs = hchs_, cnts = cnts_, orows = orows_, xrows = xrows_;
     // the item B requests meanwhile (dma_group).  The slot is a chain of latencies in ONE wave per SIMD (the partner multiplies), so
     // it is kept short: every LDS read goes out first, and the publish needs no LDS -- the eight lanes of a clip hand their
     // (hi | lo << 16) words to the clip's first lane by DPP row shifts, which stores both planes' 16 bytes.
-    auto cell_item = [&](auto jc, int t, unsigned osoff, unsigned parw, auto djc, bool don, unsigned dpar) {
+    auto cell_item = [&](auto jc, int t, unsigned osoff, unsigned parw, auto djc, bool don, unsigned dpar, auto xjc, const float* xptr, bool xon) {
         constexpr int J = decltype(jc)::value;
         constexpr std::integral_constant<int, 0> G0; constexpr std::integral_constant<int, 1> G1;
         constexpr std::integral_constant<int, 2> G2; constexpr std::integral_constant<int, 3> G3;
-        if (!TOK(J)) { dma_group(djc, G0, don, dpar); dma_group(djc, G1, don, dpar); dma_group(djc, G2, don, dpar); dma_group(djc, G3, don, dpar); return; }
+        if (!TOK(J)) { if (xon) xg_request(xjc, xptr); dma_group(djc, G0, don, dpar); dma_group(djc, G1, don, dpar); dma_group(djc, G2, don, dpar); dma_group(djc, G3, don, dpar); return; }
         float rv[NG][4], xg[NG];
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
@@ -283,6 +283,10 @@ unsigned hchs = hchs_, cnts = cnts_, orows = orows_, xrows = xrows_;
         const float hprev = st_h[J * RNT + tid];
         float cprev = KIND == DSMI_RNN_LSTM ? st_c[J * RNT + tid] : 0.f;
         __builtin_amdgcn_sched_barrier(0);
+        // the x-projection of this half's NEXT cell item: from HBM, the slowest of what the end of the next slot waits for -- requested
+        // as early as xgl's present values have been read (the reads above went out first; LDS serves a wave in order)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (xon) xg_request(xjc, xptr);
         dma_group(djc, G0, don, dpar);
         dma_group(djc, G1, don, dpar);
         RSTAMP(11);
@@ -418,12 +422,13 @@ unsigned hchs = hchs_, cnts = cnts_, orows = orows_, xrows = xrows_;
                 // item q + 1 = (s, J + 1) reads h_(s-1) [needs s >= 1], or (s + 1, 0) reads h_s
                 const bool don = J + 1 < NT ? s >= 1 : more;
                 const unsigned dpar = J + 1 < NT ? parr : parw;
-                if (J >= 1) cell_item(JP, t, osoff, parw, JN, don, dpar);
-                else if (s >= 1) cell_item(JP, d == 0 ? t - 1 : t + 1, d == 0 ? osoff - ostride_by : osoff + ostride_by, parr, JN, don, dpar);
+                // (B's next cell item is q = (s, J): its x-projection is requested inside this cell)
+                if (J >= 1) cell_item(JP, t, osoff, parw, JN, don, dpar, jc, xstep, true);
+                else if (s >= 1) cell_item(JP, d == 0 ? t - 1 : t + 1, d == 0 ? osoff - ostride_by : osoff + ostride_by, parr, JN, don, dpar, jc, xstep, true);
                 else { constexpr std::integral_constant<int, 0> G0; constexpr std::integral_constant<int, 1> G1;
                        constexpr std::integral_constant<int, 2> G2; constexpr std::integral_constant<int, 3> G3;
+                       xg_request(jc, xstep);
                        dma_group(JN, G0, don, dpar); dma_group(JN, G1, don, dpar); dma_group(JN, G2, don, dpar); dma_group(JN, G3, don, dpar); }
-                xg_request(jc, xstep);          // B's next cell item: q = (s, J)
                 RSTAMP(13);
                 RT_MARK(2);
             }
@@ -432,8 +437,7 @@ unsigned hchs = hchs_, cnts = cnts_, orows = orows_, xrows = xrows_;
             // ---------------- odd slot 2q + 1: A finishes item q; B multiplies it and polls for item q + 2
             if (!(skipf & 32)) { if (hx == 0) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }
             if (hx == 0) {
-                cell_item(jc, t, osoff, parw, jc, false, 0u);
-                if (J + 1 < NT) xg_request(JN, xstep); else if (more) xg_request(JN, xnext);
+                cell_item(jc, t, osoff, parw, jc, false, 0u, JN, J + 1 < NT ? xstep : xnext, J + 1 < NT || more);
                 RSTAMP(13);
                 RT_MARK(2);
             } else {
@@ -460,7 +464,7 @@ unsigned hchs = hchs_, cnts = cnts_, orows = orows_, xrows = xrows_;
     if (hx == 1) {
         const int t = d == 0 ? p.T - 1 : 0;
         constexpr std::integral_constant<int, NT - 1> JL;
-        cell_item(JL, t, (unsigned)t * ostride_by, (unsigned)((p.T - 1) & 1) * hp_par, JL, false, 0u);
+        cell_item(JL, t, (unsigned)t * ostride_by, (unsigned)((p.T - 1) & 1) * hp_par, JL, false, 0u, JL, p.xp, false);
     }
     ring_barrier();
 #undef TOK

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Diagnostics: where the ring kernel (rnn_persist_ring.hip) spends its slots.  ring_stamps.py [B]"""
+"""Diagnostics: where the ring kernel (rnn_persist_ring.hip, two-slot form) spends its slots.  ring_stamps.py [B]
+Per wave, per item (two slots): M work (MFMAs + partial tiles), M-end waits (vmcnt(0) + B's poll), C work (cell + requests), the
+barrier behind each, B wave 0's poll spin; in a diagnostics build whose stamps live in LDS."""
 import os, sys
 import numpy as np
 os.environ["DSMI_STAMP_RING"] = "1"
@@ -14,17 +16,13 @@ buf = np.zeros((256, 8, 16), dtype=np.uint64)
 n = _native.lib().dsmi_debug_persist_stamps(m._h, 1, B, T, buf.ctypes.data_as(C.c_void_p), buf.size)
 assert n > 0, n
 raw = buf[:n].astype(np.float64)
-nte = max((B + 15) // 16, 4)
-items = T * nte
+items = T * 4
 names = ["M work", "M-end waits", "C work", "barrier after M", "barrier after C", "poll spin"]
-print("B %d: %d workgroups, %d items per half; us per item (median over workgroups); total per step = sum x %d tiles" % (B, n, items, nte))
+print("B %d: %d workgroups, %d items per half; us per item (median over workgroups)" % (B, n, items))
 for half in (0, 1):
     for wv in (0, 1, 3):
         c = raw[:, 4 * half + wv, :]
         us = c[:, :6] * 10.0 / 1000.0 / items
         tot = np.median(us[:, 0] + us[:, 1] + us[:, 2] + us[:, 3] + us[:, 4])
         print("half %s wave %d: " % ("AB"[half], wv) + " | ".join("%s %.3f" % (names[k], np.median(us[:, k])) for k in range(6)) +
-              " | sum %.3f -> %.2f us per step | M clock %.0f MHz" % (tot, tot * nte, np.median(c[:, 6] / np.maximum(c[:, 0], 1)) * 100.0))
-        cyc = c[:, 8:14] / items
-        print("      cycles per item: M head %.0f | MFMA loop %.0f | partials %.0f || DMA requests %.0f | reduce + cell %.0f | publish + xg %.0f" %
-              tuple(np.median(cyc[:, k]) for k in range(6)))
+              " | sum %.3f -> %.2f us per step" % (tot, tot * 4))

@@ -8,8 +8,7 @@
 set -u
 TAG=${1:-r02}
 export TMPDIR=/tmp
-CMD="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-side-paths --no-kernel-sampling"
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_trace -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-side-paths --no-kernel-sampling > gpurun_out/${TAG}_trace.log 2>&1
+CMD="python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-side-paths --no-kernel-sampling"
 for G in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES" "GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_MFMA"; do
     N=$(echo $G | cut -d' ' -f1)
     rocprofv3 --pmc $G --output-format csv -d gpurun_out/${TAG}_pmc_${N} -- $CMD > gpurun_out/${TAG}_pmc_${N}.log 2>&1 || echo "pass $N failed (see gpurun_out/${TAG}_pmc_${N}.log)"

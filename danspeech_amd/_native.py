@@ -366,7 +366,7 @@ class NativeFrontend:
     PCM_STEREO = 16
     WAV_WIDTH_DTYPE = {1: 3, 2: 0, 3: 4, 4: 5}       # sample width in bytes -> DSMI_PCM_{U8,I16,I24,I32}
 
-    def features(self, pcm_dev, n_samples, t_stride=None, wav_format=None):
+    def features(self, pcm_dev, n_samples, t_stride=None, wav_format=None, device=None):
         """pcm_dev: 1-D CUDA tensor (int16/float32/float64), clips back to back; or, with
         ``wav_format=(sample_width, channels)``, a uint8 tensor holding the raw frames of PCM WAV
         files back to back (``n_samples`` then counts frames; stereo is folded on the device).
@@ -386,7 +386,7 @@ class NativeFrontend:
             if int(n_samples.sum()) * width * channels != pcm_dev.numel():
                 raise ValueError("frame counts do not add up to the size of the byte buffer")
             dt = self.WAV_WIDTH_DTYPE[width] | (self.PCM_STEREO if channels == 2 else 0)
-        feat = torch.empty((B, 1, self.n_freq, t_stride), dtype=torch.float32, device=pcm_dev.device)
+        feat = torch.empty((B, 1, self.n_freq, t_stride), dtype=torch.float32, device=device if device is not None else pcm_dev.device)
         fr = np.empty(B, dtype=np.int32)
         rc = lib().dsmi_features(self._h, pcm_dev.data_ptr(), dt, _np_ptr(n_samples), B, feat.data_ptr(),
                                  int(t_stride), _np_ptr(fr), _stream(self.device))

@@ -4,6 +4,8 @@
 float32 torch tensor; the STFT runs in libdsmi.so (float64 DFT on the GPU, features.hip) and the
 tensor stays on the device (the engine's ``.to(device)`` is then a no-op).
 """
+import os
+
 import numpy as np
 
 
@@ -28,8 +30,8 @@ class StagedClips(object):
     the upload on the copy stream; ``parse_batch`` makes the current stream wait for it and runs the spectrograms.  Lets a
     pipeline start a batch's upload before it has a model handle free for it."""
 
-    def __init__(self, pcm, n_samples, itemsize, done):
-        self.pcm, self.n_samples, self.itemsize, self.done = pcm, n_samples, itemsize, done
+    def __init__(self, pcm, n_samples, itemsize, done, slot=None):
+        self.pcm, self.n_samples, self.itemsize, self.done, self.slot = pcm, n_samples, itemsize, done, slot
 
     def __len__(self):
         return len(self.n_samples)
@@ -114,7 +116,7 @@ class SpectrogramAudioParser(AudioParser):
         fills one while the copy engine still drains the other, and nothing waits for the GPU's compute stream."""
         import torch
         if getattr(self, "_slots", None) is None:
-            self._slots = [dict(buf=None, done=None), dict(buf=None, done=None)]
+            self._slots = [dict(buf=None, done=None, dev=None, used=None), dict(buf=None, done=None, dev=None, used=None)]
             self._turn = 0
             self._copy_stream = torch.cuda.Stream(device=self.device)
         slot = self._slots[self._turn]
@@ -154,11 +156,19 @@ class SpectrogramAudioParser(AudioParser):
         # the parser's own upload stream, or the one all parsers of the device share (share_copy_stream: set by a pipeline
         # that also keeps a decode stream busy -- see _shared_copy_stream)
         up = _shared_copy_stream(self.device) if getattr(self, "share_copy_stream", False) else self._copy_stream
+        nbytes = total * dtype.itemsize
         with torch.cuda.stream(up):
-            pcm = slot["buf"][:total * dtype.itemsize].to("cuda:%d" % self.device, non_blocking=True)
+            # the slot's own device buffer (not a fresh allocation per batch: tens of megabytes allocated on the copy stream and
+            # released on the compute stream go round the caching allocator's cross-stream bookkeeping every batch)
+            if slot["dev"] is None or slot["dev"].numel() < nbytes:
+                slot["dev"] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device="cuda:%d" % self.device)
+            if slot["used"] is not None:
+                up.wait_event(slot["used"])                  # the kernels that read this buffer two batches ago
+            pcm = slot["dev"][:nbytes]
+            pcm.copy_(slot["buf"][:nbytes], non_blocking=True)
             slot["done"] = torch.cuda.Event()
             slot["done"].record(up)
-        return StagedClips(pcm, n, dtype.itemsize, slot["done"])
+        return StagedClips(pcm, n, dtype.itemsize, slot["done"], slot)
 
     def parse_batch(self, recordings):
         """list of 1-D arrays (or ``StagedClips`` / ``DeviceClips``) -> (features [B,1,F,Tmax] CUDA float32, frames int32[B]);
@@ -168,9 +178,16 @@ class SpectrogramAudioParser(AudioParser):
             return self._frontend().features(recordings.pcm, recordings.n_samples)
         staged = recordings if isinstance(recordings, StagedClips) else self.stage(recordings)
         main = torch.cuda.current_stream(self.device)
-        main.wait_event(staged.done)
-        staged.pcm.record_stream(main)
-        return self._frontend().features(staged.pcm.view({2: torch.int16, 4: torch.float32, 8: torch.float64}[staged.itemsize]), staged.n_samples)
+        if staged.done is not None:
+            main.wait_event(staged.done)
+        out = self._frontend().features(staged.pcm.view({2: torch.int16, 4: torch.float32, 8: torch.float64}[staged.itemsize]), staged.n_samples,
+                                        device="cuda:%d" % self.device)
+        if staged.slot is not None:
+            staged.slot["used"] = torch.cuda.Event()
+            staged.slot["used"].record(main)                 # the staging slot's device buffer may be overwritten behind this point
+        else:
+            staged.pcm.record_stream(main)
+        return out
 
     def parse_wav_frames(self, raws, width, channels):
         """Raw PCM WAV frames (``read_wav_frames``; one common sample width / channel count) ->

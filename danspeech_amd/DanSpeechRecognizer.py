@@ -322,9 +322,33 @@ class DanSpeechRecognizer(object):
                 lo += len(b)
             return out
 
+        # The next forward is put together by a helper thread (reading the source, the copy into pinned memory, the upload's start)
+        # while this thread waits for the GPU, makes strings and runs the caller's loop body: on a busy host the staging of 80 MB
+        # is milliseconds during which a lane that has just finished would otherwise stand empty.  (One forward in flight without
+        # merging = the caller asked for strictly sequential reads: inline.)
+        helper = None
+        if lanes > 1 or merge_clips > 0:
+            from concurrent.futures import ThreadPoolExecutor
+            helper = ThreadPoolExecutor(max_workers=1)
+        device_index = self._device_index()
+
+        def fetch_ahead(parser):
+            if helper is None:
+                return fetch(parser)
+
+            def work():
+                torch.cuda.set_device(device_index)
+                torch.cuda.set_stream(streams[0])        # a source that launches GPU work does so on the caller's stream, as inline
+                return fetch(parser)
+            return helper.submit(work)
+
         try:
-            group = fetch(parsers[0])
-            while group is not None:
+            ahead = fetch_ahead(parsers[0])
+            while True:
+                group = ahead.result() if helper is not None else ahead
+                ahead = None
+                if group is None:
+                    break
                 parts, merged, staged = group
                 job = None
                 if len(merged):
@@ -340,7 +364,7 @@ class DanSpeechRecognizer(object):
                     count += 1
                 pending.append((parts, job))
                 job = None
-                group = fetch(parsers[turn])         # the next forward: staged now, before the waits below
+                ahead = fetch_ahead(parsers[turn])   # the next forward: staged now, beside the waits below
                 # (one more than `depth` may be pending for a moment: the oldest forward has been waited for above -- it ran on the
                 # lane that was just refilled -- and only its strings are still to be made, while every lane is busy again)
                 while len(pending) > depth:
@@ -356,6 +380,8 @@ class DanSpeechRecognizer(object):
                 for r in res:
                     yield r
         finally:
+            if helper is not None:
+                helper.shutdown(wait=True)       # (a staging in progress finishes: its pinned slot must not be refilled under it)
             # the caller stopped early, or a batch raised: whatever is still enqueued gives its forward and its beam-search
             # ticket back, otherwise the decoder handle stays "not collected" and every later call on this engine fails
             for left in [done[1] if done else None, job] + [pj[1] for pj in pending]:

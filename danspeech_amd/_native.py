@@ -87,6 +87,7 @@ _PROTOS = {
     "dsmi_decoder_set_lm": (C.c_int, [_vp, C.c_char_p, C.c_double, C.c_double]),
     "dsmi_beam": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _vp, _vp, _vp, _vp, _vp]),
     "dsmi_forward": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "dsmi_forward_ready": (C.c_int, [_vp]),
     "dsmi_forward_status": (C.c_int, [_vp]),
     "dsmi_recompute_count": (C.c_int, [_vp]),
     "dsmi_model_set_inflight": (C.c_int, [_vp, C.c_int]),
@@ -262,6 +263,13 @@ class NativeModel:
             return True
         self._check(rc)
         return False
+
+    def ready(self):
+        """Has the oldest uncollected forward finished on the device (``status()`` would not block)?  Never blocks."""
+        rc = lib().dsmi_forward_ready(self._h)
+        if rc < 0:
+            self._check(rc)
+        return rc == 1
 
     def recompute_count(self):
         return int(lib().dsmi_recompute_count(self._h))

@@ -786,6 +786,18 @@ extern "C" int dsmi_forward_status(dsmi_model* m) {
     return collect_oldest(m, true);
 }
 
+// See include/dsmi.h: has the handle's oldest uncollected forward finished?  Never blocks.
+extern "C" int dsmi_forward_ready(dsmi_model* m) {
+    if (!m) return DSMI_ERR_INVALID;
+    if (m->fwd_count == 0) return 1;
+    (void)hipSetDevice(m->device);
+    const hipError_t e = hipEventQuery(m->fwd[m->fwd_head].done);
+    if (e == hipSuccess) return 1;
+    if (e == hipErrorNotReady) return 0;
+    m->err = std::string("hipEventQuery: ") + hipGetErrorString(e);
+    return DSMI_ERR_HIP;
+}
+
 static int forward_enqueue(dsmi_model* m, const float* feat, int B, int T, float* probs, hipStream_t s) {
     int rc;
     const dsmi_model_desc& d = m->desc;

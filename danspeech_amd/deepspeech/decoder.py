@@ -112,12 +112,14 @@ class GreedyDecoder(Decoder):
         probs = self._on_gpu(probs)
         dec = self._dec(probs.device.index or 0, slot)
         sz = None if sizes is None else np.asarray(torch.as_tensor(sizes).cpu()).astype(np.int32)
+        if not hasattr(dec, "greedy_enqueue"):           # (a native handle without the split entry points: decode now)
+            return ("decoded", dec.greedy(probs, sz))
         dec.greedy_enqueue(probs, sz)
         return dec
 
     def decode_collect(self, ticket):
         import torch
-        res = ticket.greedy_collect()
+        res = ticket[1] if isinstance(ticket, tuple) else ticket.greedy_collect()
         strings = [[self._to_string(ids)] for ids, _ in res]
         offsets = [[torch.from_numpy(off.astype(np.int32))] for _, off in res]
         return strings, offsets

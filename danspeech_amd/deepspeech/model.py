@@ -155,6 +155,10 @@ class DeepSpeech(object):
         """Wait for the oldest ``enqueue`` and validate it (``dsmi_forward_status``)."""
         return self._native.status()
 
+    def ready(self):
+        """Would ``collect()`` return without waiting?"""
+        return self._native.ready()
+
     def set_inflight(self, batches):
         """Tell the kernels how many batches the caller keeps in flight on this device (``dsmi_model_set_inflight``)."""
         if self._native is not None:

@@ -184,6 +184,10 @@ int dsmi_forward(dsmi_model* m, const float* feat_dev, const int32_t* lens_host,
  * Uncollected forwards that finished well are forgotten by the next dsmi_forward; one that finished with a timeout
  * makes the next dsmi_forward fail with DSMI_ERR_TIMEOUT (its results were invalid and may have been consumed). */
 int dsmi_forward_status(dsmi_model* m);
+/* 1 when the handle's oldest uncollected dsmi_forward has finished on the device (dsmi_forward_status would not block), 0 when
+ * it is still running, < 0 on error; never blocks.  For a host that keeps several handles busy and refills whichever
+ * finishes first (no reference counterpart). */
+int dsmi_forward_ready(dsmi_model* m);
 /* Tells the handle how many batches the caller keeps in flight on this device (each on its own handle and stream).
  * 1 (default): kernels chosen for the latency of one batch (one 16-clip tile per workgroup, the whole device).  2: the
  * recurrent layers use the paired-tile variant (a workgroup carries both tiles of a 17..32-clip batch: 100 CUs for

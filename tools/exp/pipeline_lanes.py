@@ -21,7 +21,8 @@ for lanes, merge in combos:
     eng = rec.danspeech_recognizer
     host16 = [h.astype(np.int16) for h in host]
     host32 = [h.astype(np.float32) for h in host]
-    for kind, src in (("device", lambda: (clips for _ in range(steps))), ("host", lambda: (host for _ in range(steps)))):
+    order = (("host", lambda: (host for _ in range(steps))), ("device", lambda: (clips for _ in range(steps))), ("host", lambda: (host for _ in range(steps))))
+    for kind, src in order:
         for res in eng.transcribe_batches((src() if False else (clips if kind == "device" else {"host": host, "host16": host16, "host32": host32}[kind]) for _ in range(16)), lanes=lanes, merge_clips=merge):
             pass
         torch.cuda.synchronize()

@@ -269,6 +269,7 @@ class DanSpeechRecognizer(object):
         searching = hasattr(self.decoder, "decode_enqueue") and not getattr(self.decoder, "on_lane", False)
         for ps in parsers:
             ps.share_copy_stream = searching     # a search kernel on the decode stream: fewer streams
+            ps.upload_on_compute_stream = True    # no copy stream in the pipeline: see SpectrogramAudioParser.stage
         # Depth of the pipeline in forwards.  Greedy decoding is a short host-synchronous step.  A beam search is a kernel of its
         # own that starts when its forward ends: one more job in flight (the oldest forward's search) keeps every lane's forward
         # running while the host waits for that search.
@@ -310,7 +311,8 @@ class DanSpeechRecognizer(object):
                 ahead.record(streams[0])
                 return parts, (live[0] if len(live) == 1 else _UnmergedDeviceClips(live)), ahead
             merged = live[0] if len(live) == 1 else [clip for b in live for clip in b]
-            return parts, merged, (self._stage_batch(merged, parser) if hasattr(parser, "stage") else None)
+            staged = self._stage_batch(merged, parser) if hasattr(parser, "stage") else None
+            return parts, merged, staged
 
         def results_of(done):
             """A finished forward -> one result list per batch it was merged from."""

@@ -7,8 +7,8 @@ tools/run_configs.py time), against the CPU oracle on the same seeded inputs:
   config 4  cfgB (2 conv + 7 x BiGRU 1200) + 5-gram, beam 128, B = 64 ragged clips through
             Recognizer.recognize_batch(show_all=True): once on 1.5..3 s clips with the oracle on every clip, once at the
             configuration's own 4..10 s with the oracle on sampled clips
-  config 5  one GPU's share of the long-form job: cfgA, B = 128 x 30 s (T = 3001), 3-gram beam 64: the
-            software-pipelined multi-tile recurrent kernel; oracle on a sampled subset of the clips +
+  config 5  one GPU's share of the long-form job: cfgA, B = 128 x 30 s (T = 3001), 3-gram beam 64: the ring
+            recurrent kernel, the batch's eight 16-clip tiles as four windows of two side by side (a lone batch); oracle on a sampled subset of the clips +
             batch invariance on all of them
 
 The model oracle is oracle/torch_port.py (pinned to the reference's golden vectors by
@@ -242,8 +242,8 @@ def test_config4_full_length_10s_clips(native, tmp_path):
 
 
 def test_config5_share_cfgA_batch128_30s_pipelined_kernel(native, tmp_path):
-    """B = 128 x 30 s: eight 16-clip tiles per direction on 200 CUs -> two tile groups x 4 tiles per workgroup,
-    the software-pipelined kernel.  Oracle on 6 sampled clips (as their own batches: the reference's batch
+    """B = 128 x 30 s: eight 16-clip tiles per direction -> with one batch in flight the ring kernel's four windows of two tiles side
+    by side on 4 x 50 CUs (rnn_persist_ring.hip; rounds 1-3: the tile-walking, then the paired-tile kernel in windows).  Oracle on 6 sampled clips (as their own batches: the reference's batch
     invariance is <= 1.2e-8), batch invariance of the GPU path on all 128."""
     from oracle import torch_port as tp
     cfg = _cfg(800, 5)

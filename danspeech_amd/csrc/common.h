@@ -50,7 +50,7 @@ struct ConvLaunch {
     const float* x; float* y; const float* wp; const float* bias; const float* bn_a; const float* bn_b;
     const int32_t* out_lens_dev;
     int B, ci, co, fi, fo, ti, to, xs, ys, layer;  // layer index selects the compile-time geometry
-    uint16_t* y_sp = nullptr;   // optional: split channels-last output [B][fo][2][to][32] fp16 terms (hi, lo * 2^11) (32-channel layers)
+    uint16_t* y_sp = nullptr;   // optional: split channels-last output [B][fo][2][to][32] fp16 terms (hi, lo unscaled) (32-channel layers)
     EvPair ev;
 };
 void launch_conv(const ConvLaunch& p, hipStream_t s);

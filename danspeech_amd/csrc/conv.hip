@@ -62,7 +62,7 @@ struct ConvArgs {
     const float* x; float* y; const float* wp; const float* bias; const float* bn_a; const float* bn_b;
     const int32_t* out_lens;
     int B, fi, fo, ti, to, xs, ys;
-    uint16_t* y_sp;    // when set: write [b][f][plane 2][t][32] fp16 terms (hi, lo * 2^11) instead of y (feeds conv_split.hip)
+    uint16_t* y_sp;    // when set: write [b][f][plane 2][t][32] fp16 terms (hi, lo unscaled) instead of y (feeds conv_split.hip)
 };
 
 using f16x4c = __attribute__((ext_vector_type(4))) _Float16;
@@ -156,7 +156,9 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs p) {
 
     if (f >= p.fo) return;
     if (p.y_sp) {
-        // ---- epilogue for a split-fp16 consumer: 4 consecutive channels per store, x = hi + lo * 2^-11
+        // ---- epilogue for a split-fp16 consumer: 4 consecutive channels per store, x = hi + lo, the lo term UNSCALED as
+        // conv_split.hip and conv1_split.hip's epilogue have it since round 3 (not reached today: the fp32 first layer is tied to an
+        // fp32 second one by DSMI_DENSE_MODE; kept consistent so that routing it into a split layer cannot be silently 2x off)
 #pragma unroll
         for (int tt = 0; tt < NTT; ++tt) {
             const int t = t0 + tt * 32 + li;
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvArgs p) {
                     v = fminf(fmaxf(v, 0.f), 20.f);
                     v = t < olen ? v : 0.f;
                     const _Float16 a = (_Float16)v;
-                    h[q] = a; l[q] = (_Float16)((v - (float)a) * 2048.f);
+                    h[q] = a; l[q] = (_Float16)(v - (float)a);
                 }
                 _Float16* base = reinterpret_cast<_Float16*>(p.y_sp) + ((((size_t)b * p.fo + f) * 2) * (size_t)p.to + t) * 32 + 8 * g + 4 * hk;
                 *reinterpret_cast<f16x4c*>(base) = h;

@@ -73,14 +73,32 @@ static void timer_resolve(dsmi_model* m) {
 //    fits a quarter takes ONE slot (handle-affine: four batches in flight on four handles and streams run their recurrent
 //    layers side by side), one that fits half takes a PAIR of slots (two batches in flight), anything else all four.
 constexpr int kMaxLanes = 4;
-struct PersistGate { std::mutex mu; hipEvent_t ev[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr}; int lock_fd = -1; bool lock_tried = false; int next_lane = 0; };
+// The ring kernel's windows (rnn_persist_ring.hip: H / 32 workgroups per direction, 50 CUs for cfgA) have slots of their own: as many as
+// fit the device side by side, at most kRingSlots; a ring launch is ordered behind every launch of the other kernels and vice versa
+// (the two families never share the device: the other kernels' grids are sized for halves and quarters of it).
+constexpr int kRingSlots = 5;
+struct PersistGate { std::mutex mu; hipEvent_t ev[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr}; hipEvent_t ring_ev[kRingSlots] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+                     int lock_fd = -1; bool lock_tried = false; int next_lane = 0; };
 
 // slots a launch of `width` (1, 2 or kMaxLanes) takes for a handle whose home slot is `lane`: [first, first + width)
-static int gate_first(int lane, int width) { return width >= kMaxLanes ? 0 : (width == 2 ? 2 * (lane & 1) : (lane & (kMaxLanes - 1))); }
+static int gate_first(int lane, int width) { return width >= kMaxLanes ? 0 : (width == 2 ? 2 * (lane & 1) : (lane % kMaxLanes)); }
 // Under g->mu: make stream `s` wait for the slots this launch needs ...
 static void gate_wait(PersistGate* g, hipStream_t s, int lane, int width) {
     for (int i = gate_first(lane, width); i < gate_first(lane, width) + width && i < kMaxLanes; ++i)
         if (g->ev[i]) (void)hipStreamWaitEvent(s, g->ev[i], 0);
+    for (int i = 0; i < kRingSlots; ++i)
+        if (g->ring_ev[i]) (void)hipStreamWaitEvent(s, g->ring_ev[i], 0);
+}
+// The same for `n` windows of the ring kernel on ring slots [first, first + n).
+static void ring_gate_wait(PersistGate* g, hipStream_t s, int first, int n) {
+    for (int i = first; i < first + n && i < kRingSlots; ++i)
+        if (g->ring_ev[i]) (void)hipStreamWaitEvent(s, g->ring_ev[i], 0);
+    for (int i = 0; i < kMaxLanes; ++i)
+        if (g->ev[i]) (void)hipStreamWaitEvent(s, g->ev[i], 0);
+}
+static void ring_gate_record(PersistGate* g, hipStream_t s, int first, int n) {
+    for (int i = first; i < first + n && i < kRingSlots; ++i)
+        if (g->ring_ev[i]) (void)hipEventRecord(g->ring_ev[i], s);
 }
 // ... and publish the launch on them.
 static void gate_record(PersistGate* g, hipStream_t s, int lane, int width) {
@@ -96,6 +114,8 @@ static PersistGate* persist_gate(int device) {
     PersistGate* g = new PersistGate();
     for (int i = 0; i < kMaxLanes; ++i)
         if (hipEventCreateWithFlags(&g->ev[i], hipEventDisableTiming) != hipSuccess) g->ev[i] = nullptr;
+    for (int i = 0; i < kRingSlots; ++i)
+        if (hipEventCreateWithFlags(&g->ring_ev[i], hipEventDisableTiming) != hipSuccess) g->ring_ev[i] = nullptr;
     gates[device] = g;
     return g;
 }
@@ -187,7 +207,7 @@ extern "C" int dsmi_model_create(const dsmi_model_desc* d, int device, dsmi_mode
         {
             PersistGate* g = persist_gate(device);
             std::lock_guard<std::mutex> lk(g->mu);
-            m->lane = g->next_lane++ % kMaxLanes;
+            m->lane = g->next_lane++;
         }
         if (m->rnn_mode == 1 && !persist_process_lock(device)) {
             m->rnn_mode = 0;
@@ -563,12 +583,14 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
     // ONE gate slot).  With batches in flight a handle's layer is one window on its own slot -- the other slots and the rest of
     // the chip belong to the other batches; a lone batch of more than 32 clips spreads its tiles over as many windows side by
     // side as the device holds.  (A lone batch of up to 32 clips keeps the whole-device kernel: the shortest step.)
-    int ring_ntw = 0, ring_nwin = 0;
+    int ring_ntw = 0, ring_nwin = 0, ring_slots = 0;
     if (use16 && m->rnn_kernel != 1 && (m->inflight >= 2 || B > 32 || m->rnn_kernel == 2)) {
-        const int cap = rnn_persist_ring_tiles(m->geom16, B, m->n_cus / kMaxLanes);
+        const int rcus = rnn_persist_ring_cus(m->geom16);
+        ring_slots = rcus > 0 ? std::min(kRingSlots, m->n_cus / rcus) : 0;        // windows the device holds side by side
+        const int cap = ring_slots >= 2 ? rnn_persist_ring_tiles(m->geom16, B, rcus) : 0;
         if (cap > 0) {
             const int ntiles = ceil_div(B, 16);
-            const int slots = m->inflight >= 2 ? 1 : kMaxLanes;
+            const int slots = m->inflight >= 2 ? 1 : std::min(ring_slots, kMaxLanes);
             ring_ntw = std::min(std::max(ceil_div(ntiles, slots), 1), cap);
             if (m->inflight < 2) ring_ntw = std::max(ring_ntw, std::min(ntiles, 2));
             ring_nwin = std::min(ceil_div(ntiles, ring_ntw), slots);
@@ -609,10 +631,10 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
                               part * 4.0 * Dd * (GH * m->desc.rnn_hidden_size + (double)To * B * (GH + 2.0 * m->desc.rnn_hidden_size)));
             PersistGate* gate = persist_gate(m->device);
             std::lock_guard<std::mutex> lk(gate->mu);
-            const int width = nw == 1 ? 1 : (nw == 2 ? 2 : kMaxLanes);
-            gate_wait(gate, s, m->lane, width);
+            const int first = nw == 1 ? m->lane % ring_slots : 0;      // a handle's own slot; several windows: from slot 0
+            ring_gate_wait(gate, s, first, nw);
             ok = launch_rnn_persist_ring(pl, s);
-            gate_record(gate, s, m->lane, width);
+            ring_gate_record(gate, s, first, nw);
         }
         if (ring_ntw && ok) return;
         for (int p0 = 0; !ring_ntw && p0 < (duo ? total_pairs : 1) && ok; p0 += window) {

@@ -16,7 +16,7 @@ host = [syn.make_clip(i, N) for i in range(B)]
 pcm = torch.from_numpy(np.stack(host)).cuda()
 clips = DeviceClips(pcm.view(-1), np.full(B, N, dtype=np.int64))
 want = None
-combos = [(4, 64)] if not os.environ.get("DSMI_RNN_KERNEL") else [(2, 32), (2, 64), (4, 32)]
+combos = [(4, 64), (5, 64)] if not os.environ.get("DSMI_RNN_KERNEL") else [(2, 32), (2, 64), (4, 32)]
 for lanes, merge in combos:
     eng = rec.danspeech_recognizer
     host16 = [h.astype(np.int16) for h in host]

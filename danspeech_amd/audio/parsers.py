@@ -4,10 +4,7 @@
 float32 torch tensor; the STFT runs in libdsmi.so (float64 DFT on the GPU, features.hip) and the
 tensor stays on the device (the engine's ``.to(device)`` is then a no-op).
 """
-import os
-
 import numpy as np
-
 
 
 _COPY_STREAMS = {}

@@ -13,20 +13,24 @@
 //     (virtual workgroups 2w and 2w + 1) instead of two copies of one group: no weight is held twice, a chain has half as many
 //     producers (H / 32), and the 50 KB of a tile's state are brought in ONCE per CU and step -- by LDS-DMA into the ring --
 //     for both halves (the paired-tile kernel ingests them once per 16 units).  A 64-clip layer of cfgA takes 50 CUs.
-//   * Fixed schedule, one workgroup barrier per slot; item q = (step s, tile j) = s * NT + j:
+//   * Fixed schedule, one workgroup barrier per slot; item q = (step s, tile j) = 4 s + j, unrolled over the four tiles:
 //
-//        slot 2q        A: MFMAs of item q  (B operands from ring slot q & 1)         B: cell of item q - 1, DMA requests of item q + 1
-//        slot 2q + 1    A: cell of item q                                             B: MFMAs of item q, poll for item q + 2,
-//                                                                                        signal item q - 1
+//        slot 2q        A: MFMAs of item q  (B operands from ring slot q & 1)         B: signal item q - 2; cell of item q - 1 with the
+//                          partial tiles -> LDS; wait for its own requests                DMA requests of item q + 1 in four groups between
+//                                                                                         its parts; x-projection request for item q
+//        slot 2q + 1    A: cell of item q; x-projection request for item q + 1        B: poll request for item q + 2 (wave 4); MFMAs of item q;
+//                                                                                         wait for its own requests; poll answer (spin if not yet)
 //
 //     so every slot has one half on the matrix pipe and the other on the vector / memory side.  A half issues vector-memory
-//     operations only in its cell slots (publish stores, x-projection loads, B's DMA requests) and waits for all of them at
+//     operations only in its cell slots (publish stores, x-projection requests, B's DMA requests) and waits for all of them at
 //     the end of its next MFMA slot: that one wait is the store drain in front of the signal, the landing of the DMA before
 //     the barrier that releases the readers, and the arrival of the next cell's x-projection.
-//   * The DMA requests are inline assembly: the compiler orders every LDS read behind an LDS-DMA it knows of (vmcnt(0)),
-//     which would put the landing latency in front of the cell's reduce-buffer reads.
-//   * Publish: a wave's new state values go through 256 bytes of LDS into 16-byte sc1 stores, one whole 128-byte line per
-//     plane and wave instruction (2-byte sc1 stores are one fabric write each).
+//   * The DMA and x-projection requests are inline assembly: the compiler orders every LDS read behind an LDS-DMA it knows of
+//     (vmcnt(0)), which would put the landing latency in front of the cell's reduce-buffer reads.
+//   * Publish: the eight lanes of a clip hand their (hi | lo << 16) words to the clip's first lane by DPP row shifts; that lane
+//     stores 16 bytes of each plane with sc1 -- one whole 128-byte line per plane and wave instruction (2-byte sc1 stores are one
+//     fabric write each).  Stores carry no branch: a lane with nothing to store has an offset beyond the buffer's range.
+//   Measured forms and what bounds the kernel: DESIGN.md 4 "The ring kernel", profiles/r04_ring_experiments.txt.
 #include "common.h"
 #include "rnn_cell.h"
 #include <algorithm>
@@ -99,10 +103,9 @@ __global__ __launch_bounds__(RNT, 2) void rnn_persist_ring_kernel(RingArgs p) {
     float* red_all = reinterpret_cast<float*>(rlds + 2 * sbytes);                 // [2 halves][4 waves][NG][16 units][RRP]
     float* st_h = red_all + 2 * 4 * NG * 16 * RRP;                               // [NT][512] own previous state per (tile, thread)
     float* st_c = st_h + NT * RNT;                                                // LSTM only: [NT][512]
-    unsigned short* stg = reinterpret_cast<unsigned short*>(st_c + (KIND == DSMI_RNN_LSTM ? NT * RNT : 0));   // [8 waves][128]
-    float* xgl = reinterpret_cast<float*>(stg + 8 * 128);                         // [2 halves][NG][256] x-projection of the half's next cell item
+    float* xgl = st_c + (KIND == DSMI_RNN_LSTM ? NT * RNT : 0);                    // [2 halves][NG][256] x-projection of the half's next cell item
     int* st_len = reinterpret_cast<int*>(xgl + 2 * NG * 256);                     // [NT][16]
-    int* sync = st_len + NT * 16;                                                 // [0] dead flag, [8] drained-waves counter
+    int* sync = st_len + NT * 16;                                                 // [0] dead flag (a hand-off wait timed out: stop waiting)
     // diagnostics build: the accumulated stamps live in LDS (sixteen 8-byte words per wave) -- in registers they cost the kernel 32
     // of the 256 it is built around, and a stamped build that spills measures the spills
     unsigned long long* tacc = reinterpret_cast<unsigned long long*>(sync + 32) + (STAMP ? (threadIdx.x >> 6) * 16 : 0);
@@ -479,7 +482,7 @@ unsigned hchs = hchs_, cnts = cnts_, orows = orows_, xrows = xrows_;
 size_t ring_lds_bytes(int kind, int nkb) {
     const int NG = kind == DSMI_RNN_GRU ? 3 : (kind == DSMI_RNN_LSTM ? 4 : 1);
     return (size_t)2 * nkb * 2048 + (size_t)2 * 4 * NG * 16 * RRP * 4 + (size_t)RMINT * RNT * 4 * (kind == DSMI_RNN_LSTM ? 2 : 1) +
-           8 * 128 * 2 + (size_t)2 * NG * 256 * 4 + RMINT * 16 * 4 + 32 * 4 + 8 * 16 * 8;
+           (size_t)2 * NG * 256 * 4 + RMINT * 16 * 4 + 32 * 4 + 8 * 16 * 8;
 }
 
 template <int KIND>

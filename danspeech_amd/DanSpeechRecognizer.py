@@ -296,7 +296,8 @@ class DanSpeechRecognizer(object):
                 nxt = next_batch()
                 if nxt is end:
                     break
-                if isinstance(nxt, DeviceClips) != on_device or total + len(nxt) > merge_clips:
+                if isinstance(nxt, DeviceClips) != on_device or total + len(nxt) > merge_clips or \
+                        (on_device and nxt.pcm.dtype != first.pcm.dtype):          # (one sample type per device-resident forward)
                     held[0], held[1] = nxt, True
                     break
                 parts.append(nxt)

@@ -82,6 +82,12 @@ def test_device_resident_clips_equal_host_arrays():
         dc = DeviceClips(pcm, n)
         assert rec.recognize_batch(dc) == want
         assert list(rec.recognize_batches([dc, dc.part(1, 4), dc])) == [want, want[1:4], want]
+    # consecutive batches are merged into one forward: of one sample type only, host and device-resident batches apart, empty ones kept
+    d64 = DeviceClips(torch.from_numpy(np.concatenate(clips)).cuda(), n)
+    d16 = DeviceClips(torch.from_numpy(np.concatenate(clips).astype(np.int16)).cuda(), n)
+    mixed = [d64, d16, clips, [], d16.part(0, 2), d16.part(2, 5), clips[:1], d64]
+    assert list(rec.recognize_batches(mixed)) == [want, want, want, [], want[:2], want[2:], want[:1], want]
+    assert list(rec.danspeech_recognizer.transcribe_batches(mixed, lanes=1, merge_clips=0)) == [want, want, want, [], want[:2], want[2:], want[:1], want]
     with pytest.raises(ValueError):
         DeviceClips(pcm, n[::-1].copy())
     with pytest.raises(ValueError):

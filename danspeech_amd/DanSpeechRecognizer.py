@@ -247,11 +247,21 @@ class DanSpeechRecognizer(object):
         streams = [torch.cuda.current_stream(self._device_index())] + [self._side_stream("lane %d" % k) for k in range(1, len(handles))]
         return handles, parsers, streams
 
+    def _lanes_that_pay(self, most, clips):
+        """Forwards in flight when the caller did not say.  Several forwards side by side pay where the recurrent kernel of
+        each holds a fifth of the chip (the ring form: GRU / RNN up to 896 units, LSTM up to 512, one window of up to 64
+        clips) and the dense kernels of the others fill the rest.  A forward of more clips, or a model whose recurrent kernel
+        takes the whole device, fills the chip with two in flight; more only contend (measured: profiles/r04_run_configs.txt,
+        configs 4 and 5: two in flight 8 % / 6 % faster than four)."""
+        hidden, kind = getattr(self.model, "rnn_hidden_size", 0), getattr(self.model, "rnn_type", "gru")
+        ring = hidden % 16 == 0 and hidden <= (512 if kind == "lstm" else 896)
+        return most if ring and clips <= 64 else min(most, 2)
+
     def transcribe_batches(self, batches, show_all=False, lanes=None, merge_clips=None):
         """Generator over ``transcribe_batch(b)`` for every ``b`` of ``batches``, software-pipelined: consecutive batches are
         merged into forwards of up to ``merge_clips`` clips (per-clip results do not depend on the batch they run in), and up to
-        ``lanes`` forwards are in flight, each on a model handle, stream and workspaces of its own -- the latency-bound
-        recurrent layers of several forwards run side by side on disjoint compute units while the dense kernels of the others
+        ``lanes`` forwards are in flight (default: ``pipeline_lanes``, or two where more do not pay: ``_lanes_that_pay``), each
+        on a model handle, stream and workspaces of its own -- the latency-bound recurrent layers of several forwards run side by side on disjoint compute units while the dense kernels of the others
         fill the rest of the chip; the decoder of a finished forward runs on a side stream.  Results come out in order, one
         list per batch.  ``batches`` is read AHEAD of the results: up to ``merge_clips`` clips for the forward being put
         together, plus one forward more (host clips are copied to pinned memory and uploaded before the loop waits for the
@@ -259,21 +269,25 @@ class DanSpeechRecognizer(object):
         merge_clips=0``."""
         import torch
         import collections
-        lanes = self.pipeline_lanes if lanes is None else max(1, int(lanes))
+        auto_lanes = lanes is None
+        lanes = self.pipeline_lanes if auto_lanes else max(1, int(lanes))
         merge_clips = self.pipeline_merge_clips if merge_clips is None else int(merge_clips)
-        handles, parsers, streams = self._lanes(lanes)
-        lanes = len(handles)
-        for h in handles:
-            if hasattr(h, "set_inflight"):
-                h.set_inflight(max(2, lanes) if lanes > 1 else 1)
         searching = hasattr(self.decoder, "decode_enqueue") and not getattr(self.decoder, "on_lane", False)
-        for ps in parsers:
-            ps.share_copy_stream = searching     # a search kernel on the decode stream: fewer streams
-            ps.upload_on_compute_stream = True    # no copy stream in the pipeline: see SpectrogramAudioParser.stage
+        # (the lanes are set up once the first forward has been put together: how many pay depends on its size)
+        handles, parsers, streams = self._lanes(1)
+
+        def set_up(count):
+            hs, ps, ss = self._lanes(count)
+            for h in hs:
+                if hasattr(h, "set_inflight"):
+                    h.set_inflight(max(2, len(hs)) if len(hs) > 1 else 1)
+            for p in ps:
+                p.share_copy_stream = searching      # a search kernel on the decode stream: fewer streams
+                p.upload_on_compute_stream = True    # no copy stream in the pipeline: see SpectrogramAudioParser.stage
+            return hs, ps, ss
         # Depth of the pipeline in forwards.  Greedy decoding is a short host-synchronous step.  A beam search is a kernel of its
         # own that starts when its forward ends: one more job in flight (the oldest forward's search) keeps every lane's forward
         # running while the host waits for that search.
-        depth = lanes + 1 if searching else lanes
         pending, turn, count, job, done = collections.deque(), 0, 0, None, None
         end = object()
         source = iter(batches)
@@ -346,12 +360,15 @@ class DanSpeechRecognizer(object):
             return helper.submit(work)
 
         try:
+            set_up(1)
             ahead = fetch_ahead(parsers[0])
-            while True:
-                group = ahead.result() if helper is not None else ahead
-                ahead = None
-                if group is None:
-                    break
+            group = ahead.result() if helper is not None else ahead
+            if auto_lanes and group is not None:
+                lanes = self._lanes_that_pay(lanes, sum(len(b) for b in group[0]))
+            handles, parsers, streams = set_up(lanes)
+            lanes = len(handles)
+            depth = lanes + 1 if searching else lanes
+            while group is not None:
                 parts, merged, staged = group
                 job = None
                 if len(merged):
@@ -376,6 +393,7 @@ class DanSpeechRecognizer(object):
                     done = None
                     for r in res:
                         yield r
+                group = ahead.result() if helper is not None else ahead
             while pending:
                 done = pending.popleft()
                 res = results_of(done)

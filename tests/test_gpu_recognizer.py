@@ -94,6 +94,30 @@ def test_device_resident_clips_equal_host_arrays():
         DeviceClips(pcm[:-1], n)
 
 
+def test_forwards_in_flight_follow_the_first_forward():
+    """Nobody named a lane count: four forwards in flight where a forward is one ring window (up to 64 clips of a model the ring
+    kernel takes), two where it is more clips than that or the model's recurrent kernel takes the whole device; results equal
+    either way, and a count that was named is taken as it is."""
+    from danspeech_amd import Recognizer
+    model, sd, cfg = _model("small", 64, 3, seed=12)
+    clips = [syn.make_clip(i, n) for i, n in enumerate([9000, 8000, 8000, 7000, 6000])]
+    rec = Recognizer(model=model)
+    eng = rec.danspeech_recognizer
+    want = rec.recognize_batch(clips)
+    assert eng._lanes_that_pay(4, 64) == 4 and eng._lanes_that_pay(4, 65) == 2 and eng._lanes_that_pay(1, 65) == 1
+    big = clips * 14                                             # 70 clips: one forward of more than a window
+    assert list(rec.recognize_batches([big, clips, big])) == [want * 14, want, want * 14]
+    assert len(eng._replicas) == 1
+    assert list(rec.recognize_batches([clips] * 6)) == [want] * 6
+    assert len(eng._replicas) == 3
+    wide, _, _ = _model("wide", 912, 1, seed=13)                 # 912 units: no ring form
+    rec2 = Recognizer(model=wide)
+    one = rec2.recognize_batch(clips)
+    assert list(rec2.recognize_batches([clips] * 5)) == [one] * 5 and len(rec2.danspeech_recognizer._replicas) == 1
+    assert list(rec2.danspeech_recognizer.transcribe_batches([clips] * 5, lanes=3)) == [one] * 5
+    assert len(rec2.danspeech_recognizer._replicas) == 2
+
+
 def test_device_clips_batches_wait_for_their_producer():
     """Device-resident clips are produced by asynchronous work on the caller's stream (an RCCL scatter, a widening copy): every
     second batch of the pipeline runs on a side stream, which must wait for that producer.  Here the producer is a slow chain

@@ -360,6 +360,8 @@ __global__ __launch_bounds__(QNT) void rnn_persist16_pipe_kernel(P16Args p) {
     }
     unsigned* pend = nullptr;
     bool pend_drop = false;
+    const int shard = lane & (kPersist16Shards - 1);
+    const unsigned need = (unsigned)((p.nwg + kPersist16Shards - 1 - shard) / kPersist16Shards);
 
     for (int i = 0; i < NI; ++i) {
         const int s = i / nz, z = i - s * nz;
@@ -368,6 +370,15 @@ __global__ __launch_bounds__(QNT) void rnn_persist16_pipe_kernel(P16Args p) {
         const int chain = d * p.ntiles + tile;
         unsigned* cnt = p.cnt + (size_t)chain * p.T * kPersist16CntWords;
         float* red = red0 + (i & 1) * RED;
+        // ---- the poll of instance i + 1 goes out in front of the MFMAs of instance i (its producers signalled an iteration or
+        // more ago: the answer is there when the MFMAs are done); every wave polls for itself, so that no barrier stands between
+        // the answer and the wave's own state loads
+        const int s1 = (i + 1) / nz, z1 = (i + 1) - s1 * nz;
+        const bool next_state = i + 1 < NI && s1 > 0;
+        const int chain1 = d * p.ntiles + tile_of(z1);
+        const unsigned* cp = p.cnt + (size_t)chain1 * p.T * kPersist16CntWords + (size_t)(next_state ? s1 - 1 : 0) * kPersist16CntWords + shard * 64;
+        unsigned got = need;
+        if (next_state && lane < kPersist16Shards) got = __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // ---- B(i): multiply (the state of instance i was requested during the previous iteration)
         f32x4 acc[NG], acl[NG];
 #pragma unroll
@@ -390,29 +401,20 @@ __global__ __launch_bounds__(QNT) void rnn_persist16_pipe_kernel(P16Args p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 red[((v * 4 + g) * 16 + 4 * lg + r) * QRP + ln] = acc[g][r] + acl[g][r] * kLoInv;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // instance i-1's state stores are acknowledged
-        __syncthreads();
-        if (tid == 0 && pend && !pend_drop) __hip_atomic_fetch_add(pend, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // ---- A(i+1): wait for the producers of the next instance and request its state and x-projection
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // instance i-1's state stores are acknowledged (and the poll has answered)
+        // ---- A(i+1): the producers of the next instance have signalled -> request its state and x-projection, this wave's part
         if (i + 1 < NI) {
-            const int s1 = (i + 1) / nz, z1 = (i + 1) - s1 * nz;
-            if (s1 > 0) {
-                const int chain1 = d * p.ntiles + tile_of(z1);
-                const unsigned* c1 = p.cnt + (size_t)chain1 * p.T * kPersist16CntWords + (size_t)(s1 - 1) * kPersist16CntWords;
-                if (v == 0 && !s_dead) {
+            if (next_state) {
+                if (!*(volatile int*)&s_dead) {
                     unsigned spins = 0;
-                    const unsigned* cp = c1 + (lane & (kPersist16Shards - 1)) * 64;
-                    const unsigned need = (unsigned)((p.nwg + kPersist16Shards - 1 - (lane & (kPersist16Shards - 1))) / kPersist16Shards);
-                    while (true) {
-                        const unsigned got = lane < kPersist16Shards ? __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need;
-                        if (__builtin_amdgcn_ballot_w64(got < need) == 0) break;
+                    while (__builtin_amdgcn_ballot_w64(got < need) != 0) {
                         __builtin_amdgcn_s_sleep(1);
                         ++spins;
                         if ((spins & 1023u) == 0 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { s_dead = 1; break; }
                         if (spins > p.spin_limit) { atomicExch(p.err, 1u); s_dead = 1; break; }
+                        got = lane < kPersist16Shards ? __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need;
                     }
                 }
-                __syncthreads();
                 const unsigned hbase = (unsigned)(((s1 - 1) & 1) * hp_par) + (unsigned)((size_t)chain1 * p.nkb * 2048) + (unsigned)lane * 16u;
 #pragma unroll
                 for (int k = 0; k < NKW; ++k) {
@@ -428,6 +430,8 @@ __global__ __launch_bounds__(QNT) void rnn_persist16_pipe_kernel(P16Args p) {
                 for (int g = 0; g < NG; ++g) xn[g] = xr[g * QU];
             }
         }
+        __syncthreads();                                      // partial tiles written, everybody's stores of instance i-1 acknowledged
+        if (tid == 0 && pend && !pend_drop) __hip_atomic_fetch_add(pend, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // ---- C(i): reduce + cell + publish
         float hn = 0.f;
         const bool eact = active(z);

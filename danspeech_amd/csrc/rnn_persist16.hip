@@ -21,6 +21,8 @@
 #include "common.h"
 #include "rnn_cell.h"
 #include <cstring>
+#include <cstdlib>
+#include <type_traits>
 
 namespace dsmi {
 
@@ -35,11 +37,23 @@ constexpr int QRP = 20;                // row pitch (words) of the reduce buffer
 constexpr int QMAXZ = 8;               // batch tiles one workgroup can walk
 constexpr size_t Q_LDS = 82 * 1024;    // > half of the CU's LDS: one workgroup per CU
 constexpr size_t Q_LDS_HALF = 78 * 1024;   // four-wave variant: at most two workgroups per CU (its 256 registers per wave allow no third)
-constexpr size_t Q_LDS_PIPE = 112 * 1024;   // pipelined variant: two reduce buffers
 
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 constexpr float kLoScale = 2048.f, kLoInv = 1.f / 2048.f;
+
+// A word of LDS as it is now (a volatile access through a generic pointer is a flat load: vmcnt(0) with it).
+__device__ inline int lds_peek(const int* q) {
+    int r;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"((unsigned)(size_t)q) : "memory");
+    return r;
+}
+
+// Tile-walking kernel: a feeder wave keeps two sets of state operands in registers, a cell wave one set and the cell, so with
+// three gates and five k-blocks per wave the last eight of the thirty W_hh fragments live in LDS (1 KiB each per wave, read per
+// instance): with all thirty in registers the compiler spills one and reloads it in every instance -- a vector-memory load whose
+// in-order return waits for every state request before it.
+constexpr int pipe_lds_frags(int ng, int nkw) { return ng == 3 && nkw == 5 ? 8 : 0; }
 
 struct P16Args {
     const uint16_t* whh[2];    // pack_whh16 per direction
@@ -52,6 +66,8 @@ struct P16Args {
     unsigned spin_limit;       // polls of one wait before the workgroup raises *err and stops waiting
     int drop_wg, drop_step;    // test hook (DSMI_DEBUG_DROP_SIGNAL): workgroup drop_wg of chain 0 never signals step drop_step (-1: off)
     unsigned long long* dbg;   // diagnostics build only: per-wave accumulated phase times [workgroup][wave][8]
+    int skip;                  // timing experiments (DSMI_DEBUG_PIPE_SKIP, tile-walking kernel only; results are garbage):
+                               // 1 no state loads, 2 no MFMAs, 4 polls taken as answered, 8 no stores, 16 no cell
 };
 
 #define QSTAMP(k)                                                                         \
@@ -287,16 +303,20 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void rnn_persist16_kern
 // Every wave issues the same two 2-byte state stores after its state loads (the non-cell waves' go out of the buffer's
 // bounds and are dropped by the hardware, but still count), so that "wait until at most two memory operations are
 // outstanding" means "my state loads have landed" for every wave.
-template <int KIND, int NKW>
+template <int KIND, int NKW, bool SKIPS = false>
 __global__ __launch_bounds__(QNT) void rnn_persist16_pipe_kernel(P16Args p) {
+    const int skip = SKIPS ? p.skip : 0;                             // (timing experiments: a build of its own)
     constexpr int NG = KIND == DSMI_RNN_GRU ? 3 : (KIND == DSMI_RNN_LSTM ? 4 : 1);
-    constexpr int RED = QNW * 4 * 16 * QRP;                          // words per reduce buffer
+    constexpr int NF = NKW * NG * 2, NFL = pipe_lds_frags(NG, NKW);  // W_hh fragments (k-block, gate, plane) of a wave; the last NFL in LDS
+    constexpr int AHEAD = (NG == 4 && NKW >= 4) ? 1 : 2;             // (an LSTM of four k-blocks per wave has no registers for a second set)
+    constexpr int RED = QNW * NG * 16 * QRP;                         // words per reduce buffer
     extern __shared__ __attribute__((aligned(16))) float qlds[];
-    float* red0 = qlds;                                              // [2][QNW][4][16 units][QRP]
+    float* red0 = qlds;                                              // [2][QNW][NG][16 units][QRP]
     int& s_dead = *reinterpret_cast<int*>(red0 + 2 * RED);
     float* st_h = red0 + 2 * RED + 32;                               // [QMAXZ][256] carried state of the tiles
     float* st_c = st_h + QMAXZ * 256;
     int* st_len = reinterpret_cast<int*>(st_c + QMAXZ * 256);
+    u32x4* wlds = reinterpret_cast<u32x4*>(st_len + QMAXZ * 256);    // [QNW][NFL][64 lanes] 16-byte fragments
     const int tid = threadIdx.x, lane = tid & 63;
     const int v = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ln = lane & 15, lg = lane >> 4;
@@ -308,7 +328,8 @@ __global__ __launch_bounds__(QNT) void rnn_persist16_pipe_kernel(P16Args p) {
     if (tid == 0) s_dead = 0;
 
     const int kb0 = (v * p.nkb) / QNW, kb1 = ((v + 1) * p.nkb) / QNW;
-    f16x8 wv[NKW][NG][2];
+    f16x8 wv[NKW][NG][2];                                            // (the entries that live in LDS are never touched)
+    u32x4* wl = wlds + (size_t)v * (NFL > 0 ? NFL : 1) * 64 + lane;  // written and read by this same lane only
     {
         const u32x4* wp = reinterpret_cast<const u32x4*>(p.whh[d]) + ((size_t)w * p.nkb) * (NG * 2 * 64) + lane;
 #pragma unroll
@@ -317,12 +338,16 @@ __global__ __launch_bounds__(QNT) void rnn_persist16_pipe_kernel(P16Args p) {
 #pragma unroll
             for (int g = 0; g < NG; ++g)
 #pragma unroll
-                for (int pl = 0; pl < 2; ++pl) wv[i][g][pl] = __builtin_bit_cast(f16x8, wp[(((size_t)kb * NG + g) * 2 + pl) * 64]);
+                for (int pl = 0; pl < 2; ++pl) {
+                    const u32x4 frag = wp[(((size_t)kb * NG + g) * 2 + pl) * 64];
+                    const int f = (i * NG + g) * 2 + pl;
+                    if (f < NF - NFL) wv[i][g][pl] = __builtin_bit_cast(f16x8, frag);
+                    else wl[(f - (NF - NFL)) * 64] = frag;
+                }
         }
     }
     const size_t hp_par = (size_t)p.D * p.ntiles * p.nkb * 2048;
     const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.hpack, 0, (int)(2 * hp_par), 0x00020000);
-    const unsigned oob = (unsigned)(2 * hp_par) + 64u;               // out of bounds: dropped, but counted by vmcnt
 
     const int cuh = tid >> 7, ce = tid & 7, cj = (tid >> 3) & 15;
     const int cu = 8 * cuh + ce;
@@ -347,90 +372,145 @@ __global__ __launch_bounds__(QNT) void rnn_persist16_pipe_kernel(P16Args p) {
     };
     auto active = [&](int z) { return cunit_ok && cj < min(QB, p.B - tile_of(z) * QB); };
 
-    f16x8 hv[NKW][2];
+    f16x8 hva[NKW][2], hvb[NKW][2];       // the state operands of even / odd instances: requested TWO instances ahead
 #pragma unroll
-    for (int i = 0; i < NKW; ++i) { hv[i][0] = f16x8{0, 0, 0, 0, 0, 0, 0, 0}; hv[i][1] = hv[i][0]; }
-    float xg[NG], xn[NG];
+    for (int i = 0; i < NKW; ++i) { hva[i][0] = f16x8{0, 0, 0, 0, 0, 0, 0, 0}; hva[i][1] = hva[i][0]; hvb[i][0] = hva[i][0]; hvb[i][1] = hva[i][0]; }
+    float xa[NG], xb[NG];                  // x-projection of even / odd instances (AHEAD == 1: of this / the next instance)
 #pragma unroll
-    for (int g = 0; g < NG; ++g) { xg[g] = 0.f; xn[g] = 0.f; }
+    for (int g = 0; g < NG; ++g) { xa[g] = 0.f; xb[g] = 0.f; }
     if (active(0)) {
         const float* xr = xp_of(0, 0);
 #pragma unroll
-        for (int g = 0; g < NG; ++g) xg[g] = xr[g * QU];
+        for (int g = 0; g < NG; ++g) xa[g] = xr[g * QU];
     }
     unsigned* pend = nullptr;
     bool pend_drop = false;
     const int shard = lane & (kPersist16Shards - 1);
     const unsigned need = (unsigned)((p.nwg + kPersist16Shards - 1 - shard) / kPersist16Shards);
 
-    for (int i = 0; i < NI; ++i) {
-        const int s = i / nz, z = i - s * nz;
+    // Roles (AHEAD == 2).  Waves 0-3 are the CELL waves: after the barrier of instance i they reduce, run the cell and publish,
+    // while waves 4-7, the FEEDERS, are already in instance i + 1.  A feeder polls for instance i + 2 behind its MFMAs of
+    // instance i (it would wait for the cell waves at the barrier anyway) and requests its own part of that state; it does not
+    // pass the barrier before the poll has answered, so a cell wave knows without polling that the state of instance i + 1 is
+    // there when it starts instance i, and requests its part behind its MFMAs of instance i (it has the cell of instance i to
+    // cover the landing; a feeder, which would go straight on, has two sets of operands and a whole instance).
+    auto state_base = [&](const int si, const int zi) {
+        const int ch = d * p.ntiles + tile_of(zi);
+        return (unsigned)(((si - 1) & 1) * hp_par) + (unsigned)((size_t)ch * p.nkb * 2048) + (unsigned)lane * 16u;
+    };
+    auto load_state_k = [&](const unsigned hbase, const int k, f16x8 (&dst)[NKW][2]) __attribute__((always_inline)) {
+        if (skip & 1) return;
+        const int kb = min(kb0 + k, max(kb1 - 1, kb0));
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+            dst[k][pl] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(hrs, hbase + (unsigned)(kb * 2 + pl) * 1024u, 0, 16));
+    };
+    auto load_state = [&](const int si, const int zi, f16x8 (&dst)[NKW][2]) __attribute__((always_inline)) {
+        const unsigned hbase = state_base(si, zi);
+#pragma unroll
+        for (int k = 0; k < NKW; ++k) load_state_k(hbase, k, dst);
+    };
+
+    // (the two roles run SEPARATE copies of the loop: in one copy the compiler orders a cell wave's request into a register set
+    // behind the feeder branch's request into the same set -- a wait for all but the newest operation, i.e. for the cell's
+    // stores, at the top of every instance)
+    // STEADY instances (every instance from the second step on, in the two-role form) issue the SAME memory operations on every
+    // path -- requests beyond the last instance are clamped to it and never used -- because the compiler's wait for an
+    // operand counts the operations issued since on the path that issued fewest: one path without requests turns every wait
+    // for an old operand into a wait for everything.
+    int sz[2] = {0, 0};
+    auto instance = [&](auto role_tag, auto steady_tag, const int i, f16x8 (&hv)[NKW][2], float (&xg)[NG], float (&xn)[NG])
+                        __attribute__((always_inline)) {
+        constexpr bool STEADY = decltype(steady_tag)::value;
+        constexpr int ROLE = decltype(role_tag)::value;              // 0: every wave does everything (AHEAD == 1); 1: cell wave; 2: feeder
+        constexpr bool feeder = ROLE == 2;
+        const int s = sz[0], z = sz[1];                              // i = s * nz + z (carried: no division per instance)
         const int t = d == 0 ? s : p.T - 1 - s;
         const int tile = tile_of(z);
         const int chain = d * p.ntiles + tile;
         unsigned* cnt = p.cnt + (size_t)chain * p.T * kPersist16CntWords;
         float* red = red0 + (i & 1) * RED;
-        // ---- the poll of instance i + 1 goes out in front of the MFMAs of instance i (its producers signalled an iteration or
-        // more ago: the answer is there when the MFMAs are done); every wave polls for itself, so that no barrier stands between
-        // the answer and the wave's own state loads
-        const int s1 = (i + 1) / nz, z1 = (i + 1) - s1 * nz;
-        const bool next_state = i + 1 < NI && s1 > 0;
-        const int chain1 = d * p.ntiles + tile_of(z1);
-        const unsigned* cp = p.cnt + (size_t)chain1 * p.T * kPersist16CntWords + (size_t)(next_state ? s1 - 1 : 0) * kPersist16CntWords + shard * 64;
+        const int z1 = z + 1 < nz ? z + 1 : 0, s1 = z + 1 < nz ? s : s + 1;
+        const int z2 = AHEAD == 1 ? z1 : (z1 + 1 < nz ? z1 + 1 : 0), s2 = AHEAD == 1 ? s1 : (z1 + 1 < nz ? s1 : s1 + 1);   // whom a polling wave polls for
+        const bool next_state = i + AHEAD < NI && (STEADY || s2 > 0);
+        const int chain2 = d * p.ntiles + tile_of(z2);
+        const unsigned* cp = p.cnt + (size_t)chain2 * p.T * kPersist16CntWords + (size_t)(next_state ? s2 - 1 : 0) * kPersist16CntWords + shard * 64;
         unsigned got = need;
-        if (next_state && lane < kPersist16Shards) got = __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // a cell wave has ONE set of state operands (the cell's registers take the place of the second): it requests the k-blocks
+        // of instance i + 1 one by one behind the MFMAs that read those of instance i
+        const bool cell_ahead = ROLE == 1 && (STEADY || (i + 1 < NI && s1 > 0));
+        const bool last = i + 1 >= NI;                               // (requests beyond the last instance are clamped to it)
+        const int sx = STEADY && last ? s : s1, zx = STEADY && last ? z : z1;
+        const unsigned hbase1 = cell_ahead ? state_base(sx, zx) : 0u;
+        if (ROLE != 0) {
+            if (ROLE == 1 && (STEADY || i + 1 < NI)) {
+                asm volatile("" ::: "memory");                 // (behind the cell's stores: the wait below counts on the order)
+                const float* xr = p.xp + ((size_t)(d == 0 ? sx : p.T - 1 - sx) * p.B + min(tile_of(zx) * QB + cj, p.B - 1)) * p.Np + xcol + cu;
+#pragma unroll
+                for (int g = 0; g < NG; ++g) xn[g] = xr[g * QU];
+            }
+        } else {
+            // one set of state operands: the poll of instance i + 1 goes out in front of the MFMAs of instance i (its producers
+            // signalled an iteration or more ago); every wave polls for itself: no barrier between the answer and its loads
+            if (next_state && lane < kPersist16Shards) got = __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         // ---- B(i): multiply (the state of instance i was requested during the previous iteration)
         f32x4 acc[NG], acl[NG];
 #pragma unroll
         for (int g = 0; g < NG; ++g) { acc[g] = f32x4{0.f, 0.f, 0.f, 0.f}; acl[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        if (s > 0) {
+        {
 #pragma unroll
             for (int k = 0; k < NKW; ++k) {
-                if (kb0 + k < kb1) {
+                if ((STEADY || s > 0) && !(skip & 2) && kb0 + k < kb1) {
+                    f16x8 wf[NG][2];
 #pragma unroll
-                    for (int g = 0; g < NG; ++g) acl[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[k][g][1], hv[k][0], acl[g], 0, 0, 0);
+                    for (int g = 0; g < NG; ++g)
 #pragma unroll
-                    for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[k][g][0], hv[k][0], acc[g], 0, 0, 0);
+                        for (int pl = 0; pl < 2; ++pl)
+                            wf[g][pl] = (k * NG + g) * 2 + pl < NF - NFL ? wv[k][g][pl]
+                                                                         : __builtin_bit_cast(f16x8, wl[max((k * NG + g) * 2 + pl - (NF - NFL), 0) * 64]);
 #pragma unroll
-                    for (int g = 0; g < NG; ++g) acl[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[k][g][0], hv[k][1], acl[g], 0, 0, 0);
+                    for (int g = 0; g < NG; ++g) acl[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[g][1], hv[k][0], acl[g], 0, 0, 0);
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[g][0], hv[k][0], acc[g], 0, 0, 0);
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) acl[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[g][0], hv[k][1], acl[g], 0, 0, 0);
                 }
+                if (cell_ahead) load_state_k(hbase1, k, hv);
             }
         }
 #pragma unroll
         for (int g = 0; g < NG; ++g)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                red[((v * 4 + g) * 16 + 4 * lg + r) * QRP + ln] = acc[g][r] + acl[g][r] * kLoInv;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // instance i-1's state stores are acknowledged (and the poll has answered)
-        // ---- A(i+1): the producers of the next instance have signalled -> request its state and x-projection, this wave's part
-        if (i + 1 < NI) {
-            if (next_state) {
-                if (!*(volatile int*)&s_dead) {
-                    unsigned spins = 0;
-                    while (__builtin_amdgcn_ballot_w64(got < need) != 0) {
-                        __builtin_amdgcn_s_sleep(1);
-                        ++spins;
-                        if ((spins & 1023u) == 0 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { s_dead = 1; break; }
-                        if (spins > p.spin_limit) { atomicExch(p.err, 1u); s_dead = 1; break; }
-                        got = lane < kPersist16Shards ? __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need;
-                    }
-                }
-                const unsigned hbase = (unsigned)(((s1 - 1) & 1) * hp_par) + (unsigned)((size_t)chain1 * p.nkb * 2048) + (unsigned)lane * 16u;
-#pragma unroll
-                for (int k = 0; k < NKW; ++k) {
-                    const int kb = min(kb0 + k, max(kb1 - 1, kb0));
-#pragma unroll
-                    for (int pl = 0; pl < 2; ++pl)
-                        hv[k][pl] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(hrs, hbase + (unsigned)(kb * 2 + pl) * 1024u, 0, 16));
+                red[((v * NG + g) * 16 + 4 * lg + r) * QRP + ln] = acc[g][r] + acl[g][r] * kLoInv;
+        // ---- the cell waves' stores of instance i-1 are acknowledged (in-order return: everything older than the requests of
+        // this instance's top has come back)
+        if (cell_ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NKW + NG) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ---- the producers of instance i + AHEAD have signalled -> request its state, this wave's part
+        if ((next_state || STEADY) && ROLE != 1) {
+            if (next_state && !lds_peek(&s_dead) && !(skip & 4)) {
+                unsigned spins = 0;
+                if (ROLE == 2) got = lane < kPersist16Shards ? __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need;
+                while (__builtin_amdgcn_ballot_w64(got < need) != 0) {
+                    __builtin_amdgcn_s_sleep(1);
+                    ++spins;
+                    if ((spins & 1023u) == 0 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { s_dead = 1; break; }
+                    if (spins > p.spin_limit) { atomicExch(p.err, 1u); s_dead = 1; break; }
+                    got = lane < kPersist16Shards ? __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need;
                 }
             }
-            if (active(z1)) {
-                const float* xr = xp_of(s1, z1);
+            const bool beyond = STEADY && i + AHEAD >= NI;
+            load_state(beyond ? s : s2, beyond ? z : z2, hv);
+        }
+        if (ROLE == 0 && i + 1 < NI && active(z1)) {
+            const float* xr = xp_of(s1, z1);
 #pragma unroll
-                for (int g = 0; g < NG; ++g) xn[g] = xr[g * QU];
-            }
+            for (int g = 0; g < NG; ++g) xn[g] = xr[g * QU];
         }
         __syncthreads();                                      // partial tiles written, everybody's stores of instance i-1 acknowledged
+        if (feeder) return;
         if (tid == 0 && pend && !pend_drop) __hip_atomic_fetch_add(pend, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // ---- C(i): reduce + cell + publish
         float hn = 0.f;
@@ -440,36 +520,55 @@ __global__ __launch_bounds__(QNT) void rnn_persist16_pipe_kernel(P16Args p) {
             const int mylen = st_len[z * 256 + tid];
             const float hprev_own = st_h[z * 256 + tid];
             float cprev_own = st_c[z * 256 + tid];
-            if (eact) {
+            if (eact && !(skip & 16)) {
                 float hg[NG];
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
                     float sum = 0.f;
 #pragma unroll
-                    for (int k = 0; k < QNW; ++k) sum += red[((k * 4 + g) * 16 + cu) * QRP + cj];
+                    for (int k = 0; k < QNW; ++k) sum += red[((k * NG + g) * 16 + cu) * QRP + cj];
                     hg[g] = sum + bh[g];
                 }
-                hn = rnn_cell<KIND>(xg, hg, hprev_own, cprev_own, t < mylen);
+                hn = rnn_cell<KIND, true>(xg, hg, hprev_own, cprev_own, t < mylen);
                 st_h[z * 256 + tid] = hn;
                 if (KIND == DSMI_RNN_LSTM) st_c[z * 256 + tid] = cprev_own;
-                p.out[d][((size_t)t * p.B + eb) * p.Hs + cunit] = hn;
+                if (!(skip & 8)) p.out[d][((size_t)t * p.B + eb) * p.Hs + cunit] = hn;
             } else if (cj < min(QB, p.B - tile * QB) && cunit < p.Hs) {
                 p.out[d][((size_t)t * p.B + eb) * p.Hs + cunit] = 0.f;
             }
         }
-        {
+        if (tid < 256 && !(skip & 8)) {
             const _Float16 h1 = (_Float16)hn;
             const _Float16 h2 = (_Float16)((hn - (float)h1) * kLoScale);
-            const unsigned off = tid < 256 ? (unsigned)((s & 1) * hp_par) + (unsigned)((size_t)chain * p.nkb * 2048) + (unsigned)(w >> 1) * 2048u +
-                                                 (unsigned)(2 * (w & 1) + cuh) * 256u + (unsigned)cj * 16u + (unsigned)ce * 2u
-                                           : oob;
+            const unsigned off = (unsigned)((s & 1) * hp_par) + (unsigned)((size_t)chain * p.nkb * 2048) + (unsigned)(w >> 1) * 2048u +
+                                 (unsigned)(2 * (w & 1) + cuh) * 256u + (unsigned)cj * 16u + (unsigned)ce * 2u;
             __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, h1), hrs, off, 0, 16);
-            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, h2), hrs, tid < 256 ? off + 1024u : oob, 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, h2), hrs, off + 1024u, 0, 16);
         }
         pend = &cnt[(size_t)s * kPersist16CntWords + (w & (kPersist16Shards - 1)) * 64];
         pend_drop = chain == 0 && w == p.drop_wg && s == p.drop_step;
+        if (ROLE == 0)
 #pragma unroll
-        for (int g = 0; g < NG; ++g) xg[g] = xn[g];
+            for (int g = 0; g < NG; ++g) xg[g] = xn[g];
+    };
+    auto step = [&]() { sz[0] = sz[1] + 1 < nz ? sz[0] : sz[0] + 1; sz[1] = sz[1] + 1 < nz ? sz[1] + 1 : 0; };
+    if (AHEAD == 2) {
+        auto walk = [&](auto role_tag) __attribute__((always_inline)) {
+            const std::false_type first{};
+            const std::true_type steady{};
+            const int P = min((nz + 1) & ~1, NI);        // the instances of step 0 (and one more where nz is odd) in the general form
+            int i = 0;
+            constexpr bool one_set = decltype(role_tag)::value == 1;
+            auto& hodd = *(one_set ? &hva : &hvb);
+            for (; i + 1 < P; i += 2) { instance(role_tag, first, i, hva, xa, xb); step(); instance(role_tag, first, i + 1, hodd, xb, xa); step(); }
+            if (i < P) { instance(role_tag, first, i, hva, xa, xb); return; }      // (one step of an odd number of tiles)
+            for (; i + 1 < NI; i += 2) { instance(role_tag, steady, i, hva, xa, xb); step(); instance(role_tag, steady, i + 1, hodd, xb, xa); step(); }
+            if (i < NI) instance(role_tag, steady, i, hva, xa, xb);
+        };
+        if (v >= 4) walk(std::integral_constant<int, 2>{});
+        else walk(std::integral_constant<int, 1>{});
+    } else {
+        for (int i = 0; i < NI; ++i) { instance(std::integral_constant<int, 0>{}, std::false_type{}, i, hva, xa, xb); step(); }
     }
 }
 
@@ -508,13 +607,21 @@ bool launch16(const P16Args& a, hipStream_t s, const EvPair& ev, int waves) {
     }
     if (ceil_div(a.ntiles, a.pgroups) > 2) {      // three or more tiles per workgroup: the software-pipelined kernel (with two
                                                    // tiles the next instance's producers were signalled a moment ago: nothing to overlap)
+        constexpr int NGK = KIND == DSMI_RNN_GRU ? 3 : (KIND == DSMI_RNN_LSTM ? 4 : 1);
+        auto lds_pipe = [](int nkw) {            // two reduce buffers, the dead flag, carried state of up to QMAXZ tiles, W_hh fragments
+            return (size_t)2 * QNW * NGK * 16 * QRP * 4 + 128 + (size_t)3 * QMAXZ * 256 * 4 + (size_t)QNW * pipe_lds_frags(NGK, nkw) * 1024;
+        };
 #define LAUNCH_QP(N)                                                                                                 \
     do {                                                                                                             \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rnn_persist16_pipe_kernel<KIND, N>),                  \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)Q_LDS_PIPE);                       \
-        DSMI_LAUNCH((rnn_persist16_pipe_kernel<KIND, N>), grid, block, Q_LDS_PIPE, s, ev, a);                         \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pipe(N));                      \
+        DSMI_LAUNCH((rnn_persist16_pipe_kernel<KIND, N>), grid, block, lds_pipe(N), s, ev, a);                        \
     } while (0)
-        if (nkw <= 2) LAUNCH_QP(2);
+        if (a.skip && KIND == DSMI_RNN_GRU && nkw == 5) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rnn_persist16_pipe_kernel<DSMI_RNN_GRU, 5, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pipe(5));
+            DSMI_LAUNCH((rnn_persist16_pipe_kernel<DSMI_RNN_GRU, 5, true>), grid, block, lds_pipe(5), s, ev, a);
+        } else if (nkw <= 2) LAUNCH_QP(2);
         else if (nkw <= 4) LAUNCH_QP(4);
         else if (nkw <= 5 && KIND != DSMI_RNN_LSTM) LAUNCH_QP(5);
         else return false;
@@ -602,6 +709,8 @@ bool launch_rnn_persist16(const RnnPersist16Launch& p, hipStream_t s) {
     a.B = p.B; a.T = p.T; a.H = p.g.H; a.Hs = p.g.Kp; a.Np = p.g.Np; a.nwg = p.g.nwg; a.nkb = ceil_div(p.g.H, 32);
     a.ntiles = ceil_div(p.B, QB); a.pgroups = p.pgroups; a.D = p.g.D; a.dbg = p.dbg;
     a.spin_limit = p.spin_limit; a.drop_wg = p.drop_wg; a.drop_step = p.drop_step;
+    static const int skip_env = [] { const char* e = std::getenv("DSMI_DEBUG_PIPE_SKIP"); return e ? std::atoi(e) : 0; }();
+    a.skip = skip_env;
     switch (p.g.kind) {
         case DSMI_RNN_GRU: return launch16<DSMI_RNN_GRU>(a, s, p.ev, p.waves);
         case DSMI_RNN_LSTM: return launch16<DSMI_RNN_LSTM>(a, s, p.ev, p.waves);

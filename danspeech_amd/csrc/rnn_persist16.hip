@@ -431,11 +431,15 @@ __global__ __launch_bounds__(QNT) void rnn_persist16_pipe_kernel(P16Args p) {
         unsigned* cnt = p.cnt + (size_t)chain * p.T * kPersist16CntWords;
         float* red = red0 + (i & 1) * RED;
         const int z1 = z + 1 < nz ? z + 1 : 0, s1 = z + 1 < nz ? s : s + 1;
-        const int z2 = AHEAD == 1 ? z1 : (z1 + 1 < nz ? z1 + 1 : 0), s2 = AHEAD == 1 ? s1 : (z1 + 1 < nz ? s1 : s1 + 1);   // whom a polling wave polls for
-        const bool next_state = i + AHEAD < NI && (STEADY || s2 > 0);
+        constexpr int AH = ROLE == 0 ? 1 : 2;                        // how many instances ahead a polling wave polls and requests
+        const int z2 = AH == 1 ? z1 : (z1 + 1 < nz ? z1 + 1 : 0), s2 = AH == 1 ? s1 : (z1 + 1 < nz ? s1 : s1 + 1);
+        const bool next_state = i + AH < NI && (STEADY || s2 > 0);
         const int chain2 = d * p.ntiles + tile_of(z2);
         const unsigned* cp = p.cnt + (size_t)chain2 * p.T * kPersist16CntWords + (size_t)(next_state ? s2 - 1 : 0) * kPersist16CntWords + shard * 64;
         unsigned got = need;
+        // (a workgroup that walks TWO tiles -- the short group of a launch whose other groups walk three -- polls for what its own
+        // previous instance wrote: only behind the barrier and the signal of this instance)
+        const bool late_poll = ROLE == 0 && nz < 3;
         // a cell wave has ONE set of state operands (the cell's registers take the place of the second): it requests the k-blocks
         // of instance i + 1 one by one behind the MFMAs that read those of instance i
         const bool cell_ahead = ROLE == 1 && (STEADY || (i + 1 < NI && s1 > 0));
@@ -452,7 +456,7 @@ __global__ __launch_bounds__(QNT) void rnn_persist16_pipe_kernel(P16Args p) {
         } else {
             // one set of state operands: the poll of instance i + 1 goes out in front of the MFMAs of instance i (its producers
             // signalled an iteration or more ago); every wave polls for itself: no barrier between the answer and its loads
-            if (next_state && lane < kPersist16Shards) got = __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (next_state && !late_poll && lane < kPersist16Shards) got = __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         // ---- B(i): multiply (the state of instance i was requested during the previous iteration)
         f32x4 acc[NG], acl[NG];
@@ -489,10 +493,10 @@ __global__ __launch_bounds__(QNT) void rnn_persist16_pipe_kernel(P16Args p) {
         if (cell_ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NKW + NG) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // ---- the producers of instance i + AHEAD have signalled -> request its state, this wave's part
-        if ((next_state || STEADY) && ROLE != 1) {
+        auto poll_and_request = [&](const bool fresh) __attribute__((always_inline)) {
             if (next_state && !lds_peek(&s_dead) && !(skip & 4)) {
                 unsigned spins = 0;
-                if (ROLE == 2) got = lane < kPersist16Shards ? __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need;
+                if (fresh) got = lane < kPersist16Shards ? __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need;
                 while (__builtin_amdgcn_ballot_w64(got < need) != 0) {
                     __builtin_amdgcn_s_sleep(1);
                     ++spins;
@@ -501,9 +505,10 @@ __global__ __launch_bounds__(QNT) void rnn_persist16_pipe_kernel(P16Args p) {
                     got = lane < kPersist16Shards ? __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need;
                 }
             }
-            const bool beyond = STEADY && i + AHEAD >= NI;
+            const bool beyond = STEADY && i + AH >= NI;
             load_state(beyond ? s : s2, beyond ? z : z2, hv);
-        }
+        };
+        if ((next_state || STEADY) && ROLE != 1 && !late_poll) poll_and_request(ROLE == 2);
         if (ROLE == 0 && i + 1 < NI && active(z1)) {
             const float* xr = xp_of(s1, z1);
 #pragma unroll
@@ -512,6 +517,7 @@ __global__ __launch_bounds__(QNT) void rnn_persist16_pipe_kernel(P16Args p) {
         __syncthreads();                                      // partial tiles written, everybody's stores of instance i-1 acknowledged
         if (feeder) return;
         if (tid == 0 && pend && !pend_drop) __hip_atomic_fetch_add(pend, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ROLE == 0 && late_poll && next_state) poll_and_request(true);
         // ---- C(i): reduce + cell + publish
         float hn = 0.f;
         const bool eact = active(z);
@@ -552,7 +558,10 @@ __global__ __launch_bounds__(QNT) void rnn_persist16_pipe_kernel(P16Args p) {
             for (int g = 0; g < NG; ++g) xg[g] = xn[g];
     };
     auto step = [&]() { sz[0] = sz[1] + 1 < nz ? sz[0] : sz[0] + 1; sz[1] = sz[1] + 1 < nz ? sz[1] + 1 : 0; };
-    if (AHEAD == 2) {
+    // Two instances ahead is the state instance i + 2 - nz wrote, signalled behind the barrier of instance i + 3 - nz: a feeder
+    // polls for it IN FRONT of the barrier of instance i, so the two-role form needs four tiles or more (with three it waits
+    // for its own workgroup's signal).  Workgroups of one launch may walk different numbers of tiles.
+    if (AHEAD == 2 && nz >= 4) {
         auto walk = [&](auto role_tag) __attribute__((always_inline)) {
             const std::false_type first{};
             const std::true_type steady{};

@@ -239,6 +239,7 @@ def test_wide_and_odd_layers_vs_oracle(native, monkeypatch, H, why, gen1_launche
         assert ks["rnn_step"]["launches"] == int(ol[0]) and "rnn_layer_persistent" not in ks
     else:
         assert ks["rnn_layer_persistent"]["launches"] == (gen1_launches or 1) and "rnn_step" not in ks
+        assert m.recompute_count() == 0
     m.close()
 
 
@@ -347,23 +348,25 @@ def test_full_width_variants_vs_oracle(native, kind, H, L, cl, bidir):
     m.close()
 
 
-@pytest.mark.parametrize("kind,B,why", [("gru", 20, "two tiles per workgroup: deferred signalling"),
-                                        ("gru", 40, "three tiles per workgroup: software-pipelined kernel"),
-                                        ("gru", 64, "four tiles: the state requested a whole iteration ahead"),
-                                        ("gru", 104, "seven tiles, an odd number of tile instances"),
-                                        ("rnn", 72, "five tiles, one gate"),
-                                        ("lstm", 56, "four tiles, LSTM cell state carried per tile")])
-def test_second_generation_walks_several_tiles_vs_oracle(native, kind, B, why):
-    """H = 1024: 64 workgroups x 2 directions leave room for ONE tile group on 256 CUs, so every workgroup of
+@pytest.mark.parametrize("kind,B,why,H,T", [
+    ("gru", 20, "two tiles per workgroup: deferred signalling", 1024, 44),
+    ("gru", 40, "three tiles per workgroup: the tile-walking kernel, cell waves and feeder waves", 1024, 44),
+    ("gru", 64, "four tiles: a feeder requests the state two instances ahead", 1024, 44),
+    ("gru", 104, "seven tiles, an odd number of tile instances", 1024, 46),
+    ("rnn", 72, "five tiles, one gate", 1024, 44),
+    ("lstm", 56, "four tiles, LSTM cell state carried per tile (one operand set: every wave polls)", 1024, 44),
+    ("gru", 56, "config 4's width: five k-blocks per wave, eight W_hh fragments per wave in LDS, ragged last tile", 1200, 44),
+    ("gru", 40, "config 4's width, three tiles and an odd number of steps: the last instance stands alone", 1200, 46)])
+def test_second_generation_walks_several_tiles_vs_oracle(native, kind, B, why, H, T):
+    """H = 1024 / 1200: the workgroups of both directions leave room for ONE tile group on 256 CUs, so every workgroup of
     rnn_persist16.hip walks ceil(B / 16) batch tiles per step (ragged lengths, ragged last tile)."""
     from oracle import model as om
-    H = 1024
     sd = syn.make_state_dict(2, kind, H, 1, seed=44, fc_gain=4.0)
     cfg = _cfg(2, kind, H, 1)
     rng = np.random.default_rng(45)
-    lens = np.sort(rng.integers(7, 44, size=B))[::-1].astype(np.int32).copy()
-    lens[0] = 44
-    x = syn.make_features(B, 44, seed=46)
+    lens = np.sort(rng.integers(7, T, size=B))[::-1].astype(np.int32).copy()
+    lens[0] = T
+    x = syn.make_features(B, T, seed=46)
     for b, L in enumerate(lens):
         x[b, :, :, L:] = 0
     m = native.NativeModel(cfg, sd)
@@ -373,4 +376,5 @@ def test_second_generation_walks_several_tiles_vs_oracle(native, kind, B, why):
     assert np.array_equal(ol, ol_ref)
     np.testing.assert_allclose(p.cpu().numpy(), ref, rtol=0, atol=1e-4)
     assert m.kernel_stats()["rnn_layer_persistent"]["launches"] == 1
+    assert m.recompute_count() == 0         # (a hand-off that times out is recomputed: right results would hide a wrong schedule)
     m.close()

@@ -251,8 +251,8 @@ class DanSpeechRecognizer(object):
         """Forwards in flight when the caller did not say.  Several forwards side by side pay where the recurrent kernel of
         each holds a fifth of the chip (the ring form: GRU / RNN up to 896 units, LSTM up to 512, one window of up to 64
         clips) and the dense kernels of the others fill the rest.  A forward of more clips, or a model whose recurrent kernel
-        takes the whole device, fills the chip with two in flight; more only contend (measured: profiles/r04_run_configs.txt,
-        configs 4 and 5: two in flight 8 % / 6 % faster than four)."""
+        takes the whole device, fills the chip with two in flight: four measure the same within the noise
+        (profiles/r04_run_configs.txt, configs 4 and 5) and cost two more sets of workspaces."""
         hidden, kind = getattr(self.model, "rnn_hidden_size", 0), getattr(self.model, "rnn_type", "gru")
         ring = hidden % 16 == 0 and hidden <= (512 if kind == "lstm" else 896)
         return most if ring and clips <= 64 else min(most, 2)

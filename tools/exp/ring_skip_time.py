@@ -4,7 +4,7 @@ import os, sys, subprocess
 here = os.path.dirname(os.path.abspath(__file__))
 only = [int(a) for a in sys.argv[1:]]
 for skip, what in ((0, "complete"), (1, "no state DMA"), (2, "no MFMAs"), (3, "no DMA, no MFMAs"), (4, "no polls"), (5, "no DMA, no polls"),
-                   (8, "no x-projection requests"), (16, "no output / publish stores"), (31, "barriers + cell only"), (32, "no wave priorities"), (63, "barriers + cell only, no priorities")):
+                   (8, "no x-projection requests"), (16, "no output / publish stores"), (25, "no DMA, no x-projection requests, no stores: no memory request but the polls"), (29, "no memory request at all"), (27, "no memory request but the polls, no MFMAs"), (31, "barriers + cell only"), (32, "no wave priorities"), (63, "barriers + cell only, no priorities")):
     if only and skip not in only:
         continue
     env = dict(os.environ, DSMI_DEBUG_RING_SKIP=str(skip))

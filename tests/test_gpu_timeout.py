@@ -251,6 +251,36 @@ def test_paired_tile_kernel_equals_oracle_and_the_single_tile_kernels(native, ki
         np.testing.assert_allclose(outs[0][b, :ol_ref[b]], outs[1][b, :ol_ref[b]], rtol=0, atol=5e-5)
 
 
+@pytest.mark.parametrize("H,B,drop", [(1200, 64, "1:5:9"), (1024, 104, "0:60:17")])
+def test_tile_walking_kernel_timeout_is_recomputed(native, H, B, drop):
+    """The tile-walking kernel (more 16-clip tiles than fit side by side: rnn_persist16_pipe_kernel) with its wave roles: a
+    feeder wave's poll never answers (one workgroup does not signal one step of tile 0), the feeders give up, the cell waves
+    run on behind the barrier, the forward reports it and its results are the recomputed ones.  H = 1200: four tiles per
+    workgroup, 150 workgroups; H = 1024 with 104 clips: two groups of workgroups walking four and three tiles (the second
+    in the one-role form) in one launch, sharing the error word."""
+    from oracle import torch_port as tp
+    cfg = _cfg(H, 2)
+    sd = syn.make_state_dict(2, "gru", H, 2, seed=65, **syn.TALKATIVE)
+    x, lens = _batch(B=B, T=81, seed=66)
+    ref, _ = tp.forward(sd, cfg, x, lens)
+    with _env(DSMI_DEBUG_DROP_SIGNAL=drop, DSMI_DEBUG_SPIN_LIMIT="3000"):
+        m = native.NativeModel(cfg, sd)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        p, ol = m.forward(_dev(x), lens, check=False)
+        assert m.status() is True
+    assert m.recompute_count() == 1 and any("timed out" in str(x.message) for x in w)
+    pn = p.cpu().numpy()
+    for b in range(B):
+        np.testing.assert_allclose(pn[b, :ol[b]], ref[b, :ol[b]], rtol=0, atol=1e-4)
+    # the same handle, nothing dropped any more?  (the hook is read when the handle is made: a fresh one runs clean)
+    m.close()
+    m = native.NativeModel(cfg, sd)
+    p, ol = m.forward(_dev(x), lens)
+    assert m.recompute_count() == 0
+    m.close()
+
+
 @pytest.mark.parametrize("H,B,drop", [(64, 24, "1:2:9"), (800, 96, "1:3:11")])
 def test_paired_tile_kernel_timeout_is_recomputed(native, H, B, drop):
     """The paired-tile kernel's own hand-off timeout (DSMI_RNN_KERNEL=duo, two batches in flight): one pair on the handle's lane,

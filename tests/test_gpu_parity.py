@@ -356,7 +356,8 @@ def test_full_width_variants_vs_oracle(native, kind, H, L, cl, bidir):
     ("rnn", 72, "five tiles, one gate", 1024, 44),
     ("lstm", 56, "four tiles, LSTM cell state carried per tile (one operand set: every wave polls)", 1024, 44),
     ("gru", 56, "config 4's width: five k-blocks per wave, eight W_hh fragments per wave in LDS, ragged last tile", 1200, 44),
-    ("gru", 40, "config 4's width, three tiles and an odd number of steps: the last instance stands alone", 1200, 46)])
+    ("gru", 40, "config 4's width, three tiles and an odd number of steps: the last instance stands alone", 1200, 46),
+    ("gru", 128, "config 4's width, eight tiles per workgroup (as many as a workgroup carries)", 1200, 30)])
 def test_second_generation_walks_several_tiles_vs_oracle(native, kind, B, why, H, T):
     """H = 1024 / 1200: the workgroups of both directions leave room for ONE tile group on 256 CUs, so every workgroup of
     rnn_persist16.hip walks ceil(B / 16) batch tiles per step (ragged lengths, ragged last tile)."""

@@ -63,7 +63,8 @@ struct RingArgs {
     unsigned spin_limit;
     int drop_wg, drop_step;
     int skip;                  // timing experiments only (DSMI_DEBUG_RING_SKIP; results are garbage): 1 no state DMA, 2 no MFMAs, 4 no polls,
-                               // 8 no x-projection requests, 16 no output / publish stores
+                               // 8 no x-projection requests, 16 no output / publish stores, 32 no wave priorities, 64 every slot ~500 cycles longer
+                               // (128: nothing -- the build with the switches as it stands)
     unsigned long long* dbg;   // diagnostics build only: per wave, 100 MHz ticks: [0] M work, [1] M-end waits, [2] C work, [3] barrier
                                // behind M, [4] barrier behind C, [5] poll spin; [7] slots; shader cycles: [6] M work, [8] M head (to the
                                // first operands' arrival), [9] MFMA loop, [10] partial tiles -> LDS, [11] DMA requests, [12] reduce + cell,
@@ -414,6 +415,7 @@ unsigned hchs = hchs_, cnts = cnts_, orows = orows_, xrows = xrows_;
             // the cell slot is a short chain of dependent vector and LDS instructions, the MFMA slot a long stream that only needs
             // the matrix pipe kept fed: the cell wave goes first wherever both want the SIMD's issue port
             if (!(skipf & 32)) { if (hx == 0) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3); }
+            if (skipf & 64) __builtin_amdgcn_s_sleep(8);       // (timing experiments: every slot ~500 cycles longer)
             if (hx == 0) {
                 mfma_item(jc, s);
                 RT_MARK(0);
@@ -439,6 +441,7 @@ unsigned hchs = hchs_, cnts = cnts_, orows = orows_, xrows = xrows_;
             RT_MARK(3 + hx);
             // ---------------- odd slot 2q + 1: A finishes item q; B multiplies it and polls for item q + 2
             if (!(skipf & 32)) { if (hx == 0) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }
+            if (skipf & 64) __builtin_amdgcn_s_sleep(8);
             if (hx == 0) {
                 cell_item(jc, t, osoff, parw, jc, false, 0u, JN, J + 1 < NT ? xstep : xnext, J + 1 < NT || more);
                 RSTAMP(13);

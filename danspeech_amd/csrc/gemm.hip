@@ -212,6 +212,7 @@ struct GemmSplitArgs {
     const uint16_t* w_sp; const float* bias; float* c;
     int M, N, K, lda, ldc, B, T, ys, tiles_per_b, ktiles;
     int ntiles, mtiles;       // output tiles (gemm kernel's XCD-aware tile order)
+    int pn;                   // n-tiles of a W panel: what an XCD keeps in its L2 while it walks the m-tiles (gemm_panel_width)
 };
 
 // Pass 1: form the A operand ONCE (producer transforms + two-term split) as tiled fp16 planes
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(256, 3) void gemm_f16x3_kernel(GemmSplitArgs p, con
         const int share = (total + 7) / 8;
         const int idx = (blockIdx.x & 7) * share + (blockIdx.x >> 3);
         if ((int)(blockIdx.x >> 3) >= share || idx >= total) return;
-        constexpr int PN = 8;
+        const int PN = p.pn;
         const int panel = idx / (PN * mtiles), rem = idx - panel * (PN * mtiles);
         const int pw = min(PN, ntiles - panel * PN);
         mt = rem / pw; nt = panel * PN + (rem - mt * pw);
@@ -408,6 +409,16 @@ std::vector<uint16_t> pack_gemm_w_split(const float* w, int N, int K, int ldw) {
     return out;
 }
 
+// The W panel an XCD walks the m-tiles with should stay in that XCD's 4-MiB L2 beside the A tiles streaming through it (a k-tile of
+// one n-tile is 16 KiB: two planes).  Measured by FETCH_SIZE on 64-clip launches (tools/exp/gemm_panel_fetch.sh,
+// profiles/r04_gemm_panel_fetch.txt): eight n-tiles 1.46 GB (K = 800) / 3.75 GB (K = 1312), five 1.29 / 2.81, four 1.35 / 2.78, three
+// 1.58 / 3.16 -- five; the time does not move, alone or in the pipeline.  DSMI_DEBUG_GEMM_PN overrides.
+static int gemm_panel_width(int ktiles) {
+    static const int forced = [] { const char* e = std::getenv("DSMI_DEBUG_GEMM_PN"); return e ? std::atoi(e) : 0; }();
+    (void)ktiles;
+    return forced > 0 ? forced : 5;
+}
+
 void launch_gemm(const GemmLaunch& g, hipStream_t s) {
     if (g.w_sp && g.a_sp) {
         GemmSplitArgs a;
@@ -424,6 +435,7 @@ void launch_gemm(const GemmLaunch& g, hipStream_t s) {
             default: hipLaunchKernelGGL(split_a_kernel<GEMM_A_CONV>, sgrid, dim3(256), 0, s, a, g.a_sp); break;
         }
         a.ntiles = ceil_div(g.N, BN); a.mtiles = mtiles3;
+        a.pn = gemm_panel_width(a.ktiles);
         const dim3 grid3(8 * ceil_div(a.ntiles * a.mtiles, 8));
         const size_t lds3 = 32768;                      // one stage: four 8-KiB operand planes of a 32-deep k-tile
         if (g.mode == GEMM_A_CONV) DSMI_LAUNCH(gemm_f16x3_kernel<true>, grid3, dim3(256), lds3, s, g.ev, a, (const uint16_t*)g.a_sp);

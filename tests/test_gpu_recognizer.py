@@ -118,6 +118,25 @@ def test_forwards_in_flight_follow_the_first_forward():
     assert len(rec2.danspeech_recognizer._replicas) == 2
 
 
+def test_wide_model_stream_of_batches_runs_clean():
+    """Config 4's width (H = 1200: the tile-walking recurrent kernel, four tiles per workgroup) as a stream of 64-clip batches, with the
+    forwards in flight the engine picks and with four: every batch equals the single call, and no hand-off of any handle timed out
+    (a recomputed batch would give the same strings)."""
+    from danspeech_amd import Recognizer
+    model, sd, cfg = _model("wide", 1200, 3, seed=5)
+    rec = Recognizer(model=model)
+    eng = rec.danspeech_recognizer
+    clips = [syn.make_clip(i, 32000 + 500 * (i % 7)) for i in range(64)]
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        one = rec.recognize_batch(clips)
+        for lanes in (None, 4):
+            assert all(out == one for out in eng.transcribe_batches([clips] * 6, lanes=lanes))
+    handles = [eng.model._native] + [r[0]._native for r in eng._replicas]
+    assert len(handles) == 4 and [h.recompute_count() for h in handles] == [0, 0, 0, 0]
+    assert not [x for x in w if "timed out" in str(x.message)]
+
+
 def test_device_clips_batches_wait_for_their_producer():
     """Device-resident clips are produced by asynchronous work on the caller's stream (an RCCL scatter, a widening copy): every
     second batch of the pipeline runs on a side stream, which must wait for that producer.  Here the producer is a slow chain

@@ -55,6 +55,15 @@ def run(name, rec, B, seconds, reps=3):
 
 
 which = ([int(a) for a in sys.argv[1:]] or [2, 3, 4, 5, 6]) if __name__ == "__main__" else []
+if len(which) > 1:
+    # One process per configuration: the ROCm runtime deals every stream a process creates onto GPU_MAX_HW_QUEUES hardware queues in
+    # turn, so the second engine's lane and decode streams land on queues the first engine's (idle) streams already hold, two of its
+    # own on one queue as often as not -- and two streams on one queue run one after the other (config 3 read 9.3 ms per batch as the
+    # second engine of a process, 6.8-7.9 alone).
+    import subprocess
+    for cfg_no in which:
+        subprocess.run([sys.executable, os.path.abspath(__file__), str(cfg_no)])
+    which = []
 if 2 in which:
     run("config 2: cfgA greedy B=32 x 10 s", build(800, 5), 32, 10.0)
 if 3 in which:

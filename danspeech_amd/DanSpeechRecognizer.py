@@ -18,6 +18,7 @@ Everything numeric runs in libdsmi.so on the MI355X; ``with_gpu`` is accepted fo
 """
 import warnings
 
+import os
 import numpy as np
 
 from .deepspeech.decoder import GreedyDecoder, BeamCTCDecoder
@@ -84,6 +85,9 @@ class _BatchJob(object):
         return self.recomputed
 
 
+_SIDE_STREAMS = {}        # (name, device index) -> torch.cuda.Stream, shared by every engine of the process: see _side_stream
+
+
 class DanSpeechRecognizer(object):
 
     def __init__(self, model_name=None, lm_name=None, alpha=1.3, beta=0.2, with_gpu=False, beam_width=64):
@@ -141,13 +145,17 @@ class DanSpeechRecognizer(object):
 
     # ---- batches ----------------------------------------------------------------------------------------------------
     def _side_stream(self, name):
-        """A per-engine HIP stream beside the compute stream ("decode": the decoder of batch i runs while batch
-        i+1 computes)."""
+        """A HIP stream beside the compute stream ("lane k": the k-th forward in flight; "decode": the decoder of batch i runs
+        while batch i + 1 computes).  ONE set per device for every engine of the process: the ROCm runtime deals each stream a
+        process creates onto GPU_MAX_HW_QUEUES hardware queues in turn, so a second engine with streams of its own would find
+        two of them on one queue as often as not, and those run one after the other (measured: config 5's share 113 ms per
+        batch as the fourth engine of a process, 100 ms alone).  Engines are used one at a time; two used at once share the lanes."""
         import torch
         key = (name, self._device_index())
-        if key not in self._side_streams:
-            self._side_streams[key] = torch.cuda.Stream(device=key[1])
-        return self._side_streams[key]
+        if key not in _SIDE_STREAMS:
+            _SIDE_STREAMS[key] = torch.cuda.Stream(device=key[1])
+        self._side_streams[key] = _SIDE_STREAMS[key]
+        return _SIDE_STREAMS[key]
 
     def _stage_batch(self, recordings, parser=None):
         """Host clips, longest first (pack_padded_sequence's order, reference model.py:117), copied to pinned memory and on

@@ -115,7 +115,7 @@ class SpectrogramAudioParser(AudioParser):
         if getattr(self, "_slots", None) is None:
             self._slots = [dict(buf=None, done=None, dev=None, used=None), dict(buf=None, done=None, dev=None, used=None)]
             self._turn = 0
-            self._copy_stream = torch.cuda.Stream(device=self.device)
+            self._copy_stream = None         # made when an upload asks for it: every stream of the process takes a place on the hardware queues
         slot = self._slots[self._turn]
         self._turn ^= 1
         if slot["done"] is not None:
@@ -154,15 +154,22 @@ class SpectrogramAudioParser(AudioParser):
             copy(0, len(recordings))
         # the parser's own upload stream, or the one all parsers of the device share (share_copy_stream: set by a pipeline
         # that also keeps a decode stream busy -- see _shared_copy_stream)
-        up = _shared_copy_stream(self.device) if getattr(self, "share_copy_stream", False) else self._copy_stream
         nbytes = total * dtype.itemsize
         if getattr(self, "upload_on_compute_stream", False):
             # the pipeline's choice: no copy stream at all -- parse_batch uploads on the stream that runs the forward (1.7 ms of a
             # 40 ms forward, while the other forwards in flight keep the device busy).  A forward enqueued behind a cross-stream wait
-            # for an upload on another stream found that upload taking 20 ms.
+            # for an upload on another stream found that upload taking 20 ms; measured again at the end of round 4 with
+            # five streams in the process (no two on one hardware queue): one shared upload stream 7.33 ms per batch, one per parser
+            # 7.58, this 5.89-5.98.
             if slot["dev"] is None or slot["dev"].numel() < nbytes:
                 slot["dev"] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device="cuda:%d" % self.device)
             return StagedClips(slot["buf"][:nbytes], n, dtype.itemsize, None, slot)
+        if getattr(self, "share_copy_stream", False):
+            up = _shared_copy_stream(self.device)
+        else:
+            if self._copy_stream is None:
+                self._copy_stream = torch.cuda.Stream(device=self.device)
+            up = self._copy_stream
         with torch.cuda.stream(up):
             # the slot's own device buffer (not a fresh allocation per batch: tens of megabytes allocated on the copy stream and
             # released on the compute stream go round the caching allocator's cross-stream bookkeeping every batch)

@@ -294,15 +294,15 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void rnn_persist16_kern
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Several batch tiles per workgroup (more 16-clip tiles than fit side by side): the tile instances (step s, tile z)
-// are software-pipelined.  While the cell of instance i runs (LDS reduce, exp/rcp, stores), the state of instance
-// i+1 is already on its way from L2, and instance i is signalled behind instance i+1's MFMAs (its write-through
-// stores drain meanwhile): the per-instance chain shrinks from wait + load + MFMA + reduce + cell + drain to
-// max(wait, ...) + MFMA + reduce + cell.  The reduce buffer is double-buffered because a fast wave may write
-// instance i+1's partial tiles while a cell wave still reads instance i's.
-// Every wave issues the same two 2-byte state stores after its state loads (the non-cell waves' go out of the buffer's
-// bounds and are dropped by the hardware, but still count), so that "wait until at most two memory operations are
-// outstanding" means "my state loads have landed" for every wave.
+// Several batch tiles per workgroup (more 16-clip tiles than fit side by side): the tile-walking kernel.  A workgroup walks the
+// tile instances i = s * nz + z (step s, its z-th tile) with ONE barrier per instance: MFMAs of instance i and partial tiles
+// -> barrier -> signal of instance i - 1 (its stores were drained in front of the barrier) -> cell of instance i, and the
+// reduce buffer is double-buffered because a fast wave writes instance i + 1's partial tiles while a cell wave still reads
+// instance i's.  From four tiles per workgroup on (and where the registers allow: AHEAD) the eight K-split waves have ROLES
+// (round 4; DESIGN.md 4 "The tile-walking kernel"): waves 0-3 reduce, run the cell, publish and signal and never poll; waves
+// 4-7, the feeders, poll for instance i + 2 behind their MFMAs of instance i and request their part of its state two
+// instances ahead.  Workgroups of two or three tiles (the short groups of a launch) run a one-role form: every wave polls for
+// instance i + 1 in front of its MFMAs of instance i (a two-tile group: behind its own signal).
 template <int KIND, int NKW, bool SKIPS = false>
 __global__ __launch_bounds__(QNT) void rnn_persist16_pipe_kernel(P16Args p) {
     const int skip = SKIPS ? p.skip : 0;                             // (timing experiments: a build of its own)

@@ -10,6 +10,7 @@
 // histogram selection); the parity tests compare with both.  DESIGN.md 4 "Beam search" describes the frame's six phases.
 #include "common.h"
 #include <cstring>
+#include <mutex>
 #include "lm.h"
 #include "lm.cpp.inc"
 #include "lm_klm.cpp.inc"
@@ -52,8 +53,27 @@ struct dsmi_decoder {
     int32_t* pin_sz = nullptr; size_t pin_sz_cap = 0;
     unsigned char* pin = nullptr; size_t pin_bytes = 0;
     hipEvent_t beam_done = nullptr;
-    hipStream_t copy_stream = nullptr;      // the collect's device-to-host copies: a stream of the handle's own
+    hipStream_t copy_stream = nullptr;      // the collect's device-to-host copies: the device's collect stream (collect_stream)
 };
+
+// ONE stream per device for the device-to-host copies of every decoder handle's collect, made at the first collect and kept for
+// the life of the process.  (It was a stream per handle: a pipeline with a beam search keeps six decoder handles, and the runtime
+// deals every stream of a process onto GPU_MAX_HW_QUEUES hardware queues in turn -- a collect whose stream shares a queue with a
+// lane's stream waits behind that lane's 40-ms forward.  The copies are host-synchronous and short: one stream serves them all.)
+static hipStream_t collect_stream(int device) {
+    static std::mutex mu;
+    static hipStream_t per_device[64] = {};
+    std::lock_guard<std::mutex> lock(mu);
+    if (device < 0 || device >= 64) return nullptr;
+    if (!per_device[device]) {
+        // highest priority: the runtime keeps the queues of a priority apart from the others', so this stream shares none with a lane
+        int lo = 0, hi = 0;
+        (void)hipSetDevice(device);
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = 0; hi = 0; }
+        if (hipStreamCreateWithPriority(&per_device[device], hipStreamNonBlocking, hi) != hipSuccess) per_device[device] = nullptr;
+    }
+    return per_device[device];
+}
 
 static thread_local std::string g_dec_error;
 
@@ -91,7 +111,7 @@ static void free_lm(dsmi_decoder* d) {
 extern "C" void dsmi_decoder_destroy(dsmi_decoder* d) {
     if (d && d->pin) { (void)hipSetDevice(d->device); (void)hipDeviceSynchronize(); (void)hipHostFree(d->pin); d->pin = nullptr; }
     if (d && d->beam_done) { (void)hipEventDestroy(d->beam_done); d->beam_done = nullptr; }
-    if (d && d->copy_stream) { (void)hipStreamDestroy(d->copy_stream); d->copy_stream = nullptr; }
+    if (d) d->copy_stream = nullptr;        // (the device's collect stream: not the handle's to destroy)
     if (d && d->pin_sz) { (void)hipHostFree(d->pin_sz); d->pin_sz = nullptr; }
     if (d && d->gh) { (void)hipSetDevice(d->device); (void)hipDeviceSynchronize(); (void)hipHostFree(d->gh); d->gh = nullptr; }
     if (d && d->g_done) { (void)hipEventDestroy(d->g_done); d->g_done = nullptr; }
@@ -336,7 +356,8 @@ extern "C" int dsmi_beam_collect(dsmi_decoder* d, int32_t* tokens, int32_t* tste
     const unsigned char* dev = d->ws + d->pb_out;
     // (on a stream of the handle's own: a blocking copy would go to the null stream and wait there for whatever forward the
     // caller has queued meanwhile, and the search's stream may already hold the next batch's search of another handle)
-    if (!d->copy_stream) DEC_HIP(d, hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking));
+    if (!d->copy_stream) d->copy_stream = collect_stream(d->device);
+    if (!d->copy_stream) { d->err = "no stream for the collect's copies"; return DSMI_ERR_HIP; }
     DEC_HIP(d, hipMemcpyAsync(d->pin + 2 * tok_bytes, dev + 2 * tok_bytes, d->pb_out_bytes - 2 * tok_bytes, hipMemcpyDeviceToHost, d->copy_stream));
     DEC_HIP(d, hipStreamSynchronize(d->copy_stream));
     const unsigned char* q0 = d->pin;

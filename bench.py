@@ -28,6 +28,9 @@ Rank 0 prints ONE JSON line (see the driver contract), including
   parity         -- max |probs - oracle| and transcript equality of the GPU's batch vs that oracle run
   host_arrays    -- the same call with float64 HOST arrays in (staging + PCIe upload included), N = 1 only; never `value`
   abi_path       -- the same work as bare C-ABI calls (dsmi_features / dsmi_forward / dsmi_greedy), N = 1 only
+  steady_state   -- the timed entry again over --steady-steps (>= 96) steps after the timed region, with `energy` (mean board
+                    power and joules per batch over those steps), N = 1 only; never `value`
+  rccl           -- N > 1: RCCL's version and the world size the process group reports (a rank count other than --gpus exits 4)
 
 ``--dry-run`` (CPU, no GPU work, backend gloo, a stand-in engine) exercises the launch, scatter, per-step gather and
 the JSON line; its numbers mean nothing and the line says so.
@@ -123,6 +126,69 @@ class _DryEngine(object):
             yield ["dry %d" % int(row.sum()) for row in rows]
 
 
+class PowerSampler(object):
+    """Board power of one GPU, sampled by a thread while a block runs: the hwmon file of the device (microwatts) where the
+    driver exposes it to an ordinary user, `rocm-smi --showpower` otherwise (slower: fewer samples)."""
+
+    def __init__(self, index=0, period=0.05):
+        self.index, self.period, self.vals, self.source = index, period, [], None
+        self._stop = None
+        self._file = self._find_hwmon(index)
+
+    @staticmethod
+    def _find_hwmon(index):
+        import glob
+        cards = []
+        for dev in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+            for name in ("power1_average", "power1_input"):
+                hits = glob.glob(os.path.join(dev, "hwmon", "hwmon*", name))
+                if hits:
+                    cards.append(hits[0])
+                    break
+        return cards[index] if index < len(cards) else None
+
+    def _read(self):
+        if self._file:
+            try:
+                with open(self._file) as f:
+                    return int(f.read().strip()) / 1e6
+            except (OSError, ValueError):
+                self._file = None
+        import re
+        import subprocess
+        try:
+            out = subprocess.run(["rocm-smi", "-d", str(self.index), "--showpower"], capture_output=True, text=True, timeout=5).stdout
+            m = re.search(r"Power[^:]*:\s*([0-9.]+)", out)
+            return float(m.group(1)) if m else None
+        except Exception:
+            return None
+
+    def __enter__(self):
+        import threading
+        self.source = ("sysfs " + self._file) if self._file else "rocm-smi --showpower"
+        self._stop = threading.Event()
+
+        def loop():
+            while not self._stop.is_set():
+                v = self._read()
+                if v is not None:
+                    self.vals.append(v)
+                self._stop.wait(self.period)
+        self._thread = threading.Thread(target=loop, daemon=True)
+        self._thread.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        self._thread.join(timeout=10)
+
+    def mean_watts(self):
+        return sum(self.vals) / len(self.vals) if self.vals else None
+
+    def count(self):
+        return len(self.vals)
+
+
 def physical_cores():
     """(count, model name) of this host's physical cores from /proc/cpuinfo."""
     cores, model, phys, core = set(), "unknown", None, None
@@ -163,6 +229,7 @@ def main(argv=None):
     ap.add_argument("--strict-f32-child", action="store_true", help=argparse.SUPPRESS)     # the f32_strict side run (a fresh process)
     ap.add_argument("--abi-child", action="store_true", help=argparse.SUPPRESS)            # the abi_path side run (a fresh process)
     ap.add_argument("--no-kernel-sampling", action="store_true")
+    ap.add_argument("--steady-steps", type=int, default=384, help="steps of the steady_state side run (at least 96)")
     ap.add_argument("--dry-run", action="store_true", help="CPU only: launch, scatter, gather and the JSON line with a stand-in engine")
     args = ap.parse_args(argv)
 
@@ -188,11 +255,18 @@ def main(argv=None):
     else:
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
+    rccl = None
     if world > 1:
         if dry:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+        if dist.get_world_size() != args.gpus:          # a launcher that started fewer ranks than asked for must not read as N GPUs
+            sys.stderr.write("bench.py: --gpus %d but the process group has %d ranks\n" % (args.gpus, dist.get_world_size()))
+            raise SystemExit(4)
+        if not dry:
+            rccl = {"version": ".".join(str(x) for x in torch.cuda.nccl.version()), "world_size_seen": dist.get_world_size(),
+                    "backend": dist.get_backend()}
 
     c = dict(CONFIGS[args.config])
     if args.hidden:
@@ -288,6 +362,23 @@ def main(argv=None):
             a["avg_us"] = a["_us"] / max(a["samples"], 1)
             a["flops_per_launch"] = a["_fl"] / max(a["launches"], 1)
             a["bytes_per_launch"] = a["_by"] / max(a["launches"], 1)
+    # ---- side measurement, after the timed region: the same entry over enough steps that the pipeline's fill and drain (four forwards
+    # of two batches) are a few per cent of it, with the board power sampled beside it.  Never `value`.
+    steady = None
+    if world == 1 and not dry and not args.no_side_paths and not args.strict_f32_child:
+        ss_steps = max(args.steady_steps, 96)
+        with PowerSampler(local) as pw:
+            sync()
+            t1 = time.perf_counter()
+            run(ss_steps)
+            sync()
+            dts = time.perf_counter() - t1
+        steady = {"value": round(B * (n_samples / 16000.0) * ss_steps / dts, 2), "unit": "audio-s/s", "ms_per_step": round(dts / ss_steps * 1e3, 3),
+                  "steps": ss_steps, "entry": "the timed entry again, run after the timed region"}
+        watts = pw.mean_watts()
+        steady["energy"] = {"watts_mean": None if watts is None else round(watts, 1),
+                            "joules_per_batch": None if watts is None else round(watts * dts / ss_steps, 3),
+                            "samples": pw.count(), "source": pw.source, "note": "board power while the steady-state steps ran"}
     recomputed = sum(h.recompute_count() for h in handles)
     P = (1 + len(eng._replicas)) if eng is not None else 2           # forwards in flight, each of up to pipeline_merge_clips clips
     merge_clips = max(eng.pipeline_merge_clips, B) if eng is not None else B
@@ -314,14 +405,15 @@ def main(argv=None):
                         frac=round(ach / peak, 4), traffic=(PMC_TRAFFIC.get(dom) or {}).get("bytes_per_launch"),
                         peak_note=("fp16 dense MFMA peak 2500 TFLOP/s / 3 products per fp32-grade multiply (executed fp16 rate = 3 x achieved)"
                                    if split else "fp32 MFMA peak"),
-                        # with P batches in flight P launches of the recurrent kernel run at a time, each on its own lane of CUs:
-                        # `achieved` / `frac` are per launch (the contract's definition); the rate the chip sustains while they
-                        # run is `concurrent_launches` times that
-                        concurrent_launches=(P if dom == "rnn_layer_persistent" else 1),
-                        frac_all_concurrent_launches=round(ach / peak * (P if dom == "rnn_layer_persistent" else 1), 4),
+                        # `achieved` / `frac` are per launch (the contract's definition).  Launches of this kernel overlap (one per
+                        # forward in flight, each on its own CUs): their summed durations / the timed region's wall time is the
+                        # MEASURED time-averaged number of them running, and frac x that the share of the chip's peak this kernel
+                        # sustains over the whole region
+                        mean_concurrent_launches=round(s["avg_us"] * 1e-6 * s["launches"] / dt, 3),
+                        frac_chip_time_averaged=round(ach / peak * s["avg_us"] * 1e-6 * s["launches"] / dt, 4),
                         traffic_source=PMC_TRAFFIC.get("_source", "profiles/pmc_traffic.json (builder's counter pass of an earlier tree, "
                                                                    "not measured in this run)"),
-                        avg_launch_us=round(s["avg_us"], 3), launches_per_step=s["launches"] // args.steps,
+                        avg_launch_us=round(s["avg_us"], 3), launches_per_step=round(s["launches"] / args.steps, 3),
                         flops_per_launch=s["flops_per_launch"],
                         kernel_time_share={k: round(v / sum(tot.values()), 4) for k, v in sorted(tot.items())})
         result = {
@@ -342,7 +434,7 @@ def main(argv=None):
             # every sampled kernel kind: mean dispatch time, ALGORITHMIC rates (SURVEY 8(d) FLOPs and bytes) and, where a
             # counter pass exists, the HBM/fabric bytes per launch it measured (FETCH_SIZE x2 + WRITE_SIZE) and that rate;
             # conv1/conv2 are the "conv front end" the north star asks GB/s for (HBM spec 8000 GB/s)
-            "kernels": {k: {"avg_us": round(v["avg_us"], 2), "launches_per_step": v["launches"] // args.steps,
+            "kernels": {k: {"avg_us": round(v["avg_us"], 2), "launches_per_step": round(v["launches"] / args.steps, 3),
                             "tflops": round(v["flops_per_launch"] / (v["avg_us"] * 1e-6) / 1e12, 2),
                             "gbps": round(v["bytes_per_launch"] / (v["avg_us"] * 1e-6) / 1e9, 1),
                             "pmc_bytes": (PMC_TRAFFIC.get(k) or {}).get("bytes_per_launch"),
@@ -353,7 +445,11 @@ def main(argv=None):
             "sample_transcript_len": len(out[0]) if out else None,
             "transcripts_gathered": len(out) if out else 0,
             "recomputed_batches": recomputed,
+            "steady_state": steady,
+            "energy": steady["energy"] if steady else None,
         }
+        if rccl:
+            result["rccl"] = rccl
         if world == 1 and not args.no_cpu_baseline and not dry:
             probs, sizes = eng.last_output          # the last forward: consecutive batches merged, this batch's clips first
             base, parity = cpu_baseline_and_parity(cfg, sd, B, n_samples, labels, {"probs": probs[:B], "out_lens": np.asarray(sizes)[:B]}, out)

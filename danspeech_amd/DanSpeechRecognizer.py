@@ -274,7 +274,11 @@ class DanSpeechRecognizer(object):
         list per batch.  ``batches`` is read AHEAD of the results: up to ``merge_clips`` clips for the forward being put
         together, plus one forward more (host clips are copied to pinned memory and uploaded before the loop waits for the
         GPU) -- a source that produces a batch only after it has seen an earlier batch's result must pass ``lanes=1,
-        merge_clips=0``."""
+        merge_clips=0``: then batch k + 1 is read only after result k has been yielded, on the caller's own thread.  In every
+        other mode ``batches`` is advanced on a HELPER THREAD (one, the same for the whole call), concurrently with the
+        consumer's loop body: a source with thread-affine state (a GUI toolkit's objects, a thread-local CUDA stream of its own)
+        must be wrapped accordingly or use the sequential mode.  Latency: with the defaults (four forwards of up to 64 clips in
+        flight and one staged) a result comes out eight to ten batches of 32 clips after its batch was read."""
         import torch
         import collections
         auto_lanes = lanes is None
@@ -392,6 +396,15 @@ class DanSpeechRecognizer(object):
                     count += 1
                 pending.append((parts, job))
                 job = None
+                if helper is None:
+                    # strictly sequential (lanes=1, merge_clips=0): every result is out before the source is asked for its next
+                    # batch -- a source may wait for result k before it produces batch k + 1
+                    while pending:
+                        done = pending.popleft()
+                        res = results_of(done)
+                        done = None
+                        for r in res:
+                            yield r
                 ahead = fetch_ahead(parsers[turn])   # the next forward: staged now, beside the waits below
                 # (one more than `depth` may be pending for a moment: the oldest forward has been waited for above -- it ran on the
                 # lane that was just refilled -- and only its strings are still to be made, while every lane is busy again)

@@ -78,6 +78,7 @@ constexpr int kMaxLanes = 4;
 // (the two families never share the device: the other kernels' grids are sized for halves and quarters of it).
 constexpr int kRingSlots = 5;
 struct PersistGate { std::mutex mu; hipEvent_t ev[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr}; hipEvent_t ring_ev[kRingSlots] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+                     int ring_cus[kRingSlots] = {0, 0, 0, 0, 0};     // CUs of the window last recorded on each ring slot (it may still be running)
                      int lock_fd = -1; bool lock_tried = false; int next_lane = 0; };
 
 // slots a launch of `width` (1, 2 or kMaxLanes) takes for a handle whose home slot is `lane`: [first, first + width)
@@ -89,16 +90,31 @@ static void gate_wait(PersistGate* g, hipStream_t s, int lane, int width) {
     for (int i = 0; i < kRingSlots; ++i)
         if (g->ring_ev[i]) (void)hipStreamWaitEvent(s, g->ring_ev[i], 0);
 }
-// The same for `n` windows of the ring kernel on ring slots [first, first + n).
-static void ring_gate_wait(PersistGate* g, hipStream_t s, int first, int n) {
-    for (int i = first; i < first + n && i < kRingSlots; ++i)
+// The same for `n` windows of the ring kernel, `cus` CUs each, on ring slots [first, first + n).  Slots are counted per model
+// (n_cus / cus of ITS geometry), but they index one set of events per device: two models of different widths in one process
+// could otherwise be admitted side by side beyond the device (H = 800: 50 CUs on slots 0..4, H = 896: 56 CUs on slots 0..3 --
+// slot 4 at 50 CUs beside four windows at 56 is 274 CUs), and windows that are not all resident spin to their timeout.  So a
+// launch also waits for as many OTHER slots as it takes for the windows that may still run plus its own to fit the device.
+static void ring_gate_wait(PersistGate* g, hipStream_t s, int first, int n, int cus, int n_cus) {
+    int others = 0;
+    for (int i = 0; i < kRingSlots; ++i) {
+        const bool mine = i >= first && i < first + n;
+        if (mine) { if (g->ring_ev[i]) (void)hipStreamWaitEvent(s, g->ring_ev[i], 0); }
+        else others += g->ring_cus[i];
+    }
+    for (int i = 0; i < kRingSlots && others + n * cus > n_cus; ++i) {
+        if ((i >= first && i < first + n) || !g->ring_cus[i]) continue;
         if (g->ring_ev[i]) (void)hipStreamWaitEvent(s, g->ring_ev[i], 0);
+        others -= g->ring_cus[i];
+    }
     for (int i = 0; i < kMaxLanes; ++i)
         if (g->ev[i]) (void)hipStreamWaitEvent(s, g->ev[i], 0);
 }
-static void ring_gate_record(PersistGate* g, hipStream_t s, int first, int n) {
-    for (int i = first; i < first + n && i < kRingSlots; ++i)
+static void ring_gate_record(PersistGate* g, hipStream_t s, int first, int n, int cus) {
+    for (int i = first; i < first + n && i < kRingSlots; ++i) {
         if (g->ring_ev[i]) (void)hipEventRecord(g->ring_ev[i], s);
+        g->ring_cus[i] = cus;
+    }
 }
 // ... and publish the launch on them.
 static void gate_record(PersistGate* g, hipStream_t s, int lane, int width) {
@@ -191,6 +207,7 @@ extern "C" int dsmi_model_create(const dsmi_model_desc* d, int device, dsmi_mode
         // parity tests of those kernels); =ring: the ring kernel also for a lone batch of up to 32 clips
         const char* rk = std::getenv("DSMI_RNN_KERNEL");
         m->rnn_kernel = (rk && std::string(rk) == "duo") ? 1 : ((rk && std::string(rk) == "ring") ? 2 : 0);
+        m->ring8 = rk && std::string(rk) == "ring8";      // the eight-wave form of the ring kernel (A/B runs)
         // DSMI_DENSE_MODE=f32: GEMM and conv layers on the plain fp32-MFMA kernels (the round-1 path, and where a model whose
         // weights leave fp16's range ends up by itself); with DSMI_RNN_MODE=steps the whole forward is the second, independent
         // implementation the parity tests compare the default one with
@@ -587,7 +604,7 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
     if (use16 && m->rnn_kernel != 1 && (m->inflight >= 2 || B > 32 || m->rnn_kernel == 2)) {
         const int rcus = rnn_persist_ring_cus(m->geom16);
         ring_slots = rcus > 0 ? std::min(kRingSlots, m->n_cus / rcus) : 0;        // windows the device holds side by side
-        const int cap = ring_slots >= 2 ? rnn_persist_ring_tiles(m->geom16, B, rcus) : 0;
+        const int cap = ring_slots >= 2 ? (m->ring8 ? rnn_persist_ring_tiles(m->geom16, B, rcus) : rnn_persist_ring4_tiles(m->geom16, B, rcus)) : 0;
         if (cap > 0) {
             const int ntiles = ceil_div(B, 16);
             const int slots = m->inflight >= 2 ? 1 : std::min(ring_slots, kMaxLanes);
@@ -632,9 +649,10 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
             PersistGate* gate = persist_gate(m->device);
             std::lock_guard<std::mutex> lk(gate->mu);
             const int first = nw == 1 ? m->lane % ring_slots : 0;      // a handle's own slot; several windows: from slot 0
-            ring_gate_wait(gate, s, first, nw);
-            ok = launch_rnn_persist_ring(pl, s);
-            ring_gate_record(gate, s, first, nw);
+            const int rcus = rnn_persist_ring_cus(m->geom16);
+            ring_gate_wait(gate, s, first, nw, rcus, m->n_cus);
+            ok = m->ring8 ? launch_rnn_persist_ring(pl, s) : launch_rnn_persist_ring4(pl, s);
+            ring_gate_record(gate, s, first, nw, rcus);
         }
         if (ring_ntw && ok) return;
         for (int p0 = 0; !ring_ntw && p0 < (duo ? total_pairs : 1) && ok; p0 += window) {
@@ -1057,7 +1075,8 @@ extern "C" int dsmi_debug_step_stamps(dsmi_model* m, int layer, int B, int To, i
 // ---- diagnostics: accumulated per-wave phase times (100 MHz ticks) of one persistent layer launch;
 // stamps_host[workgroups][8 waves][8]: 0 loop head, 1 wait, 2 h load + MFMA, 3 LDS + barrier, 4 cell (+ publish stores),
 // 5 drain + signal.  Returns the number of workgroups stamped (> 0) or a DSMI_ERR_* code (< 0).
-// DSMI_STAMP_RING=1: the ring kernel (one window of every tile of B <= 128 clips): stamps[workgroup][8 waves][16] (RingArgs::dbg) = M work, M-end waits,
+// DSMI_STAMP_RING=1: the ring kernel (one window of every tile of B <= 64 clips): the four-wave form stamps[workgroup][4 waves][8] (Ring4Args::dbg) = phase work,
+// wait for the wave's requests, poll spin, barrier ([7] phases); DSMI_RNN_KERNEL=ring8, the eight-wave form: stamps[workgroup][8 waves][16] (RingArgs::dbg) = M work, M-end waits,
 // C work, barrier behind M, barrier behind C, poll spin (100 MHz ticks), shader cycles in M work, slots.
 static int ring_stamps(dsmi_model* m, int layer, int B, int To, uint64_t* stamps_host, int64_t n_words);
 
@@ -1145,8 +1164,9 @@ extern "C" int dsmi_debug_persist_stamps(dsmi_model* m, int layer, int B, int To
 }
 
 static int ring_stamps(dsmi_model* m, int layer, int B, int To, uint64_t* stamps_host, int64_t n_words) {
-    if (B < 1 || B > 64 || layer < 0 || layer >= m->desc.rnn_layers || !m->have16 ||
-        rnn_persist_ring_tiles(m->geom16, B, m->n_cus) < ceil_div(B, 16)) return DSMI_ERR_INVALID;
+    if (B < 1 || B > 64 || layer < 0 || layer >= m->desc.rnn_layers || !m->have16) return DSMI_ERR_INVALID;
+    const int cap = m->ring8 ? rnn_persist_ring_tiles(m->geom16, B, m->n_cus) : rnn_persist_ring4_tiles(m->geom16, B, m->n_cus);
+    if (cap < ceil_div(B, 16)) return DSMI_ERR_INVALID;
     int Tin = To;
     while (seq_len(m, Tin) < To) Tin += 1;
     int rc;
@@ -1154,13 +1174,14 @@ static int ring_stamps(dsmi_model* m, int layer, int B, int To, uint64_t* stamps
     HIP_OK(m, hipSetDevice(m->device));
     if (!persist_process_lock(m->device)) return fail(m, DSMI_ERR_INVALID, "another process holds this GPU's persistent-kernel lock");
     PersistGate* stamp_gate = persist_gate(m->device);
-    std::lock_guard<std::mutex> stamp_lk(stamp_gate->mu);
+    std::lock_guard<std::mutex> stamp_lk(stamp_gate->mu);      // (no other launch of this process can start; the device is drained below)
     HIP_OK(m, hipDeviceSynchronize());
+    // per workgroup: the eight-wave form 8 waves x 16 words, the four-wave form 4 waves x 8 words (in the first 32 of the 128)
     const int64_t need = (int64_t)rnn_persist_ring_cus(m->geom16) * 8 * 16;
     if (n_words < need) return fail(m, DSMI_ERR_INVALID, "stamp buffer too small");
-    unsigned long long* dbg;
-    HIP_OK(m, hipMalloc((void**)&dbg, sizeof(unsigned long long) * need));
-    HIP_OK(m, hipMemset(dbg, 0, sizeof(unsigned long long) * need));
+    struct DevBuf { unsigned long long* p = nullptr; ~DevBuf() { if (p) (void)hipFree(p); } } dbg;      // freed on every return
+    HIP_OK(m, hipMalloc((void**)&dbg.p, sizeof(unsigned long long) * need));
+    HIP_OK(m, hipMemset(dbg.p, 0, sizeof(unsigned long long) * need));
     std::vector<int32_t> lens(B, To);
     HIP_OK(m, hipMemcpy(m->lens_dev, lens.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice));
     HIP_OK(m, hipMemset(m->xp, 0, sizeof(float) * (size_t)To * B * m->geom16.Np));
@@ -1172,11 +1193,10 @@ static int ring_stamps(dsmi_model* m, int layer, int B, int To, uint64_t* stamps
     bool ok = true;
     for (int rep = 0; rep < 2 && ok; ++rep) {
         HIP_OK(m, hipMemset(m->pcnt, 0, sizeof(unsigned) * (size_t)m->geom.D * ceil_div(B, 16) * To * kPersist16CntWords));
-        pl.dbg = rep ? dbg : nullptr;
-        ok = launch_rnn_persist_ring(pl, nullptr);
+        pl.dbg = rep ? dbg.p : nullptr;
+        ok = m->ring8 ? launch_rnn_persist_ring(pl, nullptr) : launch_rnn_persist_ring4(pl, nullptr);
         HIP_OK(m, hipDeviceSynchronize());
     }
-    HIP_OK(m, hipMemcpy(stamps_host, dbg, sizeof(unsigned long long) * need, hipMemcpyDeviceToHost));
-    (void)hipFree(dbg);
+    HIP_OK(m, hipMemcpy(stamps_host, dbg.p, sizeof(unsigned long long) * need, hipMemcpyDeviceToHost));
     return ok ? (int)(need / 128) : DSMI_ERR_INVALID;
 }

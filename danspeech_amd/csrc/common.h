@@ -193,6 +193,10 @@ bool launch_rnn_persist_duo(const RnnPersist16Launch& p, hipStream_t s);
 int rnn_persist_ring_tiles(const RnnGeom& g16, int B, int n_cus);    // tiles one window can walk (0: not this shape)
 int rnn_persist_ring_cus(const RnnGeom& g16);                        // CUs one window occupies
 bool launch_rnn_persist_ring(const RnnPersist16Launch& p, hipStream_t s);
+// rnn_persist_ring4.hip: the same window on FOUR waves, one per SIMD on the whole register file (W_hh of a 16-unit group's K half
+// per wave, in AccVGPRs), the cell of an item in the shadows of the next item's MFMAs.  Same CUs per window as the eight-wave form.
+int rnn_persist_ring4_tiles(const RnnGeom& g16, int B, int n_cus);   // tiles one window can walk (0: not this shape)
+bool launch_rnn_persist_ring4(const RnnPersist16Launch& p, hipStream_t s);
 
 // head.hip
 //   lookahead: y[t][b][h] = clip(sum_k w[h][k] * x[t+k][b][h], 0, 20)

@@ -233,9 +233,16 @@ extern "C" int dsmi_greedy_collect(dsmi_decoder* d, int32_t* ids, int32_t* offse
     if (!d) return DSMI_ERR_INVALID;
     if (!d->greedy_pending) { d->err = "no greedy decode to collect"; return DSMI_ERR_INVALID; }
     if (!ids || !offsets || !n_out) { d->err = "bad greedy arguments"; return DSMI_ERR_INVALID; }
-    d->greedy_pending = false;
     DEC_HIP(d, hipSetDevice(d->device));
-    DEC_HIP(d, hipEventSynchronize(d->g_done));
+    // the pinned image may be reused by the next enqueue only once its copies have landed: `pending` is cleared behind the wait,
+    // and a wait that fails falls back to the device's (the copies are then over, whatever state they are in)
+    if (hipEventSynchronize(d->g_done) != hipSuccess) {
+        (void)hipDeviceSynchronize();
+        d->greedy_pending = false;
+        d->err = "hipEventSynchronize failed while collecting the greedy decode";
+        return DSMI_ERR_HIP;
+    }
+    d->greedy_pending = false;
     const size_t rows = (size_t)d->gp_B * d->gp_T;
     std::memcpy(ids, d->gh, sizeof(int32_t) * rows);
     std::memcpy(offsets, d->gh + rows, sizeof(int32_t) * rows);

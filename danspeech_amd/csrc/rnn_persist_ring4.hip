@@ -1,0 +1,540 @@
+// Persistent recurrent layer, ring variant on the whole register file: one workgroup of FOUR waves (one per SIMD, up to 512
+// registers each) owns 32 hidden units of one direction and walks every batch tile of its window round-robin, with the tiles'
+// packed states staged through a two-slot ring in LDS -- and every wave does the cell of the previous item in the shadows of
+// the current item's MFMAs.
+//
+// Same arithmetic, packed weights, x-projection order, state layout and hand-off protocol as rnn_persist16.hip /
+// rnn_persist_duo.hip (split-fp16 products on v_mfma_f32_16x16x32_f16, sc1 stores / sc1 loads, sharded agent-scope counter per
+// (chain, step), bounded spins); replaces reference danspeech/deepspeech/model.py:114-122 (the nn.GRU / nn.LSTM / nn.RNN call
+// inside BatchRNN.forward on a packed batch).  Against the eight-wave form it replaces (two halves taking turns on the matrix
+// pipe, each with its own cell slot: a slot was as long as a GRU cell's dependent chain in ONE wave per SIMD, 0.90 us, of
+// which the partner's 63 MFMAs needed 0.58):
+//
+//   * Wave (mh, kh): the 16-unit group mh of the workgroup's two ADJACENT groups (virtual workgroups 2 w and 2 w + 1 of the
+//     16-unit geometry) and the half kh of the k-blocks.  Its W_hh -- up to 14 k-blocks x G gates x 2 planes x 4 registers = 336
+//     -- stays in registers for the whole layer: the first 256 / (8 G) k-blocks in AccVGPRs, read by the MFMAs as their A
+//     operands directly (the file is compiled with -mllvm -amdgpu-mfma-vgpr-form=1: results in VGPRs, no v_accvgpr copies),
+//     the rest in VGPRs.  One wave per SIMD is what makes the file 512 registers deep.
+//   * One phase per item q = (step s, tile j) = NT s + j, one workgroup barrier per phase:
+//
+//        P_q:  signal item q - 2  |  x-projection request for item q  |  MFMAs of item q (B operands from ring slot q & 1)
+//              with the cell of item q - 1 (K-split reduction, cell, publish, output row) and the state DMA requests of item q + 1
+//              between them  |  partial tiles -> LDS  |  wait for everything requested  |  poll for item q + 2  |  barrier
+//
+//     so the matrix pipe of every SIMD works in every phase, and a chain's hand-off (cell -> store drain -> signal -> everybody's
+//     signal visible -> state DMA -> MFMAs) lies under the other tiles' phases: NT - 1 of them.
+//   * The K-split reduction is two-way (the eight-wave form: four-way): a lane writes its 4 units x 1 clip of a gate as one
+//     16-byte store, the cell's thread -- (clip, two adjacent units) -- reads 8 bytes per gate and K-half.  Reduce buffers and the
+//     x-projection's landing zone are double-buffered by the item's parity, which is what lets ONE barrier per phase order them.
+//   * The x-projection of an item comes by LDS-DMA, 16 bytes per lane, 1 KiB per instruction ([16 clips][16 units] of one gate
+//     and group), requested at the start of the phase before the one that reads it.
+//   * Publish: the four lanes of a (clip, 8-unit k-group) hand their (hi | lo << 16) words to the first of them by DPP row shifts;
+//     that lane stores 16 bytes of each plane with sc1.  Stores carry no branch: a lane with nothing to store has an offset
+//     beyond the buffer's range.
+//   * The body of a phase is ONE basic block (no branch between the first MFMA and the last): requests that do not apply are
+//     clamped onto valid, harmless ones instead of being skipped, step 0 (h = 0: no MFMAs, no state) is a prologue of its own.
+#include "common.h"
+#include "rnn_cell.h"
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+
+namespace dsmi {
+
+namespace {
+
+constexpr int XNT = 256;               // 4 waves: (group mh = v & 1, K half kh = v >> 1)
+constexpr int XU = 16;                 // hidden units per group
+constexpr int XB = 16;                 // clips per batch tile
+constexpr int XRP = 20;                // row pitch (words) of the reduce buffers: [16 clips][16 units + 4]
+constexpr int XMAXT = 8;               // tiles a window walks at most
+
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned int;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+constexpr float kLoScale = 2048.f, kLoInv = 1.f / 2048.f;
+
+struct Ring4Args {
+    const uint16_t* whh[2];    // pack_whh16 per direction
+    const float* bhh[2]; const float* xp; float* out[2];
+    const int32_t* lens; uint16_t* hpack; unsigned* cnt; unsigned* err;
+    int B, T, H, Hs, Np, nwg16, nkb;
+    int ntiles, D;             // 16-clip tiles of the whole batch (state and counter layout), directions
+    int tile0, ntw, tile_end;  // window z (blockIdx.z) walks tiles tile0 + z * ntw .. + ntw - 1, below tile_end
+    unsigned spin_limit;
+    int drop_wg, drop_step;
+    unsigned long long* dbg;   // diagnostics build only: per wave, 100 MHz ticks: [0] phase work (to the end of the partial tiles),
+                               // [1] wait for the wave's requests, [2] poll spin (wave 0), [3] barrier; [7] phases
+};
+
+__device__ __forceinline__ void ring4_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+
+
+
+// SKIP (timing experiments only, DSMI_DEBUG_RING_SKIP; results are garbage): 1 no state DMA, 2 no MFMAs, 4 polls taken as answered,
+// 8 no x-projection requests, 16 no output / publish stores, 32 no cell
+template <int KIND, int NKW, int NT, bool STAMP = false, int SKIP = 0>
+__global__ __launch_bounds__(XNT) void rnn_persist_ring4_kernel(Ring4Args p) {
+    constexpr int NG = KIND == DSMI_RNN_GRU ? 3 : (KIND == DSMI_RNN_LSTM ? 4 : 1);
+    constexpr int NKA = NKW * NG * 8 <= 256 ? NKW : 256 / (NG * 8);      // k-blocks of W_hh held in AccVGPRs
+    constexpr int NKD = (NKW + 1) / 2;                                    // k-blocks of an item's state one wave brings
+    constexpr int XJ = (2 * NG + 3) / 4;                                  // x-projection requests per wave and item
+    static_assert(NT >= 4 && NT <= XMAXT && (NT & 1) == 0, "the ring has two slots: an even number of tiles");
+    extern __shared__ __attribute__((aligned(16))) unsigned char xlds[];
+    const int sbytes = p.nkb * 2048;
+    unsigned char* sbuf = xlds;                                                   // [2 ring slots][nkb][2 planes][1024]
+    constexpr int RED_G = 16 * XRP;                                               // words of one (buffer, group, K half, gate)
+    constexpr int RED_BUF = 2 * 2 * NG * RED_G;
+    float* red_all = reinterpret_cast<float*>(xlds + 2 * sbytes);                 // [2 buffers][2 groups][2 K halves][NG][16 clips][XRP]
+    float* xgl = red_all + 2 * RED_BUF;                                           // [2 buffers][2 groups][NG][16 clips][16 units]
+    int* sync = reinterpret_cast<int*>(xgl + 2 * 2 * NG * 256);                   // [0] dead flag (a hand-off wait timed out: stop waiting)
+    unsigned long long* tacc = reinterpret_cast<unsigned long long*>(sync + 32) + (STAMP ? (threadIdx.x >> 6) * 8 : 0);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int v = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mh = v & 1, kh = v >> 1;
+    const int ln = lane & 15, lg = lane >> 4;
+    const int w32 = blockIdx.x, d = blockIdx.y;
+    const int tile0 = p.tile0 + (int)blockIdx.z * p.ntw;
+    const int nt = min(min(p.ntw, p.tile_end - tile0), NT);
+    const int w16 = 2 * w32 + mh;
+    const bool half_ok = w16 < p.nwg16;
+    const int nwg32 = (p.nwg16 + 1) >> 1;
+    constexpr int GU = NG * XU;
+    {   // ring slots (step 0 multiplies nothing, but a phantom k-block is read), reduce buffers (the prologue's cells read zeros)
+        u32x4* z = reinterpret_cast<u32x4*>(xlds);
+        const int n16 = (2 * sbytes + (2 * RED_BUF + 2 * 2 * NG * 256) * 4) / 16;
+        for (int i = tid; i < n16; i += XNT) z[i] = u32x4{0u, 0u, 0u, 0u};
+    }
+    if (tid < 32) sync[tid] = 0;
+    if (STAMP && lane < 8) tacc[lane] = 0;
+
+    // ---- resident operand: this wave's k-blocks [kb0, kb1) of its group's split W_hh, all gates; a wave of the second half may own
+    // one block fewer than NKW: its phantom block is zero and multiplies the wave's last real block of state
+    const int kb0 = kh ? (p.nkb + 1) / 2 : 0, kb1 = kh ? p.nkb : (p.nkb + 1) / 2;
+    f16x8 wv[NKW][NG][2];
+    {
+        const u32x4* wp = reinterpret_cast<const u32x4*>(p.whh[d]) + ((size_t)(half_ok ? w16 : 0) * p.nkb) * (NG * 2 * 64) + lane;
+#pragma unroll
+        for (int i = 0; i < NKW; ++i) {
+            const bool real = half_ok && kb0 + i < kb1;
+            const int kb = min(kb0 + i, p.nkb - 1);
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    u32x4 w = wp[(((size_t)kb * NG + g) * 2 + pl) * 64];
+                    if (!real) w = u32x4{0u, 0u, 0u, 0u};
+                    wv[i][g][pl] = __builtin_bit_cast(f16x8, w);
+                    if (i < NKA) asm volatile("" : "+a"(wv[i][g][pl]));       // into its AccVGPRs as it arrives
+                }
+        }
+    }
+    const unsigned hp_par = (unsigned)((size_t)p.D * p.ntiles * p.nkb * 2048);     // bytes per parity
+    const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.hpack, 0, (int)(2 * hp_par), 0x00020000);
+    float* outd = p.out[d];
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)outd, 0, (int)((size_t)p.T * p.B * p.Hs * 4), 0x00020000);
+    const unsigned lds_sbuf = (unsigned)(size_t)sbuf;
+    const unsigned lane16 = (unsigned)lane * 16u;
+    const unsigned char* sbr = sbuf + lane16 + kb0 * 2048;       // this lane's fragment of its wave's first k-block, ring slot 0
+    const int klast_off = (min(kb0 + NKW - 1, p.nkb - 1) - kb0) * 2048;     // the last (possibly phantom) block's offset from sbr
+
+    // ---- per tile (uniform): chain, counters, row blocks; a phantom tile (J >= nt) is computed like a real one on the LAST real
+    // tile's addresses with every store out of range
+    const int chain0 = d * p.ntiles + tile0;
+    const unsigned hchs = (unsigned)(p.nkb * 2048);                                   // state bytes of a chain
+    const unsigned cnts = (unsigned)p.T * kPersist16CntWords;                          // counter words of a chain
+    const unsigned orows = (unsigned)(XB * p.Hs), xrows = (unsigned)(XB * p.Np);      // elements of a tile inside a step's block
+#define TOK(J) ((J) < nt)
+#define TJ(J) ((unsigned)min((J), nt - 1))
+
+    // ---- cell role: thread -> (clip cj, units u0, u0 + 1 of the wave's group)
+    const int e4 = lane & 3, kg = (lane >> 2) & 1, cj = 8 * kh + (lane >> 3);
+    const int u0 = 8 * kg + 2 * e4;
+    const int cunit = w16 * XU + u0;
+    float bh[NG][2];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        bh[g][0] = half_ok ? p.bhh[d][g * p.H + cunit] : 0.f;
+        bh[g][1] = half_ok ? p.bhh[d][g * p.H + cunit + 1] : 0.f;
+    }
+    const int nb_last = p.B - (tile0 + nt - 1) * XB;                                   // clips of the window's last real tile (may exceed 16)
+    unsigned actbits = 0;                                                              // bit j: this thread's (units, clip) exist in tile j
+    int mylen[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const bool a = half_ok && j < nt && (j < nt - 1 || cj < nb_last);
+        actbits |= (unsigned)a << j;
+        mylen[j] = a ? p.lens[(tile0 + j) * XB + cj] : 0;
+    }
+    constexpr unsigned OOR = 0x80000000u;
+    const unsigned o_by = (unsigned)(cj * p.Hs + (half_ok ? cunit : 0)) * 4u;          // byte offset inside an out row block [16 clips][Hs]
+    const unsigned pub_off = (e4 == 0 && half_ok) ? (unsigned)(w16 >> 1) * 2048u + (unsigned)(2 * (w16 & 1) + kg) * 256u + (unsigned)cj * 16u : OOR;   // hi plane; lo at + 1024
+    const unsigned shard = (unsigned)(w32 & (kPersist16Shards - 1)) * 64u;
+    const unsigned need = (unsigned)((nwg32 + kPersist16Shards - 1 - (lane & (kPersist16Shards - 1))) / kPersist16Shards);
+    // reduce buffers: where this lane's MFMA results go (clip ln, units 4 lg ..), where this thread's cell reads from
+    float* red_w = red_all + ((mh * 2 + kh) * NG) * RED_G + ln * XRP + 4 * lg;
+    const float* red_r = red_all + ((mh * 2) * NG) * RED_G + cj * XRP + u0;
+    const float* xg_r = xgl + (mh * NG) * 256 + cj * 16 + u0;
+    // x-projection requests of this wave: instruction k brings (group xm, gate xg_) = j / NG, j % NG of j = min(v + 4 k, 2 NG - 1):
+    // lane l -> clip l >> 2, units 4 (l & 3) .. + 3
+    unsigned xq_lds[XJ], xq_col[XJ];
+#pragma unroll
+    for (int k = 0; k < XJ; ++k) {
+        const int j = min(v + 4 * k, 2 * NG - 1), xm = j / NG, xgate = j % NG;
+        xq_lds[k] = (unsigned)(size_t)xgl + (unsigned)((xm * NG + xgate) * 1024);
+        xq_col[k] = (unsigned)((d * p.nwg16 + min(2 * w32 + xm, p.nwg16 - 1)) * GU + xgate * XU) * 4u;
+    }
+    const unsigned xl_by = ((unsigned)(lane >> 2) * p.Np + 4u * (lane & 3)) * 4u;
+    const unsigned xl_by_last = ((unsigned)min(lane >> 2, nb_last - 1) * p.Np + 4u * (lane & 3)) * 4u;
+    // state DMA: this wave brings k-blocks dk0 .. dk0 + NKD - 1 of the item (clamped into the chain: what lies beyond the wave's
+    // share is brought twice, to the same place)
+    const int dk0 = (v * p.nkb) / 4;
+    unsigned pollv = 0;             // wave 0: the counter shard this lane read at the start of the phase
+
+    float hprev[NT][2], cprev[NT][2];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) { hprev[j][0] = hprev[j][1] = 0.f; cprev[j][0] = cprev[j][1] = 0.f; }
+
+    unsigned long long tm0 = 0, tm1 = 0;
+#define XT_BEGIN() do { if (STAMP) { __builtin_amdgcn_sched_barrier(0); tm0 = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#define XT_MARK(k) do { if (STAMP) { __builtin_amdgcn_sched_barrier(0); tm1 = __builtin_amdgcn_s_memrealtime(); if ((threadIdx.x & 63) == 0) tacc[k] += tm1 - tm0; tm0 = tm1; __builtin_amdgcn_sched_barrier(0); } } while (0)
+
+    const size_t xstride = (size_t)p.B * p.Np;
+    const unsigned ostride_by = (unsigned)((size_t)p.B * p.Hs * 4);
+
+    // One phase.  J: tile of the MFMA item (s, J).  DO_M: multiply (false: step 0, whose state is zero, and the epilogue).  DO_C: the cell
+    // of the previous item, (s, J - 1) or (s - 1, NT - 1).  DUTY: signal / poll / requests for the neighbouring items.
+    auto phase = [&](auto jc, auto domc, auto docc, auto dutyc, int s) {
+        constexpr int J = decltype(jc)::value;
+        constexpr bool DO_M = decltype(domc)::value, DO_C = decltype(docc)::value, DUTY = decltype(dutyc)::value;
+        constexpr int JP = (J + NT - 1) % NT, JN = (J + 1) % NT, JQ = (J + 2) % NT;
+        const bool more = s + 1 < p.T;
+        const int t = d == 0 ? s : p.T - 1 - s;
+        const unsigned parw = (unsigned)(s & 1) * hp_par;            // parity offset step s's cells write h_s at
+        const unsigned parr = hp_par - parw;                          // ... and its MFMAs read h_(s-1) from
+        XT_BEGIN();
+        if (DUTY) {
+            // item q - 2, whose stores every wave drained before the barrier that opened this phase: (s, J - 2), or (s - 1, J + NT - 2)
+            const int ss = J >= 2 ? s : s - 1;
+            constexpr int JS = (J + NT - 2) % NT;
+            if (v == 0 && ss >= 0 && TOK(JS)) {
+                const bool drop = d == 0 && tile0 + JS == 0 && w32 == p.drop_wg && ss == p.drop_step;
+                if (lane == 0 && !drop)
+                    __hip_atomic_fetch_add(p.cnt + ((unsigned)(chain0 + JS) * cnts + (unsigned)ss * kPersist16CntWords + shard), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // item q + 2 = (s, J + 2) needs its chain's step s - 1 [s >= 1]; or (s + 1, J + 2 - NT): its chain's step s [more]
+            const bool pon = J + 2 < NT ? s >= 1 : more;
+            const int psp = J + 2 < NT ? s - 1 : s;
+            if (pon && TOK(JQ) && v == 0 && lane < kPersist16Shards)
+                pollv = __hip_atomic_load(p.cnt + ((unsigned)(chain0 + JQ) * cnts + (unsigned)psp * kPersist16CntWords + lane * 64), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ================= the body: one basic block
+        if (DUTY && !(SKIP & 8)) {
+            // x-projection of item q = (s, J), read by its cell in the next phase: into buffer J & 1
+            const float* xrow = p.xp + (size_t)t * xstride + (size_t)((unsigned)tile0 + TJ(J)) * xrows;
+            const unsigned by = J >= nt - 1 ? xl_by_last : xl_by;
+#pragma unroll
+            for (int k = 0; k < XJ; ++k) {
+                const unsigned ldst = xq_lds[k] + (unsigned)((J & 1) * 2 * NG * 1024);
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(ldst), "v"(by + xq_col[k]), "s"(xrow) : "memory");
+            }
+        }
+        // ---- the cell's operands: K-split partial sums of both halves, x-projection, all gates; two adjacent units of one clip
+        f32x2 rv[NG][2], xg[NG];
+        if (DO_C) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                rv[g][0] = *reinterpret_cast<const f32x2*>(red_r + (JP & 1) * RED_BUF + g * RED_G);
+                rv[g][1] = *reinterpret_cast<const f32x2*>(red_r + (JP & 1) * RED_BUF + (NG + g) * RED_G);
+                xg[g] = *reinterpret_cast<const f32x2*>(xg_r + (JP & 1) * (2 * NG * 256) + g * 256);
+            }
+        }
+        // ---- MFMAs of item (s, J), B operands from ring slot J & 1; between them the state requests of item q + 1 and the cell
+        f32x4 acc[NG], acl[NG];        // hi.hi ; (hi.lo + lo.hi) * 2^11
+#pragma unroll
+        for (int g = 0; g < NG; ++g) { acc[g] = f32x4{0.f, 0.f, 0.f, 0.f}; acl[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        const unsigned char* sb = sbr + (J & 1) * sbytes;
+        f16x8 bc[2], bn[2];
+        if (DO_M) {
+            bc[0] = *reinterpret_cast<const f16x8*>(sb + (NKW > 1 ? 0 : klast_off));
+            bc[1] = *reinterpret_cast<const f16x8*>(sb + (NKW > 1 ? 0 : klast_off) + 1024);
+        }
+        // item q + 1 = (s, J + 1) reads h_(s-1), or (s + 1, 0) reads h_s; (past the layer's end: a request nobody reads)
+        const bool dma_on = DUTY && (DO_M || J == NT - 1) && !(SKIP & 1);
+        const unsigned dpar = J + 1 < NT ? parr : parw;
+        const unsigned char* dsrc = reinterpret_cast<const unsigned char*>(p.hpack) + (dpar + ((unsigned)chain0 + TJ(JN)) * hchs);
+        const unsigned dlds = lds_sbuf + (unsigned)((JN & 1) * sbytes);
+        const unsigned l16 = lane16;           // (local copies: an asm operand inside a generic lambda does not capture by itself)
+        const int dk0_ = dk0, nkb_ = p.nkb;
+        auto dma_block = [&](int i) {          // k-block dk0 + i of the item, both planes
+            const unsigned kb = (unsigned)min(dk0_ + i, nkb_ - 1) * 2048u;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024 sc1"
+                         :: "s"(dlds + kb), "v"(l16), "s"(dsrc + kb) : "memory");
+        };
+        // the cell, cut into pieces that are placed between the k-blocks' MFMAs
+        f32x2 hg[NG];
+        float hn[2] = {0.f, 0.f};
+        unsigned pk[2] = {0u, 0u};
+        u32x4 phi = {0u, 0u, 0u, 0u}, plo = {0u, 0u, 0u, 0u};
+        constexpr int CT = DO_C ? (J >= 1 ? 0 : 1) : 0;     // the cell's item lies a step back when J == 0
+        const int tc = CT ? (d == 0 ? t - 1 : t + 1) : t;
+        const unsigned osoff_c = (unsigned)tc * ostride_by;
+        const unsigned parw_c = CT ? parr : parw;
+        const bool act = (actbits >> JP) & 1u;
+        auto cell_piece = [&](int piece) {
+            if (!DO_C || (SKIP & 32)) return;
+            if (piece == 0) {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) { hg[g][0] = rv[g][0][0] + rv[g][1][0] + bh[g][0]; hg[g][1] = rv[g][0][1] + rv[g][1][1] + bh[g][1]; }
+            } else if (piece == 1 || piece == 2) {
+                const int u = piece - 1;
+                float xgu[NG], hgu[NG];
+#pragma unroll
+                for (int g = 0; g < NG; ++g) { xgu[g] = xg[g][u]; hgu[g] = hg[g][u]; }
+                float c = cprev[JP][u];
+                float h = rnn_cell<KIND, true>(xgu, hgu, hprev[JP][u], c, tc < mylen[JP]);
+                h = act ? h : 0.f;
+                hn[u] = h; hprev[JP][u] = h;
+                if (KIND == DSMI_RNN_LSTM) cprev[JP][u] = c;
+                const _Float16 h1 = (_Float16)h;
+                const _Float16 h2 = (_Float16)((h - (float)h1) * kLoScale);
+                pk[u] = (unsigned)__builtin_bit_cast(unsigned short, h1) | ((unsigned)__builtin_bit_cast(unsigned short, h2) << 16);
+            } else if (piece == 3) {
+                unsigned u[8];
+                u[0] = pk[0]; u[1] = pk[1];
+                u[2] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pk[0], 0x101, 0xF, 0xF, false);      // row_shl:n: lane i receives lane i + n's word
+                u[3] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pk[1], 0x101, 0xF, 0xF, false);
+                u[4] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pk[0], 0x102, 0xF, 0xF, false);
+                u[5] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pk[1], 0x102, 0xF, 0xF, false);
+                u[6] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pk[0], 0x103, 0xF, 0xF, false);
+                u[7] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pk[1], 0x103, 0xF, 0xF, false);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    phi[m] = __builtin_amdgcn_perm(u[2 * m + 1], u[2 * m], 0x05040100u);     // low halves: units 2m, 2m + 1 of the hi plane
+                    plo[m] = __builtin_amdgcn_perm(u[2 * m + 1], u[2 * m], 0x07060302u);     // high halves: the lo plane
+                }
+            } else if (piece == 4 && !(SKIP & 16)) {
+                const unsigned hoff = parw_c + ((unsigned)chain0 + TJ(JP)) * hchs;
+                __builtin_amdgcn_raw_buffer_store_b128(phi, hrs, TOK(JP) ? pub_off : OOR, hoff, 16);
+                __builtin_amdgcn_raw_buffer_store_b128(plo, hrs, TOK(JP) ? pub_off + 1024u : OOR, hoff, 16);
+                u32x2 ov = {__builtin_bit_cast(unsigned, hn[0]), __builtin_bit_cast(unsigned, hn[1])};
+                __builtin_amdgcn_raw_buffer_store_b64(ov, ors, act ? o_by : OOR, osoff_c + ((unsigned)tile0 + TJ(JP)) * orows * 4u, 0);
+            }
+        };
+        // placement: piece k of the cell behind k-block CP[k]'s MFMAs, DMA block i behind k-block i (the texture path takes a
+        // 1-KiB piece per ~80 cycles: one block per k-block's 9 x 16 cycles)
+        constexpr int NP = 5;
+        if (!DO_M) {
+            if (dma_on) {
+#pragma unroll
+                for (int i = 0; i < NKD; ++i) dma_block(i);
+            }
+#pragma unroll
+            for (int k = 0; k < NP; ++k) cell_piece(k);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NKW; ++i) {
+                if (i + 1 < NKW) {
+                    const int off = i + 1 < NKW - 1 ? (i + 1) * 2048 : klast_off;
+                    bn[0] = *reinterpret_cast<const f16x8*>(sb + off);
+                    bn[1] = *reinterpret_cast<const f16x8*>(sb + off + 1024);
+                }
+                if (dma_on && i < NKD) dma_block(i);
+                if (!(SKIP & 2)) {
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) acl[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[i][g][1], bc[0], acl[g], 0, 0, 0);
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[i][g][0], bc[0], acc[g], 0, 0, 0);
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) acl[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[i][g][0], bc[1], acl[g], 0, 0, 0);
+                }
+                // the cell's pieces spread over the k-blocks (NKW >= NP: one piece per block from the first; fewer blocks: the rest behind the last)
+                if (i < NP) cell_piece(i);
+                if (i == NKW - 1) {
+#pragma unroll
+                    for (int k = NKW; k < NP; ++k) cell_piece(k);
+                }
+                bc[0] = bn[0]; bc[1] = bn[1];
+            }
+            // partial tiles -> reduce buffer J & 1
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                f32x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = acc[g][r] + acl[g][r] * kLoInv;
+                *reinterpret_cast<f32x4*>(red_w + (J & 1) * RED_BUF + g * RED_G) = o;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ================= end of the body
+        XT_MARK(0);
+        // everything this wave requested: publish stores (drained), state DMA (landed), x-projection (arrived)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0x0F70);      // the same wait where the compiler sees it: nothing of this wave's is in flight
+        XT_MARK(1);
+        if (DUTY) {
+            const bool pon = J + 2 < NT ? s >= 1 : more;
+            const int psp = J + 2 < NT ? s - 1 : s;
+            if (pon && TOK(JQ) && v == 0 && !sync[0] && !(SKIP & 4)) {
+                const unsigned* cp = p.cnt + ((unsigned)(chain0 + JQ) * cnts + (unsigned)psp * kPersist16CntWords + (lane & (kPersist16Shards - 1)) * 64);
+                unsigned spins = 0;
+                unsigned got = lane < kPersist16Shards ? pollv : need;
+                while (__builtin_amdgcn_ballot_w64(got < need) != 0) {
+                    __builtin_amdgcn_s_sleep(1);
+                    ++spins;
+                    if ((spins & 1023u) == 0 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { sync[0] = 1; break; }
+                    if (spins > p.spin_limit) { atomicExch(p.err, 1u); sync[0] = 1; break; }
+                    got = lane < kPersist16Shards ? __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need;
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+        }
+        XT_MARK(2);
+        ring4_barrier();
+        XT_MARK(3);
+        if (STAMP && lane == 0) tacc[7] += 1;
+    };
+
+    // the prologue's loads (W_hh, biases, lengths) have arrived and the zeroed LDS is visible
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ring4_barrier();
+
+    using std::integral_constant;
+    constexpr std::true_type Y; constexpr std::false_type N;
+    auto for_tiles = [&](auto f) {
+        f(integral_constant<int, 0>{}); f(integral_constant<int, 1>{}); f(integral_constant<int, 2>{}); f(integral_constant<int, 3>{});
+        if constexpr (NT > 4) { f(integral_constant<int, 4>{}); f(integral_constant<int, 5>{}); }
+        if constexpr (NT > 6) { f(integral_constant<int, 6>{}); f(integral_constant<int, 7>{}); }
+    };
+    // step 0: h = 0 -- no state, no MFMAs; the cells of its items read the zeroed reduce buffers
+    for_tiles([&](auto jc) {
+        constexpr int J = decltype(jc)::value;
+        if constexpr (J == 0) phase(jc, N, N, Y, 0); else phase(jc, N, Y, Y, 0);
+    });
+    for (int s = 1; s < p.T; ++s) {
+        // W_hh's first NKA k-blocks live in AccVGPRs: the MFMAs take them from there
+#pragma unroll
+        for (int i = 0; i < NKA; ++i)
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) asm volatile("" : "+a"(wv[i][g][pl]));
+        for_tiles([&](auto jc) { phase(jc, Y, Y, Y, s); });
+    }
+    // the cell of the last item, (T - 1, NT - 1)
+    phase(integral_constant<int, 0>{}, N, Y, N, p.T);
+#undef TOK
+#undef TJ
+#undef XT_BEGIN
+#undef XT_MARK
+    if (STAMP && lane == 0) {
+        unsigned long long* o = p.dbg + ((size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + v) * 8;
+        for (int k = 0; k < 8; ++k) o[k] = tacc[k];
+    }
+}
+
+size_t ring4_lds_bytes(int kind, int nkb) {
+    const int NG = kind == DSMI_RNN_GRU ? 3 : (kind == DSMI_RNN_LSTM ? 4 : 1);
+    return (size_t)2 * nkb * 2048 + (size_t)2 * 2 * 2 * NG * 16 * XRP * 4 + (size_t)2 * 2 * NG * 256 * 4 + 32 * 4 + 4 * 8 * 8;
+}
+
+template <int KIND, int NT>
+bool launch_ring4_nt(const Ring4Args& a, hipStream_t s, const EvPair& ev) {
+    const int nkw = ceil_div(a.nkb, 2);
+    const size_t lds = ring4_lds_bytes(KIND, a.nkb);
+    const dim3 grid((a.nwg16 + 1) / 2, a.D, ceil_div(a.tile_end - a.tile0, a.ntw)), block(XNT);
+#define LAUNCH_X(NK, ST)                                                                                              \
+    do {                                                                                                             \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rnn_persist_ring4_kernel<KIND, NK, NT, ST>),         \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
+        DSMI_LAUNCH((rnn_persist_ring4_kernel<KIND, NK, NT, ST>), grid, block, lds, s, ev, a);                        \
+    } while (0)
+    if (a.dbg) {
+        if constexpr (KIND == DSMI_RNN_GRU && NT == 4) { if (nkw == 13) { LAUNCH_X(13, true); return true; } }
+        return false;
+    }
+    static const int skip = std::getenv("DSMI_DEBUG_RING_SKIP") ? std::atoi(std::getenv("DSMI_DEBUG_RING_SKIP")) : 0;
+    if (skip) {           // timing experiments: cfgA's shape only, a fixed list of masks
+        if constexpr (KIND == DSMI_RNN_GRU && NT == 4) {
+            if (nkw != 13) return false;
+#define LAUNCH_SK(M)                                                                                                             \
+    case M:                                                                                                                      \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rnn_persist_ring4_kernel<KIND, 13, NT, false, M>),               \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                         \
+        DSMI_LAUNCH((rnn_persist_ring4_kernel<KIND, 13, NT, false, M>), grid, block, lds, s, ev, a);                             \
+        return true;
+            switch (skip) {
+                LAUNCH_SK(1) LAUNCH_SK(2) LAUNCH_SK(4) LAUNCH_SK(8) LAUNCH_SK(16) LAUNCH_SK(32) LAUNCH_SK(9) LAUNCH_SK(13) LAUNCH_SK(29) LAUNCH_SK(31) LAUNCH_SK(61) LAUNCH_SK(63)
+                default: return false;
+            }
+#undef LAUNCH_SK
+        }
+        return false;
+    }
+    switch (nkw) {
+        case 1: LAUNCH_X(1, false); break;
+        case 2: LAUNCH_X(2, false); break;
+        case 3: LAUNCH_X(3, false); break;
+        case 4: LAUNCH_X(4, false); break;
+        case 5: LAUNCH_X(5, false); break;
+        case 6: LAUNCH_X(6, false); break;
+        case 7: LAUNCH_X(7, false); break;
+        case 8: LAUNCH_X(8, false); break;
+        default:
+            if constexpr (KIND == DSMI_RNN_LSTM) return false;
+            else {
+                if (nkw == 9) LAUNCH_X(9, false);
+                else if (nkw == 10) LAUNCH_X(10, false);
+                else if (nkw == 11) LAUNCH_X(11, false);
+                else if (nkw == 12) LAUNCH_X(12, false);
+                else if (nkw == 13) LAUNCH_X(13, false);
+                else if (nkw == 14) LAUNCH_X(14, false);
+                else return false;
+            }
+    }
+#undef LAUNCH_X
+    return true;
+}
+
+}  // namespace
+
+size_t rnn_persist_ring4_lds(int kind, int nkb) { return ring4_lds_bytes(kind, nkb); }
+
+// Tiles one launch of the kernel can walk for this shape on `n_cus` CUs (0: not this shape): the 16-unit geometry, W_hh of a
+// group's K half in one wave's registers (GRU / RNN: H <= 896, LSTM: H <= 512), ring + reduce buffers within the CU's LDS,
+// both directions co-resident.
+int rnn_persist_ring4_tiles(const RnnGeom& g16, int B, int n_cus) {
+    if (g16.U != XU || (g16.H % XU) != 0) return 0;
+    const int nkb = ceil_div(g16.H, 32);
+    const int nkw = ceil_div(nkb, 2);
+    if (nkw > (g16.kind == DSMI_RNN_LSTM ? 8 : 14)) return 0;
+    if (ring4_lds_bytes(g16.kind, nkb) > 160 * 1024) return 0;
+    if (((g16.nwg + 1) / 2) * g16.D > n_cus) return 0;
+    if ((size_t)g16.D * ceil_div(B, XB) * nkb * 2048 * 2 >= (1ull << 31)) return 0;      // packed state below 2 GiB (store offsets, see OOR)
+    return std::min(ceil_div(B, XB), 4);
+}
+
+bool launch_rnn_persist_ring4(const RnnPersist16Launch& p, hipStream_t s) {
+    Ring4Args a;
+    for (int d = 0; d < 2; ++d) { a.whh[d] = p.whh16[d]; a.bhh[d] = p.bhh[d]; a.out[d] = p.out[d]; }
+    a.xp = p.xp; a.lens = p.lens_dev; a.hpack = p.hpack16; a.cnt = p.counters; a.err = p.err;
+    a.B = p.B; a.T = p.T; a.H = p.g.H; a.Hs = p.g.Kp; a.Np = p.g.Np; a.nwg16 = p.g.nwg; a.nkb = ceil_div(p.g.H, 32);
+    a.ntiles = ceil_div(p.B, XB); a.D = p.g.D;
+    a.tile0 = p.tile0; a.ntw = p.ntw > 0 ? p.ntw : a.ntiles - p.tile0;
+    a.tile_end = std::min(a.ntiles, a.tile0 + a.ntw * std::max(p.nwin, 1));
+    if (a.ntw < 1 || a.ntw > 4 || a.tile_end <= a.tile0) return false;
+    if ((size_t)p.T * p.B * p.g.Kp * 4 >= (1ull << 31)) return false;          // a direction's output rows below 2 GiB (store offsets, see OOR)
+    a.spin_limit = p.spin_limit; a.drop_wg = p.drop_wg; a.drop_step = p.drop_step; a.dbg = p.dbg;
+    switch (p.g.kind) {
+        case DSMI_RNN_GRU: return launch_ring4_nt<DSMI_RNN_GRU, 4>(a, s, p.ev);
+        case DSMI_RNN_LSTM: return launch_ring4_nt<DSMI_RNN_LSTM, 4>(a, s, p.ev);
+        default: return launch_ring4_nt<DSMI_RNN_TANH, 4>(a, s, p.ev);
+    }
+}
+
+}  // namespace dsmi

@@ -118,6 +118,36 @@ def test_forwards_in_flight_follow_the_first_forward():
     assert len(rec2.danspeech_recognizer._replicas) == 2
 
 
+def test_sequential_mode_reads_a_batch_only_after_the_previous_result():
+    """``lanes=1, merge_clips=0`` is what the docstring promises a feedback-driven source: batch k + 1 is asked for only after
+    result k has been yielded, on the caller's own thread (the reference's ``recognize()`` is synchronous,
+    danspeech/Recognizer.py:82-95).  Both decoders: a beam search has one more job in flight in the pipelined modes."""
+    import threading
+    from danspeech_amd import Recognizer
+    from danspeech_amd.deepspeech.decoder import BeamCTCDecoder
+    model, sd, cfg = _model("small", 64, 3, seed=12)
+    rec = Recognizer(model=model)
+    eng = rec.danspeech_recognizer
+    clips = [syn.make_clip(i, n) for i, n in enumerate([9000, 8000, 7000])]
+    want = rec.recognize_batch(clips)
+    caller = threading.get_ident()
+    for searching in (False, True):
+        if searching:
+            eng.decoder = BeamCTCDecoder(labels=eng.labels, beam_width=8, blank_index=0)
+            want = rec.recognize_batch(clips)
+        seen = []
+
+        def source():
+            for k in range(5):
+                assert len(seen) == k, (k, len(seen))          # result k - 1 is out before batch k is asked for
+                assert threading.get_ident() == caller
+                yield clips if k != 2 else clips[:1]
+
+        for out in eng.transcribe_batches(source(), lanes=1, merge_clips=0):
+            seen.append(out)
+        assert seen == [want, want, want[:1], want, want]
+
+
 def test_wide_model_stream_of_batches_runs_clean():
     """Config 4's width (H = 1200: the tile-walking recurrent kernel, four tiles per workgroup) as a stream of 64-clip batches, with the
     forwards in flight the engine picks and with four: every batch equals the single call, and no hand-off of any handle timed out

@@ -90,6 +90,80 @@ def test_ring_kernel_equals_oracle_and_the_older_kernels(native, kind, H, B, inf
         np.testing.assert_allclose(ring[b, :ol_ref[b]], old[b, :ol_ref[b]], rtol=0, atol=5e-5)
 
 
+# The reference's unidirectional models (model.py:399-407: ``bidirectional=False`` + ``Lookahead(context)``): one direction, grid.y = 1,
+# chains d * ntiles + tile with d = 0 only, half as many CUs per window.
+UNI_CASES = [("gru", 800, 64, 2), ("lstm", 256, 40, 2), ("gru", 320, 100, 1), ("rnn", 96, 33, 2)]
+
+
+@pytest.mark.parametrize("kind,H,B,inflight", UNI_CASES)
+def test_ring_kernel_unidirectional_with_lookahead(native, kind, H, B, inflight):
+    from oracle import torch_port as tp
+    cfg = dict(conv_layers=2, rnn_type=kind, rnn_hidden_size=H, rnn_layers=2, bidirectional=False, context=20)
+    sd = syn.make_state_dict(2, kind, H, 2, bidirectional=False, context=20, seed=91, **syn.TALKATIVE)
+    x, lens = _batch(B=B, T=181, seed=92)
+    ref, ol_ref = tp.forward(sd, cfg, x, lens)
+    m = native.NativeModel(cfg, sd)
+    m.set_inflight(inflight)
+    m.set_profiling(2)
+    p, ol = m.forward(_dev(x), lens)
+    assert np.array_equal(ol, ol_ref) and m.recompute_count() == 0
+    assert m.kernel_stats()["rnn_layer_persistent"]["launches"] >= 2
+    pn = p.cpu().numpy()
+    m.close()
+    for b in range(B):
+        np.testing.assert_allclose(pn[b, :ol_ref[b]], ref[b, :ol_ref[b]], rtol=0, atol=1e-4)
+
+
+def test_unidirectional_model_through_the_pipeline(native):
+    """``transcribe_batches`` on a unidirectional model: merged forwards on several handles, equal to the lone calls."""
+    from danspeech_amd import Recognizer
+    from danspeech_amd.deepspeech.model import DeepSpeech
+    sd = syn.make_state_dict(2, "gru", 320, 3, bidirectional=False, context=20, seed=93, **syn.TALKATIVE)
+    model = DeepSpeech("uni", rnn_type="gru", rnn_hidden_size=320, rnn_layers=3, conv_layers=2, bidirectional=False, context=20).load_state_dict(sd)
+    rec = Recognizer(model=model)
+    eng = rec.danspeech_recognizer
+    batches = [[syn.make_clip(10 * k + i, 24000 + 900 * ((i + k) % 9)) for i in range(20)] for k in range(6)]
+    lone = [rec.recognize_batch(b) for b in batches]
+    assert list(rec.recognize_batches(batches)) == lone
+    handles = [eng.model._native] + [r[0]._native for r in eng._replicas]
+    assert len(handles) == 4 and [h.recompute_count() for h in handles] == [0, 0, 0, 0]
+    assert any(len(t) > 5 for t in lone[0])
+
+
+def test_two_models_of_different_widths_share_the_ring_slots(native):
+    """Ring slots are counted per model (n_cus / CUs of its window) but index one set of events per device: H = 800 (50 CUs a
+    window, five slots) beside H = 896 (56 CUs, four slots) must never be admitted beyond the device's 256 CUs -- windows that are
+    not all resident spin to their timeout and are recomputed.  Nine handles in flight, none recomputed, results right."""
+    from oracle import torch_port as tp
+    specs = [(800, 5), (896, 4)]
+    models, refs, xs, batches = [], [], [], []
+    for H, count in specs:
+        cfg = _cfg(H, 2)
+        sd = syn.make_state_dict(2, "gru", H, 2, seed=95 + H, **syn.TALKATIVE)
+        x, lens = _batch(B=64, T=161, seed=96 + H)
+        ref = tp.forward(sd, cfg, x, lens)[0]
+        for _ in range(count):
+            m = native.NativeModel(cfg, sd)
+            m.set_inflight(4)
+            models.append(m); refs.append(ref); xs.append(_dev(x)); batches.append(lens)
+    streams = [torch.cuda.Stream() for _ in models]
+    torch.cuda.synchronize()
+    for rep in range(3):
+        outs = []
+        for k, m in enumerate(models):
+            with torch.cuda.stream(streams[k]):
+                outs.append(m.forward(xs[k], batches[k], check=False))
+        for k, m in enumerate(models):
+            assert m.status() is False
+            p, ol = outs[k]
+            pn = p.cpu().numpy()
+            for b in range(0, pn.shape[0], 7):
+                np.testing.assert_allclose(pn[b, :ol[b]], refs[k][b, :ol[b]], rtol=0, atol=1e-4)
+    for m in models:
+        assert m.recompute_count() == 0
+        m.close()
+
+
 def test_ring_kernel_is_what_runs(native):
     """Two batches in flight, cfgA's width: one launch per layer on H / 32 x 2 = 50 workgroups."""
     cfg = _cfg(800, 2)

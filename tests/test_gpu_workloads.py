@@ -93,8 +93,10 @@ def _check_greedy(native, probs, out_lens, p_ref, ol_ref, err, min_tokens):
 
 @pytest.mark.parametrize("inflight", [2, 1])
 def test_config2_cfgA_batch32_ragged_greedy(native, inflight):
-    """The benchmarked geometry itself: with two batches in flight (the benchmark's default) the paired-tile kernel on 100 CUs,
-    with one the whole-CU kernel on 200."""
+    """One 32-clip batch of the benchmarked model through ``NativeModel.forward``: with batches in flight (inflight 2) the ring
+    kernel, one window of two real tiles on 50 CUs; a lone batch (inflight 1) the whole-device kernel on 200.  The geometry
+    bench.py times -- 64-clip merged forwards on four lanes through ``Recognizer.recognize_batches`` -- is
+    ``test_timed_path_recognize_batches_full_size`` below."""
     from oracle import torch_port as tp
     cfg = _cfg(800, 5)
     sd = syn.make_state_dict(2, "gru", 800, 5, seed=0, **syn.TALKATIVE)
@@ -114,6 +116,87 @@ def test_config2_cfgA_batch32_ragged_greedy(native, inflight):
     lens = _check_greedy(native, probs, out_lens, p_ref, ol_ref, err, min_tokens=30)
     print("config 2 transcript lengths: min %d max %d" % (min(lens), max(lens)))
     m.close(); fe.close()
+
+
+def _timed_path_batches(n_batches=8, B=32):
+    """What bench.py hands to ``recognize_batches``: batches of 32 float64 host arrays, here ragged 4..10 s and in shuffled order."""
+    batches = []
+    for k in range(n_batches):
+        clips = _ragged_clips(B, 64000, 160000, seed=20 + k)
+        order = np.random.default_rng(40 + k).permutation(B)
+        batches.append([clips[i] for i in order])
+    return batches
+
+
+def test_timed_path_recognize_batches_full_size(native):
+    """The path bench.py times, at its size: ``Recognizer.recognize_batches`` (reference danspeech/Recognizer.py:82-95 and
+    DanSpeechRecognizer.py:218-231, batched) over 8 batches x 32 ragged 4..10 s clips of cfgA as float64 host arrays with the
+    default pipeline -- consecutive batches merged into 64-clip forwards, four forwards in flight on four model handles, the ring
+    recurrent kernel's four-tile windows.  All 256 transcripts equal the oracle's (oracle/torch_port.py + oracle/decoder.py), no
+    handle recomputed a batch, four handles exist, and every forward carried 64 clips (5 recurrent launches per forward)."""
+    from danspeech_amd import Recognizer
+    from danspeech_amd.deepspeech.model import DeepSpeech
+    from oracle import torch_port as tp, decoder as od
+    cfg = _cfg(800, 5)
+    sd = syn.make_state_dict(2, "gru", 800, 5, seed=0, **syn.TALKATIVE)
+    model = DeepSpeech("cfgA", rnn_type="gru", rnn_hidden_size=800, rnn_layers=5, conv_layers=2).load_state_dict(sd)
+    rec = Recognizer(model=model)
+    eng = rec.danspeech_recognizer
+    batches = _timed_path_batches()
+    list(rec.recognize_batches(batches[:4]))                     # the replicas exist after a first pass: sample the second
+    handles = [eng.model._native] + [r[0]._native for r in eng._replicas]
+    assert len(handles) == 4
+    for h in handles:
+        h.set_profiling(2)
+        h.reset_kernel_stats()
+    got = list(rec.recognize_batches(batches))
+    launches = sum(h.kernel_stats()["rnn_layer_persistent"]["launches"] for h in handles)
+    assert launches == 5 * 4, launches                           # 8 batches = 4 forwards of 64 clips x 5 layers, one window each
+    assert [h.recompute_count() for h in handles] == [0, 0, 0, 0]
+    assert eng.pipeline_lanes == 4 and eng.pipeline_merge_clips == 64
+    same = total = 0
+    for k, clips in enumerate(batches):
+        order = np.argsort([-len(c) for c in clips], kind="stable")
+        x, fr = tp.spectrogram_batch([clips[i] for i in order])
+        p_ref, ol_ref = tp.forward(sd, cfg, x, fr)
+        s_ref, _ = od.greedy_decode(p_ref, ol_ref, LABELS, 0)
+        for pos, i in enumerate(order):
+            total += 1
+            same += int(got[k][i] == s_ref[pos][0])
+            if got[k][i] != s_ref[pos][0]:
+                print("batch %d clip %d differs:\n  got  %r\n  want %r" % (k, i, got[k][i], s_ref[pos][0]))
+    print("timed path: %d/%d transcripts identical to the oracle's" % (same, total))
+    assert same == total == 256
+    assert min(len(t) for b in got for t in b) >= 30
+
+
+def test_timed_path_beam64_3gram_jobs_in_flight(native, tmp_path):
+    """Config 3 through the same pipeline: beam 64 + 3-gram, five jobs in flight (four forwards and the oldest one's search).  Every
+    clip's best beam equals the lone ``recognize_batch`` call's; for the first batch the search itself is held to oracle/beam.py on
+    the GPU's probabilities (top beams, timesteps, scores) and the pipeline returns those strings."""
+    from danspeech_amd import Recognizer
+    from danspeech_amd.deepspeech.model import DeepSpeech
+    from danspeech_amd.language_models import CustomLanguageModel
+    cfg = _cfg(800, 5)
+    sd = syn.make_state_dict(2, "gru", 800, 5, seed=0, **syn.TALKATIVE)
+    lm = str(tmp_path / "syn3.arpa")
+    syn.make_arpa(lm, order=3, n_words=5000, seed=11, ngrams_per_order=20000)
+    model = DeepSpeech("cfgA", rnn_type="gru", rnn_hidden_size=800, rnn_layers=5, conv_layers=2).load_state_dict(sd)
+    rec = Recognizer(model=model, lm=CustomLanguageModel(lm), alpha=1.3, beta=0.2, beam_width=64)
+    eng = rec.danspeech_recognizer
+    batches = _timed_path_batches(6)
+    got = list(rec.recognize_batches(batches))
+    handles = [eng.model._native] + [r[0]._native for r in eng._replicas]
+    assert len(handles) == 4 and [h.recompute_count() for h in handles] == [0, 0, 0, 0]
+    for k in (0, 3, 5):
+        assert got[k] == rec.recognize_batch(batches[k]), k
+    clips = batches[0]
+    order = np.argsort([-len(c) for c in clips], kind="stable")
+    feats, frames = eng.audio_parser.parse_batch([clips[i] for i in order])
+    probs, out_lens = eng.model(feats, torch.from_numpy(frames.astype(np.int32)))
+    tok, ln, sc = _compare_beams(native, probs, out_lens.numpy(), lm, 1.3, 0.2, 64, range(0, 32, 4), n_check=5)
+    for pos, i in enumerate(order):
+        assert got[0][i] == "".join(LABELS[c] for c in tok[pos, 0, :ln[pos, 0]]), (pos, i)
 
 
 def _score_tol(ref):

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""Diagnostics: where the ring kernel (rnn_persist_ring.hip, two-slot form) spends its slots.  ring_stamps.py [B]
-Per wave, per item (two slots): M work (MFMAs + partial tiles), M-end waits (vmcnt(0) + B's poll), C work (cell + requests), the
-barrier behind each, B wave 0's poll spin; in a diagnostics build whose stamps live in LDS."""
+"""Diagnostics: where the ring kernel spends its phases.  ring_stamps.py [B]
+The four-wave form (rnn_persist_ring4.hip; default): per wave and item (one phase): phase work (requests, MFMAs with the cell
+between them, partial tiles), the wait for the wave's requests (publish stores drained, state DMA landed, x-projection arrived),
+wave 0's poll spin, the barrier.  DSMI_RNN_KERNEL=ring8: the eight-wave form (two slots per item: M work, M-end waits, C work, the
+barrier behind each, B wave 0's poll spin).  A diagnostics build whose stamps live in LDS."""
 import os, sys
 import numpy as np
 os.environ["DSMI_STAMP_RING"] = "1"
@@ -15,14 +17,25 @@ m = _native.NativeModel(cfg, syn.make_state_dict(2, "gru", H, 2, seed=0))
 buf = np.zeros((256, 8, 16), dtype=np.uint64)
 n = _native.lib().dsmi_debug_persist_stamps(m._h, 1, B, T, buf.ctypes.data_as(C.c_void_p), buf.size)
 assert n > 0, n
-raw = buf[:n].astype(np.float64)
 items = T * 4
-names = ["M work", "M-end waits", "C work", "barrier after M", "barrier after C", "poll spin"]
-print("B %d: %d workgroups, %d items per half; us per item (median over workgroups)" % (B, n, items))
-for half in (0, 1):
-    for wv in (0, 1, 3):
-        c = raw[:, 4 * half + wv, :]
-        us = c[:, :6] * 10.0 / 1000.0 / items
-        tot = np.median(us[:, 0] + us[:, 1] + us[:, 2] + us[:, 3] + us[:, 4])
-        print("half %s wave %d: " % ("AB"[half], wv) + " | ".join("%s %.3f" % (names[k], np.median(us[:, k])) for k in range(6)) +
+if os.environ.get("DSMI_RNN_KERNEL") == "ring8":
+    raw = buf[:n].astype(np.float64)
+    names = ["M work", "M-end waits", "C work", "barrier after M", "barrier after C", "poll spin"]
+    print("B %d: %d workgroups, %d items per half; us per item (median over workgroups)" % (B, n, items))
+    for half in (0, 1):
+        for wv in (0, 1, 3):
+            c = raw[:, 4 * half + wv, :]
+            us = c[:, :6] * 10.0 / 1000.0 / items
+            tot = np.median(us[:, 0] + us[:, 1] + us[:, 2] + us[:, 3] + us[:, 4])
+            print("half %s wave %d: " % ("AB"[half], wv) + " | ".join("%s %.3f" % (names[k], np.median(us[:, k])) for k in range(6)) +
+                  " | sum %.3f -> %.2f us per step" % (tot, tot * 4))
+else:
+    # the kernel writes [workgroup][4 waves][8] contiguously: the first 32 words of every 128-word row... of the flat buffer
+    raw = buf.reshape(-1)[: n * 32].reshape(n, 4, 8).astype(np.float64)
+    names = ["phase work", "wait for requests", "poll spin", "barrier"]
+    print("B %d: %d workgroups, %d phases; us per phase (median over workgroups), wave = (group, K half)" % (B, n, int(np.median(raw[:, 0, 7]))))
+    for wv in range(4):
+        us = raw[:, wv, :4] * 10.0 / 1000.0 / np.maximum(raw[:, wv, 7:8], 1)
+        tot = np.median(us.sum(axis=1))
+        print("wave %d (%d, %d): " % (wv, wv & 1, wv >> 1) + " | ".join("%s %.3f" % (names[k], np.median(us[:, k])) for k in range(4)) +
               " | sum %.3f -> %.2f us per step" % (tot, tot * 4))

@@ -27,10 +27,12 @@
 //     16-byte store, the cell's thread -- (clip, two adjacent units) -- reads 8 bytes per gate and K-half.  Reduce buffers and the
 //     x-projection's landing zone are double-buffered by the item's parity, which is what lets ONE barrier per phase order them.
 //   * The x-projection of an item comes by LDS-DMA, 16 bytes per lane, 1 KiB per instruction ([16 clips][16 units] of one gate
-//     and group), requested at the start of the phase before the one that reads it.
-//   * Publish: the four lanes of a (clip, 8-unit k-group) hand their (hi | lo << 16) words to the first of them by DPP row shifts;
-//     that lane stores 16 bytes of each plane with sc1.  Stores carry no branch: a lane with nothing to store has an offset
-//     beyond the buffer's range.
+//     and group).  It comes from HBM: the slowest request, and a wave's vector-memory operations complete in issue order -- so it
+//     is the LAST request of a phase, stays in flight across the barrier (the phase's end waits for all but these: vmcnt(XJ)) and
+//     has the whole next phase to land: three landing zones in rotation (requested in P_q, landed by the end of P_q+1, read in P_q+2).
+//   * Publish: the four lanes of a (clip, 8-unit k-group) exchange their (hi | lo << 16) words by DPP quad broadcasts; the first
+//     of them stores the 16 bytes of the hi plane, the second those of the lo plane, in ONE sc1 store instruction.  Stores carry no
+//     branch: a lane with nothing to store has an offset beyond the buffer's range.
 //   * The body of a phase is ONE basic block (no branch between the first MFMA and the last): requests that do not apply are
 //     clamped onto valid, harmless ones instead of being skipped, step 0 (h = 0: no MFMAs, no state) is a prologue of its own.
 #include "common.h"
@@ -47,7 +49,6 @@ namespace {
 constexpr int XNT = 256;               // 4 waves: (group mh = v & 1, K half kh = v >> 1)
 constexpr int XU = 16;                 // hidden units per group
 constexpr int XB = 16;                 // clips per batch tile
-constexpr int XRP = 20;                // row pitch (words) of the reduce buffers: [16 clips][16 units + 4]
 constexpr int XMAXT = 8;               // tiles a window walks at most
 
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
@@ -69,6 +70,16 @@ struct Ring4Args {
                                // [1] wait for the wave's requests, [2] poll spin (wave 0), [3] barrier; [7] phases
 };
 
+// A wave-uniform pointer as an "s" operand of inline assembly: under scalar-register pressure the compiler computes such addresses
+// on the vector unit and hands the assembly a VGPR pair for an "s" constraint (rejected by the assembler at best); through
+// readfirstlane the operand is scalar whatever its history.
+template <class T>
+__device__ __forceinline__ const T* uni_ptr(const T* q) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(q);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return reinterpret_cast<const T*>(((unsigned long long)hi << 32) | lo);
+}
+
 __device__ __forceinline__ void ring4_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 
@@ -86,11 +97,14 @@ __global__ __launch_bounds__(XNT) void rnn_persist_ring4_kernel(Ring4Args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char xlds[];
     const int sbytes = p.nkb * 2048;
     unsigned char* sbuf = xlds;                                                   // [2 ring slots][nkb][2 planes][1024]
-    constexpr int RED_G = 16 * XRP;                                               // words of one (buffer, group, K half, gate)
+    // reduce buffers: rows of 16 words (a clip's 16 units of one gate), a row's four 4-word blocks stored at block ^ ((clip >> 2) & 3):
+    // conflict-free for the 16-byte stores (lane -> clip l & 15, block l >> 4) and the 8-byte reads (8 lanes per clip) alike
+    constexpr int RED_G = 256;                                                    // words of one (buffer, group, K half, gate)
     constexpr int RED_BUF = 2 * 2 * NG * RED_G;
-    float* red_all = reinterpret_cast<float*>(xlds + 2 * sbytes);                 // [2 buffers][2 groups][2 K halves][NG][16 clips][XRP]
-    float* xgl = red_all + 2 * RED_BUF;                                           // [2 buffers][2 groups][NG][16 clips][16 units]
-    int* sync = reinterpret_cast<int*>(xgl + 2 * 2 * NG * 256);                   // [0] dead flag (a hand-off wait timed out: stop waiting)
+    constexpr int XGB = 2 * NG * 1024;                                            // bytes of one x-projection landing zone
+    float* red_all = reinterpret_cast<float*>(xlds + 2 * sbytes);                 // [2 buffers][2 groups][2 K halves][NG][16 clips][16]
+    float* xgl = red_all + 2 * RED_BUF;                                           // [3 zones][2 groups][NG][16 clips][16 units]
+    int* sync = reinterpret_cast<int*>(xgl + 3 * 2 * NG * 256);                   // [0] dead flag (a hand-off wait timed out: stop waiting)
     unsigned long long* tacc = reinterpret_cast<unsigned long long*>(sync + 32) + (STAMP ? (threadIdx.x >> 6) * 8 : 0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int v = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -105,7 +119,7 @@ __global__ __launch_bounds__(XNT) void rnn_persist_ring4_kernel(Ring4Args p) {
     constexpr int GU = NG * XU;
     {   // ring slots (step 0 multiplies nothing, but a phantom k-block is read), reduce buffers (the prologue's cells read zeros)
         u32x4* z = reinterpret_cast<u32x4*>(xlds);
-        const int n16 = (2 * sbytes + (2 * RED_BUF + 2 * 2 * NG * 256) * 4) / 16;
+        const int n16 = (2 * sbytes + (2 * RED_BUF + 3 * 2 * NG * 256) * 4) / 16;
         for (int i = tid; i < n16; i += XNT) z[i] = u32x4{0u, 0u, 0u, 0u};
     }
     if (tid < 32) sync[tid] = 0;
@@ -171,12 +185,14 @@ __global__ __launch_bounds__(XNT) void rnn_persist_ring4_kernel(Ring4Args p) {
     }
     constexpr unsigned OOR = 0x80000000u;
     const unsigned o_by = (unsigned)(cj * p.Hs + (half_ok ? cunit : 0)) * 4u;          // byte offset inside an out row block [16 clips][Hs]
-    const unsigned pub_off = (e4 == 0 && half_ok) ? (unsigned)(w16 >> 1) * 2048u + (unsigned)(2 * (w16 & 1) + kg) * 256u + (unsigned)cj * 16u : OOR;   // hi plane; lo at + 1024
+    // publish: lane e4 == 0 of a (clip, k-group) stores the hi plane's 16 bytes, lane e4 == 1 the lo plane's (+ 1024)
+    const unsigned pub_off = (e4 < 2 && half_ok) ? (unsigned)(w16 >> 1) * 2048u + (unsigned)(2 * (w16 & 1) + kg) * 256u + (unsigned)cj * 16u + (unsigned)e4 * 1024u : OOR;
+    const unsigned pub_sel = e4 == 1 ? 0x07060302u : 0x05040100u;                     // v_perm selector: the high (lo plane) or low (hi plane) halves
     const unsigned shard = (unsigned)(w32 & (kPersist16Shards - 1)) * 64u;
     const unsigned need = (unsigned)((nwg32 + kPersist16Shards - 1 - (lane & (kPersist16Shards - 1))) / kPersist16Shards);
     // reduce buffers: where this lane's MFMA results go (clip ln, units 4 lg ..), where this thread's cell reads from
-    float* red_w = red_all + ((mh * 2 + kh) * NG) * RED_G + ln * XRP + 4 * lg;
-    const float* red_r = red_all + ((mh * 2) * NG) * RED_G + cj * XRP + u0;
+    float* red_w = red_all + ((mh * 2 + kh) * NG) * RED_G + ln * 16 + 4 * (lg ^ ((ln >> 2) & 3));
+    const float* red_r = red_all + ((mh * 2) * NG) * RED_G + cj * 16 + 4 * ((u0 >> 2) ^ ((cj >> 2) & 3)) + (u0 & 3);
     const float* xg_r = xgl + (mh * NG) * 256 + cj * 16 + u0;
     // x-projection requests of this wave: instruction k brings (group xm, gate xg_) = j / NG, j % NG of j = min(v + 4 k, 2 NG - 1):
     // lane l -> clip l >> 2, units 4 (l & 3) .. + 3
@@ -192,7 +208,6 @@ __global__ __launch_bounds__(XNT) void rnn_persist_ring4_kernel(Ring4Args p) {
     // state DMA: this wave brings k-blocks dk0 .. dk0 + NKD - 1 of the item (clamped into the chain: what lies beyond the wave's
     // share is brought twice, to the same place)
     const int dk0 = (v * p.nkb) / 4;
-    unsigned pollv = 0;             // wave 0: the counter shard this lane read at the start of the phase
 
     float hprev[NT][2], cprev[NT][2];
 #pragma unroll
@@ -205,52 +220,66 @@ __global__ __launch_bounds__(XNT) void rnn_persist_ring4_kernel(Ring4Args p) {
     const size_t xstride = (size_t)p.B * p.Np;
     const unsigned ostride_by = (unsigned)((size_t)p.B * p.Hs * 4);
 
+    // x-projection of item (time index tt, tile jt): this wave's XJ requests, into landing zone `zone`
+    auto xg_request = [&](int tt, unsigned jt, bool last_tile, unsigned zone) {
+        const float* xrow = uni_ptr(p.xp + (size_t)tt * xstride + (size_t)((unsigned)tile0 + jt) * xrows);
+        const unsigned by = last_tile ? xl_by_last : xl_by;
+#pragma unroll
+        for (int k = 0; k < XJ; ++k) {
+            const unsigned ldst = __builtin_amdgcn_readfirstlane(xq_lds[k] + zone * (unsigned)XGB), vo = by + xq_col[k];
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(ldst), "v"(vo), "s"(xrow) : "memory");
+        }
+    };
+    unsigned xz = 0;                // landing zone of the phase's MFMA item q: q % 3 (its cell reads it in the next phase)
+
     // One phase.  J: tile of the MFMA item (s, J).  DO_M: multiply (false: step 0, whose state is zero, and the epilogue).  DO_C: the cell
     // of the previous item, (s, J - 1) or (s - 1, NT - 1).  DUTY: signal / poll / requests for the neighbouring items.
     auto phase = [&](auto jc, auto domc, auto docc, auto dutyc, int s) {
         constexpr int J = decltype(jc)::value;
         constexpr bool DO_M = decltype(domc)::value, DO_C = decltype(docc)::value, DUTY = decltype(dutyc)::value;
-        constexpr int JP = (J + NT - 1) % NT, JN = (J + 1) % NT, JQ = (J + 2) % NT;
+        constexpr int JP = (J + NT - 1) % NT, JN = (J + 1) % NT, JQ = (J + 2) % NT, JS = (J + NT - 2) % NT;
         const bool more = s + 1 < p.T;
         const int t = d == 0 ? s : p.T - 1 - s;
         const unsigned parw = (unsigned)(s & 1) * hp_par;            // parity offset step s's cells write h_s at
         const unsigned parr = hp_par - parw;                          // ... and its MFMAs read h_(s-1) from
+        const unsigned xz_c = xz == 0 ? 2u : xz - 1u;                 // zone of the cell's item q - 1
+        const unsigned xz_n = xz == 2 ? 0u : xz + 1u;                 // zone of item q + 1, requested at the end of this phase
+        // item q + 2 = (s, J + 2) needs its chain's step s - 1 [s >= 1]; or (s + 1, J + 2 - NT): its chain's step s [more]
+        const bool pon = DUTY && (J + 2 < NT ? s >= 1 : more) && TOK(JQ) && v == 0;
+        const int psp = J + 2 < NT ? s - 1 : s;
+        const unsigned* pollp = p.cnt + ((unsigned)(chain0 + JQ) * cnts + (unsigned)psp * kPersist16CntWords + (lane & (kPersist16Shards - 1)) * 64);
+        // Polls land in LDS (LDS-DMA, 4 bytes per lane: shard l -> sync[8 + l]): no vector-memory load in this loop is visible to the
+        // compiler, so it places no vmcnt wait of its own -- any such wait is vmcnt(0) and would also wait for the x-projection
+        // requests that are meant to stay in flight (a load into a register by assembly is no way out: the compiler may copy the
+        // register before the data has arrived)
+        const unsigned poll_lds = (unsigned)(size_t)(sync + 8);
+        auto poll_request = [&]() {
+            if (lane < kPersist16Shards) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off sc1" :: "s"(poll_lds), "v"(pollp) : "memory");
+        };
         XT_BEGIN();
         if (DUTY) {
             // item q - 2, whose stores every wave drained before the barrier that opened this phase: (s, J - 2), or (s - 1, J + NT - 2)
             const int ss = J >= 2 ? s : s - 1;
-            constexpr int JS = (J + NT - 2) % NT;
             if (v == 0 && ss >= 0 && TOK(JS)) {
                 const bool drop = d == 0 && tile0 + JS == 0 && w32 == p.drop_wg && ss == p.drop_step;
                 if (lane == 0 && !drop)
                     __hip_atomic_fetch_add(p.cnt + ((unsigned)(chain0 + JS) * cnts + (unsigned)ss * kPersist16CntWords + shard), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            // item q + 2 = (s, J + 2) needs its chain's step s - 1 [s >= 1]; or (s + 1, J + 2 - NT): its chain's step s [more]
-            const bool pon = J + 2 < NT ? s >= 1 : more;
-            const int psp = J + 2 < NT ? s - 1 : s;
-            if (pon && TOK(JQ) && v == 0 && lane < kPersist16Shards)
-                pollv = __hip_atomic_load(p.cnt + ((unsigned)(chain0 + JQ) * cnts + (unsigned)psp * kPersist16CntWords + lane * 64), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // the poll's first read, answered at the end of the phase.  With four tiles the signals it asks for go out at the start of
+            // this very phase: the read goes out in the middle of the MFMA stream instead (below)
+            if (pon && NT > 4) poll_request();
         }
         __builtin_amdgcn_sched_barrier(0);
         // ================= the body: one basic block
-        if (DUTY && !(SKIP & 8)) {
-            // x-projection of item q = (s, J), read by its cell in the next phase: into buffer J & 1
-            const float* xrow = p.xp + (size_t)t * xstride + (size_t)((unsigned)tile0 + TJ(J)) * xrows;
-            const unsigned by = J >= nt - 1 ? xl_by_last : xl_by;
-#pragma unroll
-            for (int k = 0; k < XJ; ++k) {
-                const unsigned ldst = xq_lds[k] + (unsigned)((J & 1) * 2 * NG * 1024);
-                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(ldst), "v"(by + xq_col[k]), "s"(xrow) : "memory");
-            }
-        }
         // ---- the cell's operands: K-split partial sums of both halves, x-projection, all gates; two adjacent units of one clip
         f32x2 rv[NG][2], xg[NG];
         if (DO_C) {
+            const float* xgz = xg_r + xz_c * (unsigned)(XGB / 4);
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 rv[g][0] = *reinterpret_cast<const f32x2*>(red_r + (JP & 1) * RED_BUF + g * RED_G);
                 rv[g][1] = *reinterpret_cast<const f32x2*>(red_r + (JP & 1) * RED_BUF + (NG + g) * RED_G);
-                xg[g] = *reinterpret_cast<const f32x2*>(xg_r + (JP & 1) * (2 * NG * 256) + g * 256);
+                xg[g] = *reinterpret_cast<const f32x2*>(xgz + g * 256);
             }
         }
         // ---- MFMAs of item (s, J), B operands from ring slot J & 1; between them the state requests of item q + 1 and the cell
@@ -258,28 +287,45 @@ __global__ __launch_bounds__(XNT) void rnn_persist_ring4_kernel(Ring4Args p) {
 #pragma unroll
         for (int g = 0; g < NG; ++g) { acc[g] = f32x4{0.f, 0.f, 0.f, 0.f}; acl[g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         const unsigned char* sb = sbr + (J & 1) * sbytes;
-        f16x8 bc[2], bn[2];
+        // B operands: read TWO k-blocks ahead of their MFMAs (one block ahead = 9 MFMAs = 144 cycles, about the latency of a
+        // 16-byte LDS read beside the DMA's writes: the matrix pipe then waits for its operands in every block)
+        f16x8 bq[3][2];
+        auto b_off = [&](int i) { return i < NKW - 1 ? i * 2048 : klast_off; };
         if (DO_M) {
-            bc[0] = *reinterpret_cast<const f16x8*>(sb + (NKW > 1 ? 0 : klast_off));
-            bc[1] = *reinterpret_cast<const f16x8*>(sb + (NKW > 1 ? 0 : klast_off) + 1024);
+#pragma unroll
+            for (int i = 0; i < 2 && i < NKW; ++i) {
+                bq[i][0] = *reinterpret_cast<const f16x8*>(sb + b_off(i));
+                bq[i][1] = *reinterpret_cast<const f16x8*>(sb + b_off(i) + 1024);
+            }
         }
         // item q + 1 = (s, J + 1) reads h_(s-1), or (s + 1, 0) reads h_s; (past the layer's end: a request nobody reads)
-        const bool dma_on = DUTY && (DO_M || J == NT - 1) && !(SKIP & 1);
+        constexpr bool DMA_ON = DUTY && (DO_M || J == NT - 1) && !(SKIP & 1);
         const unsigned dpar = J + 1 < NT ? parr : parw;
         const unsigned char* dsrc = reinterpret_cast<const unsigned char*>(p.hpack) + (dpar + ((unsigned)chain0 + TJ(JN)) * hchs);
         const unsigned dlds = lds_sbuf + (unsigned)((JN & 1) * sbytes);
         const unsigned l16 = lane16;           // (local copies: an asm operand inside a generic lambda does not capture by itself)
         const int dk0_ = dk0, nkb_ = p.nkb;
-        auto dma_block = [&](int i) {          // k-block dk0 + i of the item, both planes
-            const unsigned kb = (unsigned)min(dk0_ + i, nkb_ - 1) * 2048u;
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024 sc1"
-                         :: "s"(dlds + kb), "v"(l16), "s"(dsrc + kb) : "memory");
+        // State requests: k-blocks dk0 + i of the item, i < NKD, two 1-KiB planes each, in pairs of blocks on ONE base (the
+        // instruction offset applies to the global AND the LDS address: M0 and the scalar address serve four pieces).  Half h of
+        // pair G = block 2 G + h; the second half reuses the M0 its first half set (nothing else in this kernel writes M0: checked
+        // in the build's assembly, danspeech_amd/csrc/Makefile).
+        auto dma_half = [&](int G, int h) {
+            if (!DMA_ON || 2 * G + h >= NKD) return;
+            const bool two = 2 * G + 1 < NKD;
+            const unsigned kb = (unsigned)max(min(dk0_ + 2 * G, nkb_ - (two ? 2 : 1)), 0) * 2048u;
+            const unsigned char* src = uni_ptr(dsrc + kb);
+            if (h == 0)
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024 sc1"
+                             :: "s"(__builtin_amdgcn_readfirstlane(dlds + kb)), "v"(l16), "s"(src) : "memory");
+            else
+                asm volatile("global_load_lds_dwordx4 %0, %1 offset:2048 sc1\n\tglobal_load_lds_dwordx4 %0, %1 offset:3072 sc1"
+                             :: "v"(l16), "s"(src) : "memory");
         };
         // the cell, cut into pieces that are placed between the k-blocks' MFMAs
         f32x2 hg[NG];
         float hn[2] = {0.f, 0.f};
         unsigned pk[2] = {0u, 0u};
-        u32x4 phi = {0u, 0u, 0u, 0u}, plo = {0u, 0u, 0u, 0u};
+        u32x4 pub = {0u, 0u, 0u, 0u};
         constexpr int CT = DO_C ? (J >= 1 ? 0 : 1) : 0;     // the cell's item lies a step back when J == 0
         const int tc = CT ? (d == 0 ? t - 1 : t + 1) : t;
         const unsigned osoff_c = (unsigned)tc * ostride_by;
@@ -304,61 +350,73 @@ __global__ __launch_bounds__(XNT) void rnn_persist_ring4_kernel(Ring4Args p) {
                 const _Float16 h2 = (_Float16)((h - (float)h1) * kLoScale);
                 pk[u] = (unsigned)__builtin_bit_cast(unsigned short, h1) | ((unsigned)__builtin_bit_cast(unsigned short, h2) << 16);
             } else if (piece == 3) {
+                // every lane of a quad (one clip, one 8-unit k-group) gets the quad's eight words: quad_perm [k, k, k, k] = 0x55 k
                 unsigned u[8];
-                u[0] = pk[0]; u[1] = pk[1];
-                u[2] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pk[0], 0x101, 0xF, 0xF, false);      // row_shl:n: lane i receives lane i + n's word
-                u[3] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pk[1], 0x101, 0xF, 0xF, false);
-                u[4] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pk[0], 0x102, 0xF, 0xF, false);
-                u[5] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pk[1], 0x102, 0xF, 0xF, false);
-                u[6] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pk[0], 0x103, 0xF, 0xF, false);
-                u[7] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pk[1], 0x103, 0xF, 0xF, false);
+                u[0] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pk[0], 0x00, 0xF, 0xF, false);
+                u[1] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pk[1], 0x00, 0xF, 0xF, false);
+                u[2] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pk[0], 0x55, 0xF, 0xF, false);
+                u[3] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pk[1], 0x55, 0xF, 0xF, false);
+                u[4] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pk[0], 0xAA, 0xF, 0xF, false);
+                u[5] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pk[1], 0xAA, 0xF, 0xF, false);
+                u[6] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pk[0], 0xFF, 0xF, 0xF, false);
+                u[7] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pk[1], 0xFF, 0xF, 0xF, false);
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    phi[m] = __builtin_amdgcn_perm(u[2 * m + 1], u[2 * m], 0x05040100u);     // low halves: units 2m, 2m + 1 of the hi plane
-                    plo[m] = __builtin_amdgcn_perm(u[2 * m + 1], u[2 * m], 0x07060302u);     // high halves: the lo plane
-                }
+                for (int m = 0; m < 4; ++m) pub[m] = __builtin_amdgcn_perm(u[2 * m + 1], u[2 * m], pub_sel);      // units 2m, 2m + 1 of this lane's plane
             } else if (piece == 4 && !(SKIP & 16)) {
                 const unsigned hoff = parw_c + ((unsigned)chain0 + TJ(JP)) * hchs;
-                __builtin_amdgcn_raw_buffer_store_b128(phi, hrs, TOK(JP) ? pub_off : OOR, hoff, 16);
-                __builtin_amdgcn_raw_buffer_store_b128(plo, hrs, TOK(JP) ? pub_off + 1024u : OOR, hoff, 16);
+                __builtin_amdgcn_raw_buffer_store_b128(pub, hrs, TOK(JP) ? pub_off : OOR, hoff, 16);
                 u32x2 ov = {__builtin_bit_cast(unsigned, hn[0]), __builtin_bit_cast(unsigned, hn[1])};
                 __builtin_amdgcn_raw_buffer_store_b64(ov, ors, act ? o_by : OOR, osoff_c + ((unsigned)tile0 + TJ(JP)) * orows * 4u, 0);
             }
         };
-        // placement: piece k of the cell behind k-block CP[k]'s MFMAs, DMA block i behind k-block i (the texture path takes a
-        // 1-KiB piece per ~80 cycles: one block per k-block's 9 x 16 cycles)
-        constexpr int NP = 5;
-        if (!DO_M) {
-            if (dma_on) {
-#pragma unroll
-                for (int i = 0; i < NKD; ++i) dma_block(i);
+        // ---- the x-projection of item q + 1 = (s, J + 1) or (s + 1, 0): the phase's LAST requests (they stay in flight), placed in
+        // front of the last k-block's MFMAs rather than behind the partial tiles (where the matrix pipe would stand meanwhile)
+        auto xg_next = [&]() {
+            if (DUTY && !(SKIP & 8)) {
+                const int tn = J + 1 < NT ? t : (more ? (d == 0 ? t + 1 : t - 1) : t);
+                xg_request(tn, TJ(JN), JN >= nt - 1, xz_n);
             }
+        };
+        constexpr int NP = 5;
+        static_assert(NKD <= 7 && NP <= 5, "the x-projection requests follow every state request and store of the phase");
+        if (!DO_M) {
+            if (DUTY && NT == 4 && pon) poll_request();
+#pragma unroll
+            for (int i = 0; i < NKD; ++i) dma_half(i >> 1, i & 1);
 #pragma unroll
             for (int k = 0; k < NP; ++k) cell_piece(k);
         } else {
 #pragma unroll
             for (int i = 0; i < NKW; ++i) {
-                if (i + 1 < NKW) {
-                    const int off = i + 1 < NKW - 1 ? (i + 1) * 2048 : klast_off;
-                    bn[0] = *reinterpret_cast<const f16x8*>(sb + off);
-                    bn[1] = *reinterpret_cast<const f16x8*>(sb + off + 1024);
+                if (i + 2 < NKW) {
+                    bq[(i + 2) % 3][0] = *reinterpret_cast<const f16x8*>(sb + b_off(i + 2));
+                    bq[(i + 2) % 3][1] = *reinterpret_cast<const f16x8*>(sb + b_off(i + 2) + 1024);
                 }
-                if (dma_on && i < NKD) dma_block(i);
+                // (pinned: left to itself the scheduler sinks every read to its first use, to save registers it does not lack)
+                __builtin_amdgcn_sched_barrier(0);
+                const f16x8 b0 = bq[i % 3][0], b1 = bq[i % 3][1];
+                dma_half(i >> 1, i & 1);          // block i of the wave's share behind k-block i's operand reads
+                if (DUTY && NT == 4 && i == (NKW * 5) / 8 && pon) poll_request();
+                if (i == NKW - 1) {
+#pragma unroll
+                    for (int k = NKW; k < NKD; ++k) dma_half(k >> 1, k & 1);
+                }
+                if (i == (NKW - 1 > NP ? NKW - 1 : -1)) xg_next();      // (few k-blocks: behind the cell's last piece, below)
                 if (!(SKIP & 2)) {
 #pragma unroll
-                    for (int g = 0; g < NG; ++g) acl[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[i][g][1], bc[0], acl[g], 0, 0, 0);
+                    for (int g = 0; g < NG; ++g) acl[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[i][g][1], b0, acl[g], 0, 0, 0);
 #pragma unroll
-                    for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[i][g][0], bc[0], acc[g], 0, 0, 0);
+                    for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[i][g][0], b0, acc[g], 0, 0, 0);
 #pragma unroll
-                    for (int g = 0; g < NG; ++g) acl[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[i][g][0], bc[1], acl[g], 0, 0, 0);
+                    for (int g = 0; g < NG; ++g) acl[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[i][g][0], b1, acl[g], 0, 0, 0);
                 }
                 // the cell's pieces spread over the k-blocks (NKW >= NP: one piece per block from the first; fewer blocks: the rest behind the last)
                 if (i < NP) cell_piece(i);
                 if (i == NKW - 1) {
 #pragma unroll
                     for (int k = NKW; k < NP; ++k) cell_piece(k);
+                    if (!(NKW - 1 > NP)) xg_next();
                 }
-                bc[0] = bn[0]; bc[1] = bn[1];
             }
             // partial tiles -> reduce buffer J & 1
 #pragma unroll
@@ -369,38 +427,47 @@ __global__ __launch_bounds__(XNT) void rnn_persist_ring4_kernel(Ring4Args p) {
                 *reinterpret_cast<f32x4*>(red_w + (J & 1) * RED_BUF + g * RED_G) = o;
             }
         }
+        if (!DO_M) xg_next();
         __builtin_amdgcn_sched_barrier(0);
         // ================= end of the body
         XT_MARK(0);
-        // everything this wave requested: publish stores (drained), state DMA (landed), x-projection (arrived)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_waitcnt(0x0F70);      // the same wait where the compiler sees it: nothing of this wave's is in flight
+        // everything this wave requested but the x-projection of the next item: publish stores drained, state DMA landed, the
+        // x-projection requested a phase ago arrived (vector-memory operations complete in issue order)
+        if (DUTY && !(SKIP & 8)) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(XJ) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         XT_MARK(1);
-        if (DUTY) {
-            const bool pon = J + 2 < NT ? s >= 1 : more;
-            const int psp = J + 2 < NT ? s - 1 : s;
-            if (pon && TOK(JQ) && v == 0 && !sync[0] && !(SKIP & 4)) {
-                const unsigned* cp = p.cnt + ((unsigned)(chain0 + JQ) * cnts + (unsigned)psp * kPersist16CntWords + (lane & (kPersist16Shards - 1)) * 64);
-                unsigned spins = 0;
-                unsigned got = lane < kPersist16Shards ? pollv : need;
-                while (__builtin_amdgcn_ballot_w64(got < need) != 0) {
-                    __builtin_amdgcn_s_sleep(1);
-                    ++spins;
-                    if ((spins & 1023u) == 0 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { sync[0] = 1; break; }
-                    if (spins > p.spin_limit) { atomicExch(p.err, 1u); sync[0] = 1; break; }
-                    got = lane < kPersist16Shards ? __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need;
+        if (pon && !sync[0] && !(SKIP & 4)) {
+            // (LDS reads by assembly: a volatile read through a generic pointer becomes a flat load -- and a vmcnt(0) wait)
+            auto lds_word = [&](unsigned addr) { unsigned r; asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(addr) : "memory"); return r; };
+            const unsigned pl = poll_lds + (unsigned)(lane & (kPersist16Shards - 1)) * 4u;
+            unsigned spins = 0;
+            unsigned got = lane < kPersist16Shards ? lds_word(pl) : need;
+            while (__builtin_amdgcn_ballot_w64(got < need) != 0) {
+                __builtin_amdgcn_s_sleep(1);
+                ++spins;
+                if (spins > p.spin_limit) { __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); sync[0] = 1; break; }
+                if ((spins & 1023u) == 0) {           // somebody else gave up: stop waiting too
+                    if (lane == 0) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off sc1" :: "s"(poll_lds + 32u), "v"(p.err) : "memory");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lds_word(poll_lds + 32u) != 0) { sync[0] = 1; break; }
                 }
+                poll_request();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                got = lane < kPersist16Shards ? lds_word(pl) : need;
             }
-            __builtin_amdgcn_s_waitcnt(0x0F70);
         }
         XT_MARK(2);
         ring4_barrier();
         XT_MARK(3);
         if (STAMP && lane == 0) tacc[7] += 1;
+        xz = xz_n;
     };
 
-    // the prologue's loads (W_hh, biases, lengths) have arrived and the zeroed LDS is visible
+    // item 0's x-projection into zone 0; then: the prologue's loads (W_hh, biases, lengths) and that request have arrived, the zeroed
+    // LDS is visible (the zeroing stores are ordered before the DMA's landing by the barrier in between)
     __builtin_amdgcn_s_waitcnt(0x0F70);
+    ring4_barrier();
+    if (!(SKIP & 8)) xg_request(d == 0 ? 0 : p.T - 1, 0u, nt <= 1, 0u);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     ring4_barrier();
 
@@ -440,7 +507,7 @@ __global__ __launch_bounds__(XNT) void rnn_persist_ring4_kernel(Ring4Args p) {
 
 size_t ring4_lds_bytes(int kind, int nkb) {
     const int NG = kind == DSMI_RNN_GRU ? 3 : (kind == DSMI_RNN_LSTM ? 4 : 1);
-    return (size_t)2 * nkb * 2048 + (size_t)2 * 2 * 2 * NG * 16 * XRP * 4 + (size_t)2 * 2 * NG * 256 * 4 + 32 * 4 + 4 * 8 * 8;
+    return (size_t)2 * nkb * 2048 + (size_t)2 * 2 * 2 * NG * 256 * 4 + (size_t)3 * 2 * NG * 256 * 4 + 32 * 4 + 4 * 8 * 8;
 }
 
 template <int KIND, int NT>
@@ -516,7 +583,10 @@ int rnn_persist_ring4_tiles(const RnnGeom& g16, int B, int n_cus) {
     if (ring4_lds_bytes(g16.kind, nkb) > 160 * 1024) return 0;
     if (((g16.nwg + 1) / 2) * g16.D > n_cus) return 0;
     if ((size_t)g16.D * ceil_div(B, XB) * nkb * 2048 * 2 >= (1ull << 31)) return 0;      // packed state below 2 GiB (store offsets, see OOR)
-    return std::min(ceil_div(B, XB), 4);
+    // tiles per window: four (a 64-clip forward); DSMI_RING_TILES=6|8 lets a window walk more (a chain's hand-off then lies under
+    // five or seven other phases instead of three)
+    static const int most = [] { const char* e = std::getenv("DSMI_RING_TILES"); const int v = e ? std::atoi(e) : 4; return v >= 4 && v <= XMAXT ? v : 4; }();
+    return std::min(ceil_div(B, XB), most);
 }
 
 bool launch_rnn_persist_ring4(const RnnPersist16Launch& p, hipStream_t s) {
@@ -527,9 +597,16 @@ bool launch_rnn_persist_ring4(const RnnPersist16Launch& p, hipStream_t s) {
     a.ntiles = ceil_div(p.B, XB); a.D = p.g.D;
     a.tile0 = p.tile0; a.ntw = p.ntw > 0 ? p.ntw : a.ntiles - p.tile0;
     a.tile_end = std::min(a.ntiles, a.tile0 + a.ntw * std::max(p.nwin, 1));
-    if (a.ntw < 1 || a.ntw > 4 || a.tile_end <= a.tile0) return false;
+    if (a.ntw < 1 || a.ntw > XMAXT || a.tile_end <= a.tile0) return false;
     if ((size_t)p.T * p.B * p.g.Kp * 4 >= (1ull << 31)) return false;          // a direction's output rows below 2 GiB (store offsets, see OOR)
     a.spin_limit = p.spin_limit; a.drop_wg = p.drop_wg; a.drop_step = p.drop_step; a.dbg = p.dbg;
+    if (a.ntw > 4) {          // more than four tiles per window: the eight-tile schedule (six: two phantom tiles)
+        switch (p.g.kind) {
+            case DSMI_RNN_GRU: return launch_ring4_nt<DSMI_RNN_GRU, 8>(a, s, p.ev);
+            case DSMI_RNN_LSTM: return launch_ring4_nt<DSMI_RNN_LSTM, 8>(a, s, p.ev);
+            default: return launch_ring4_nt<DSMI_RNN_TANH, 8>(a, s, p.ev);
+        }
+    }
     switch (p.g.kind) {
         case DSMI_RNN_GRU: return launch_ring4_nt<DSMI_RNN_GRU, 4>(a, s, p.ev);
         case DSMI_RNN_LSTM: return launch_ring4_nt<DSMI_RNN_LSTM, 4>(a, s, p.ev);

@@ -17,11 +17,13 @@ pcm = torch.from_numpy(np.stack(host)).cuda()
 clips = DeviceClips(pcm.view(-1), np.full(B, N, dtype=np.int64))
 want = None
 combos = [(4, 64), (5, 64)] if not os.environ.get("DSMI_RNN_KERNEL") else [(2, 32), (2, 64), (4, 32)]
+if os.environ.get("PIPE_COMBOS"):          # e.g. PIPE_COMBOS="4x64,2x128,3x128,4x128"
+    combos = [tuple(int(v) for v in c.split("x")) for c in os.environ["PIPE_COMBOS"].split(",")]
 for lanes, merge in combos:
     eng = rec.danspeech_recognizer
     host16 = [h.astype(np.int16) for h in host]
     host32 = [h.astype(np.float32) for h in host]
-    order = (("host", lambda: (host for _ in range(steps))), ("device", lambda: (clips for _ in range(steps))), ("host", lambda: (host for _ in range(steps))))
+    order = (("host", lambda: (host for _ in range(steps))), ("device", lambda: (clips for _ in range(steps))))
     for kind, src in order:
         for res in eng.transcribe_batches((src() if False else (clips if kind == "device" else {"host": host, "host16": host16, "host32": host32}[kind]) for _ in range(16)), lanes=lanes, merge_clips=merge):
             pass

@@ -207,7 +207,8 @@ extern "C" int dsmi_model_create(const dsmi_model_desc* d, int device, dsmi_mode
         // parity tests of those kernels); =ring: the ring kernel also for a lone batch of up to 32 clips
         const char* rk = std::getenv("DSMI_RNN_KERNEL");
         m->rnn_kernel = (rk && std::string(rk) == "duo") ? 1 : ((rk && std::string(rk) == "ring") ? 2 : 0);
-        m->ring8 = rk && std::string(rk) == "ring8";      // the eight-wave form of the ring kernel (A/B runs)
+        m->ring8 = rk && std::string(rk) == "ring8";      // the eight-wave form of the ring kernel everywhere (A/B runs)
+        m->ring4 = rk && std::string(rk) == "ring4";      // the four-wave form everywhere (also for windows of one or two tiles)
         // DSMI_DENSE_MODE=f32: GEMM and conv layers on the plain fp32-MFMA kernels (the round-1 path, and where a model whose
         // weights leave fp16's range ends up by itself); with DSMI_RNN_MODE=steps the whole forward is the second, independent
         // implementation the parity tests compare the default one with
@@ -651,7 +652,13 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
             const int first = nw == 1 ? m->lane % ring_slots : 0;      // a handle's own slot; several windows: from slot 0
             const int rcus = rnn_persist_ring_cus(m->geom16);
             ring_gate_wait(gate, s, first, nw, rcus, m->n_cus);
-            ok = m->ring8 ? launch_rnn_persist_ring(pl, s) : launch_rnn_persist_ring4(pl, s);
+            // Which form of the ring kernel.  Four waves (one per SIMD, the cell in the MFMAs' shadows) where a window walks three
+            // tiles or more: 6.4 against 7.2 us per step of four tiles (cfgA, alone on the chip).  The four-wave form multiplies
+            // phantom tiles like real ones (its phase has no branch), the eight-wave form skips them: a window of one or two tiles
+            // -- a lone 32-clip batch at the end of a stream -- is 4.3 / 5.4 us per step there against 5.8 / 6.0 (round 5,
+            // tools/exp/ring_layer_time.py).  DSMI_RNN_KERNEL=ring8 / ring4: one form everywhere (A/B runs, the forms' own tests).
+            const bool eight = m->ring8 || (!m->ring4 && std::min(ring_ntw, ntiles - t0) <= 2 && rnn_persist_ring_tiles(m->geom16, B, rcus) > 0);
+            ok = eight ? launch_rnn_persist_ring(pl, s) : launch_rnn_persist_ring4(pl, s);
             ring_gate_record(gate, s, first, nw, rcus);
         }
         if (ring_ntw && ok) return;
@@ -1075,7 +1082,7 @@ extern "C" int dsmi_debug_step_stamps(dsmi_model* m, int layer, int B, int To, i
 // ---- diagnostics: accumulated per-wave phase times (100 MHz ticks) of one persistent layer launch;
 // stamps_host[workgroups][8 waves][8]: 0 loop head, 1 wait, 2 h load + MFMA, 3 LDS + barrier, 4 cell (+ publish stores),
 // 5 drain + signal.  Returns the number of workgroups stamped (> 0) or a DSMI_ERR_* code (< 0).
-// DSMI_STAMP_RING=1: the ring kernel (one window of every tile of B <= 64 clips): the four-wave form stamps[workgroup][4 waves][8] (Ring4Args::dbg) = phase work,
+// DSMI_STAMP_RING=1: the ring kernel (one window of every tile of B <= 64 clips; <= 128 with DSMI_RING_TILES=8): the four-wave form stamps[workgroup][4 waves][8] (Ring4Args::dbg) = phase work,
 // wait for the wave's requests, poll spin, barrier ([7] phases); DSMI_RNN_KERNEL=ring8, the eight-wave form: stamps[workgroup][8 waves][16] (RingArgs::dbg) = M work, M-end waits,
 // C work, barrier behind M, barrier behind C, poll spin (100 MHz ticks), shader cycles in M work, slots.
 static int ring_stamps(dsmi_model* m, int layer, int B, int To, uint64_t* stamps_host, int64_t n_words);
@@ -1164,7 +1171,7 @@ extern "C" int dsmi_debug_persist_stamps(dsmi_model* m, int layer, int B, int To
 }
 
 static int ring_stamps(dsmi_model* m, int layer, int B, int To, uint64_t* stamps_host, int64_t n_words) {
-    if (B < 1 || B > 64 || layer < 0 || layer >= m->desc.rnn_layers || !m->have16) return DSMI_ERR_INVALID;
+    if (B < 1 || B > 128 || layer < 0 || layer >= m->desc.rnn_layers || !m->have16) return DSMI_ERR_INVALID;
     const int cap = m->ring8 ? rnn_persist_ring_tiles(m->geom16, B, m->n_cus) : rnn_persist_ring4_tiles(m->geom16, B, m->n_cus);
     if (cap < ceil_div(B, 16)) return DSMI_ERR_INVALID;
     int Tin = To;

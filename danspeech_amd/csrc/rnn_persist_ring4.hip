@@ -27,9 +27,9 @@
 //     16-byte store, the cell's thread -- (clip, two adjacent units) -- reads 8 bytes per gate and K-half.  Reduce buffers and the
 //     x-projection's landing zone are double-buffered by the item's parity, which is what lets ONE barrier per phase order them.
 //   * The x-projection of an item comes by LDS-DMA, 16 bytes per lane, 1 KiB per instruction ([16 clips][16 units] of one gate
-//     and group).  It comes from HBM: the slowest request, and a wave's vector-memory operations complete in issue order -- so it
-//     is the LAST request of a phase, stays in flight across the barrier (the phase's end waits for all but these: vmcnt(XJ)) and
-//     has the whole next phase to land: three landing zones in rotation (requested in P_q, landed by the end of P_q+1, read in P_q+2).
+//     and group).  It comes from HBM: the slowest request -- so it goes out BEHIND the phase's one drain (vmcnt(0): publish stores
+//     drained, state requests landed, poll back), is the only thing in flight across the barrier and has the whole next phase to
+//     land: three landing zones in rotation (requested at the end of P_q, landed by the drain of P_q+1, read in P_q+2).
 //   * Publish: the four lanes of a (clip, 8-unit k-group) exchange their (hi | lo << 16) words by DPP quad broadcasts; the first
 //     of them stores the 16 bytes of the hi plane, the second those of the lo plane, in ONE sc1 store instruction.  Stores carry no
 //     branch: a lane with nothing to store has an offset beyond the buffer's range.
@@ -67,7 +67,7 @@ struct Ring4Args {
     unsigned spin_limit;
     int drop_wg, drop_step;
     unsigned long long* dbg;   // diagnostics build only: per wave, 100 MHz ticks: [0] phase work (to the end of the partial tiles),
-                               // [1] wait for the wave's requests, [2] poll spin (wave 0), [3] barrier; [7] phases
+                               // [1] (unused), [2] poll spin (wave 0), [3] barrier; [4] shader cycles of the phase work; [5] polls whose first read was too early, [6] re-reads; [7] phases
 };
 
 // A wave-uniform pointer as an "s" operand of inline assembly: under scalar-register pressure the compiler computes such addresses
@@ -213,8 +213,9 @@ __global__ __launch_bounds__(XNT) void rnn_persist_ring4_kernel(Ring4Args p) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) { hprev[j][0] = hprev[j][1] = 0.f; cprev[j][0] = cprev[j][1] = 0.f; }
 
-    unsigned long long tm0 = 0, tm1 = 0;
-#define XT_BEGIN() do { if (STAMP) { __builtin_amdgcn_sched_barrier(0); tm0 = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+    unsigned long long tm0 = 0, tm1 = 0, tc0 = 0;
+#define XT_BEGIN() do { if (STAMP) { __builtin_amdgcn_sched_barrier(0); tm0 = __builtin_amdgcn_s_memrealtime(); tc0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#define XT_CLOCK() do { if (STAMP) { __builtin_amdgcn_sched_barrier(0); if ((threadIdx.x & 63) == 0) tacc[4] += __builtin_amdgcn_s_memtime() - tc0; __builtin_amdgcn_sched_barrier(0); } } while (0)
 #define XT_MARK(k) do { if (STAMP) { __builtin_amdgcn_sched_barrier(0); tm1 = __builtin_amdgcn_s_memrealtime(); if ((threadIdx.x & 63) == 0) tacc[k] += tm1 - tm0; tm0 = tm1; __builtin_amdgcn_sched_barrier(0); } } while (0)
 
     const size_t xstride = (size_t)p.B * p.Np;
@@ -377,14 +378,24 @@ __global__ __launch_bounds__(XNT) void rnn_persist_ring4_kernel(Ring4Args p) {
                 xg_request(tn, TJ(JN), JN >= nt - 1, xz_n);
             }
         };
+        // ---- ONE drain per phase, then the x-projection requests of item q + 1.  Vector-memory LOADS (state requests, polls,
+        // x-projection: all LDS-DMA) complete in issue order, stores and atomics among themselves, but not against loads: a counted
+        // wait that is to leave the x-projection in flight cannot tell an outstanding store from it.  So the phase ends with
+        // vmcnt(0) -- publish stores drained (the next phase signals them), state requests landed, poll back -- and the requests for
+        // item q + 1's x-projection go out BEHIND it: they are the only operations in flight across the barrier and have the whole
+        // next phase to arrive from HBM.  (In front of the partial tiles: the wait lies under the last k-block's MFMAs.)
+        auto drain_then_xg = [&]() {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            xg_next();
+        };
         constexpr int NP = 5;
-        static_assert(NKD <= 7 && NP <= 5, "the x-projection requests follow every state request and store of the phase");
         if (!DO_M) {
             if (DUTY && NT == 4 && pon) poll_request();
 #pragma unroll
             for (int i = 0; i < NKD; ++i) dma_half(i >> 1, i & 1);
 #pragma unroll
             for (int k = 0; k < NP; ++k) cell_piece(k);
+            drain_then_xg();
         } else {
 #pragma unroll
             for (int i = 0; i < NKW; ++i) {
@@ -396,12 +407,11 @@ __global__ __launch_bounds__(XNT) void rnn_persist_ring4_kernel(Ring4Args p) {
                 __builtin_amdgcn_sched_barrier(0);
                 const f16x8 b0 = bq[i % 3][0], b1 = bq[i % 3][1];
                 dma_half(i >> 1, i & 1);          // block i of the wave's share behind k-block i's operand reads
-                if (DUTY && NT == 4 && i == (NKW * 5) / 8 && pon) poll_request();
+                if (DUTY && NT == 4 && i == ((SKIP >> 8) ? (SKIP >> 8) : (NKW * 5) / 8) && pon) poll_request();      // (SKIP >> 8: timing experiments)
                 if (i == NKW - 1) {
 #pragma unroll
                     for (int k = NKW; k < NKD; ++k) dma_half(k >> 1, k & 1);
                 }
-                if (i == (NKW - 1 > NP ? NKW - 1 : -1)) xg_next();      // (few k-blocks: behind the cell's last piece, below)
                 if (!(SKIP & 2)) {
 #pragma unroll
                     for (int g = 0; g < NG; ++g) acl[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[i][g][1], b0, acl[g], 0, 0, 0);
@@ -415,9 +425,10 @@ __global__ __launch_bounds__(XNT) void rnn_persist_ring4_kernel(Ring4Args p) {
                 if (i == NKW - 1) {
 #pragma unroll
                     for (int k = NKW; k < NP; ++k) cell_piece(k);
-                    if (!(NKW - 1 > NP)) xg_next();
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
+            drain_then_xg();
             // partial tiles -> reduce buffer J & 1
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
@@ -427,14 +438,10 @@ __global__ __launch_bounds__(XNT) void rnn_persist_ring4_kernel(Ring4Args p) {
                 *reinterpret_cast<f32x4*>(red_w + (J & 1) * RED_BUF + g * RED_G) = o;
             }
         }
-        if (!DO_M) xg_next();
         __builtin_amdgcn_sched_barrier(0);
         // ================= end of the body
+        XT_CLOCK();           // [4]: shader-clock cycles of the body (with [0], its 100 MHz ticks: the clock the body ran at)
         XT_MARK(0);
-        // everything this wave requested but the x-projection of the next item: publish stores drained, state DMA landed, the
-        // x-projection requested a phase ago arrived (vector-memory operations complete in issue order)
-        if (DUTY && !(SKIP & 8)) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(XJ) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         XT_MARK(1);
         if (pon && !sync[0] && !(SKIP & 4)) {
             // (LDS reads by assembly: a volatile read through a generic pointer becomes a flat load -- and a vmcnt(0) wait)
@@ -442,9 +449,11 @@ __global__ __launch_bounds__(XNT) void rnn_persist_ring4_kernel(Ring4Args p) {
             const unsigned pl = poll_lds + (unsigned)(lane & (kPersist16Shards - 1)) * 4u;
             unsigned spins = 0;
             unsigned got = lane < kPersist16Shards ? lds_word(pl) : need;
+            if (STAMP && lane == 0 && __builtin_amdgcn_ballot_w64(got < need) != 0) tacc[5] += 1;      // polls whose first read was too early
             while (__builtin_amdgcn_ballot_w64(got < need) != 0) {
                 __builtin_amdgcn_s_sleep(1);
                 ++spins;
+                if (STAMP && lane == 0) tacc[6] += 1;
                 if (spins > p.spin_limit) { __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); sync[0] = 1; break; }
                 if ((spins & 1023u) == 0) {           // somebody else gave up: stop waiting too
                     if (lane == 0) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off sc1" :: "s"(poll_lds + 32u), "v"(p.err) : "memory");
@@ -499,6 +508,7 @@ __global__ __launch_bounds__(XNT) void rnn_persist_ring4_kernel(Ring4Args p) {
 #undef TJ
 #undef XT_BEGIN
 #undef XT_MARK
+#undef XT_CLOCK
     if (STAMP && lane == 0) {
         unsigned long long* o = p.dbg + ((size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + v) * 8;
         for (int k = 0; k < 8; ++k) o[k] = tacc[k];
@@ -522,7 +532,7 @@ bool launch_ring4_nt(const Ring4Args& a, hipStream_t s, const EvPair& ev) {
         DSMI_LAUNCH((rnn_persist_ring4_kernel<KIND, NK, NT, ST>), grid, block, lds, s, ev, a);                        \
     } while (0)
     if (a.dbg) {
-        if constexpr (KIND == DSMI_RNN_GRU && NT == 4) { if (nkw == 13) { LAUNCH_X(13, true); return true; } }
+        if constexpr (KIND == DSMI_RNN_GRU) { if (nkw == 13) { LAUNCH_X(13, true); return true; } }
         return false;
     }
     static const int skip = std::getenv("DSMI_DEBUG_RING_SKIP") ? std::atoi(std::getenv("DSMI_DEBUG_RING_SKIP")) : 0;
@@ -537,6 +547,7 @@ bool launch_ring4_nt(const Ring4Args& a, hipStream_t s, const EvPair& ev) {
         return true;
             switch (skip) {
                 LAUNCH_SK(1) LAUNCH_SK(2) LAUNCH_SK(4) LAUNCH_SK(8) LAUNCH_SK(16) LAUNCH_SK(32) LAUNCH_SK(9) LAUNCH_SK(13) LAUNCH_SK(29) LAUNCH_SK(31) LAUNCH_SK(61) LAUNCH_SK(63)
+                LAUNCH_SK(0x600) LAUNCH_SK(0x700) LAUNCH_SK(0x900) LAUNCH_SK(0xA00) LAUNCH_SK(0xB00)          // the complete kernel with the poll's first read at k-block 6 .. 11
                 default: return false;
             }
 #undef LAUNCH_SK
@@ -560,7 +571,7 @@ bool launch_ring4_nt(const Ring4Args& a, hipStream_t s, const EvPair& ev) {
                 else if (nkw == 11) LAUNCH_X(11, false);
                 else if (nkw == 12) LAUNCH_X(12, false);
                 else if (nkw == 13) LAUNCH_X(13, false);
-                else if (nkw == 14) LAUNCH_X(14, false);
+                else if (nkw == 14) { if constexpr (NT > 4) return false; else LAUNCH_X(14, false); }     // (eight tiles' state per thread: no registers left at 14 k-blocks)
                 else return false;
             }
     }
@@ -586,7 +597,7 @@ int rnn_persist_ring4_tiles(const RnnGeom& g16, int B, int n_cus) {
     // tiles per window: four (a 64-clip forward); DSMI_RING_TILES=6|8 lets a window walk more (a chain's hand-off then lies under
     // five or seven other phases instead of three)
     static const int most = [] { const char* e = std::getenv("DSMI_RING_TILES"); const int v = e ? std::atoi(e) : 4; return v >= 4 && v <= XMAXT ? v : 4; }();
-    return std::min(ceil_div(B, XB), most);
+    return std::min(ceil_div(B, XB), nkw == 14 ? 4 : most);
 }
 
 bool launch_rnn_persist_ring4(const RnnPersist16Launch& p, hipStream_t s) {

@@ -1,5 +1,7 @@
-"""GPU tests of the ring kernel (rnn_persist_ring.hip): one workgroup = 32 hidden units of one direction walking every
-16-clip tile of its window, the tiles' packed states staged through an LDS ring by LDS-DMA.  Reference semantics:
+"""GPU tests of the ring kernel: one workgroup = 32 hidden units of one direction walking every 16-clip tile of its window, the
+tiles' packed states staged through an LDS ring by LDS-DMA.  Two forms: four waves, one per SIMD on the whole register file
+(rnn_persist_ring4.hip: windows of three tiles or more), eight waves (rnn_persist_ring.hip: windows of one or two tiles);
+``DSMI_RNN_KERNEL=ring4`` / ``ring8`` runs one form on every window.  Reference semantics:
 ``BatchRNN.forward`` (danspeech/deepspeech/model.py:114-122) through the whole ``DeepSpeech.forward`` (:496-515); the
 checker is oracle/torch_port.py (itself pinned to the reference's goldens, tests/test_oracle_torch_port.py)."""
 import os
@@ -65,14 +67,18 @@ CASES = [("gru", 800, 64, 2), ("gru", 800, 32, 2), ("gru", 64, 17, 2), ("lstm", 
          ("gru", 48, 70, 2), ("gru", 16, 33, 2), ("rnn", 160, 100, 1)]
 
 
+# form: "auto" = what the engine picks by the window's tiles; "ring4" / "ring8" = that form on every window (the four-wave form
+# then also walks windows of one or two real tiles padded with phantom ones, the eight-wave form also windows of four)
+@pytest.mark.parametrize("form", ["auto", "ring4", "ring8"])
 @pytest.mark.parametrize("kind,H,B,inflight", CASES)
-def test_ring_kernel_equals_oracle_and_the_older_kernels(native, kind, H, B, inflight):
+def test_ring_kernel_equals_oracle_and_the_older_kernels(native, kind, H, B, inflight, form):
     from oracle import torch_port as tp
     cfg = _cfg(H, 2, kind=kind)
     sd = syn.make_state_dict(2, kind, H, 2, seed=71, **syn.TALKATIVE)
     x, lens = _batch(B=B, T=181, seed=72)
     ref, ol_ref = tp.forward(sd, cfg, x, lens)
-    m = native.NativeModel(cfg, sd)
+    with _env(**({} if form == "auto" else {"DSMI_RNN_KERNEL": form})):
+        m = native.NativeModel(cfg, sd)
     m.set_inflight(inflight)
     m.set_profiling(2)
     p, ol = m.forward(_dev(x), lens)
@@ -95,14 +101,16 @@ def test_ring_kernel_equals_oracle_and_the_older_kernels(native, kind, H, B, inf
 UNI_CASES = [("gru", 800, 64, 2), ("lstm", 256, 40, 2), ("gru", 320, 100, 1), ("rnn", 96, 33, 2)]
 
 
+@pytest.mark.parametrize("form", ["auto", "ring4"])
 @pytest.mark.parametrize("kind,H,B,inflight", UNI_CASES)
-def test_ring_kernel_unidirectional_with_lookahead(native, kind, H, B, inflight):
+def test_ring_kernel_unidirectional_with_lookahead(native, kind, H, B, inflight, form):
     from oracle import torch_port as tp
     cfg = dict(conv_layers=2, rnn_type=kind, rnn_hidden_size=H, rnn_layers=2, bidirectional=False, context=20)
     sd = syn.make_state_dict(2, kind, H, 2, bidirectional=False, context=20, seed=91, **syn.TALKATIVE)
     x, lens = _batch(B=B, T=181, seed=92)
     ref, ol_ref = tp.forward(sd, cfg, x, lens)
-    m = native.NativeModel(cfg, sd)
+    with _env(**({} if form == "auto" else {"DSMI_RNN_KERNEL": form})):
+        m = native.NativeModel(cfg, sd)
     m.set_inflight(inflight)
     m.set_profiling(2)
     p, ol = m.forward(_dev(x), lens)
@@ -178,15 +186,17 @@ def test_ring_kernel_is_what_runs(native):
     m.close()
 
 
-def test_ring_kernel_timeout_is_recomputed(native):
+@pytest.mark.parametrize("form", ["auto", "ring8"])
+def test_ring_kernel_timeout_is_recomputed(native, form):
     """A workgroup that never signals one step of chain 0: the poll of that step times out, the error word is raised, the
-    forward's status reports it and the SAME batch is recomputed on the per-step path (api.hip collect_oldest)."""
+    forward's status reports it and the SAME batch is recomputed on the per-step path (api.hip collect_oldest).  Both forms
+    (56 clips = four tiles: the four-wave form by itself)."""
     from oracle import torch_port as tp
     cfg = _cfg(64, 2)
     sd = syn.make_state_dict(2, "gru", 64, 2, seed=75, **syn.TALKATIVE)
     x, lens = _batch(B=56, T=161, seed=76)
     ref, _ = tp.forward(sd, cfg, x, lens)
-    with _env(DSMI_DEBUG_DROP_SIGNAL="1:1:9", DSMI_DEBUG_SPIN_LIMIT="3000"):
+    with _env(DSMI_DEBUG_DROP_SIGNAL="1:1:9", DSMI_DEBUG_SPIN_LIMIT="3000", **({} if form == "auto" else {"DSMI_RNN_KERNEL": form})):
         m = native.NativeModel(cfg, sd)
     m.set_inflight(2)
     with warnings.catch_warnings(record=True):

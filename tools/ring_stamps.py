@@ -33,9 +33,13 @@ else:
     # the kernel writes [workgroup][4 waves][8] contiguously: the first 32 words of every 128-word row... of the flat buffer
     raw = buf.reshape(-1)[: n * 32].reshape(n, 4, 8).astype(np.float64)
     names = ["phase work", "wait for requests", "poll spin", "barrier"]
+    tiles = max(4, -(-B // 16)) if B > 64 else 4
     print("B %d: %d workgroups, %d phases; us per phase (median over workgroups), wave = (group, K half)" % (B, n, int(np.median(raw[:, 0, 7]))))
+    print("wave 0: polls whose first read was too early: %.0f of %.0f phases (median workgroup), re-reads per such poll %.2f"
+          % (np.median(raw[:, 0, 5]), np.median(raw[:, 0, 7]), np.median(raw[:, 0, 6] / np.maximum(raw[:, 0, 5], 1))))
     for wv in range(4):
         us = raw[:, wv, :4] * 10.0 / 1000.0 / np.maximum(raw[:, wv, 7:8], 1)
         tot = np.median(us.sum(axis=1))
+        mhz = np.median(raw[:, wv, 4] / np.maximum(raw[:, wv, 0], 1)) * 100.0
         print("wave %d (%d, %d): " % (wv, wv & 1, wv >> 1) + " | ".join("%s %.3f" % (names[k], np.median(us[:, k])) for k in range(4)) +
-              " | sum %.3f -> %.2f us per step" % (tot, tot * 4))
+              " | sum %.3f -> %.2f us per step; shader clock during the phase work %.0f MHz" % (tot, tot * tiles, mhz))

@@ -127,52 +127,66 @@ class _DryEngine(object):
 
 
 class PowerSampler(object):
-    """Board power of one GPU, sampled by a thread while a block runs: the hwmon file of the device (microwatts) where the
-    driver exposes it to an ordinary user, `rocm-smi --showpower` otherwise (slower: fewer samples)."""
+    """Board power of one GPU, sampled by a thread while a block runs.  Source: the hwmon `power1_input` / `power1_average` file
+    (microwatts, label PPT) of the device's PCI function; a box shows the files of every GPU of its node, so the device is
+    looked up by its PCI address (torch's device properties), and where that fails the file that reads highest over the block
+    is taken -- the one GPU this process loads.  `rocm-smi --showpower` where no file is readable (slower: fewer samples)."""
 
     def __init__(self, index=0, period=0.05):
-        self.index, self.period, self.vals, self.source = index, period, [], None
+        self.index, self.period, self.vals, self.source = index, period, {}, None
         self._stop = None
-        self._file = self._find_hwmon(index)
+        self._files = self._find_hwmon(index)
 
     @staticmethod
     def _find_hwmon(index):
         import glob
-        cards = []
-        for dev in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+        def files_under(dev):
             for name in ("power1_average", "power1_input"):
                 hits = glob.glob(os.path.join(dev, "hwmon", "hwmon*", name))
                 if hits:
-                    cards.append(hits[0])
-                    break
-        return cards[index] if index < len(cards) else None
+                    return hits[:1]
+            return []
+        try:                                                     # the device's own PCI function
+            import torch
+            pr = torch.cuda.get_device_properties(index)
+            addr = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            hit = files_under("/sys/bus/pci/devices/" + addr)
+            if hit:
+                return hit
+        except Exception:
+            pass
+        out = []
+        for dev in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+            out += files_under(dev)
+        return out
 
-    def _read(self):
-        if self._file:
+    def _read_all(self):
+        got = {}
+        for f in list(self._files):
             try:
-                with open(self._file) as f:
-                    return int(f.read().strip()) / 1e6
+                with open(f) as fh:
+                    got[f] = int(fh.read().strip()) / 1e6
             except (OSError, ValueError):
-                self._file = None
+                self._files.remove(f)
+        if got:
+            return got
         import re
         import subprocess
         try:
             out = subprocess.run(["rocm-smi", "-d", str(self.index), "--showpower"], capture_output=True, text=True, timeout=5).stdout
             m = re.search(r"Power[^:]*:\s*([0-9.]+)", out)
-            return float(m.group(1)) if m else None
+            return {"rocm-smi --showpower": float(m.group(1))} if m else {}
         except Exception:
-            return None
+            return {}
 
     def __enter__(self):
         import threading
-        self.source = ("sysfs " + self._file) if self._file else "rocm-smi --showpower"
         self._stop = threading.Event()
 
         def loop():
             while not self._stop.is_set():
-                v = self._read()
-                if v is not None:
-                    self.vals.append(v)
+                for k, v in self._read_all().items():
+                    self.vals.setdefault(k, []).append(v)
                 self._stop.wait(self.period)
         self._thread = threading.Thread(target=loop, daemon=True)
         self._thread.start()
@@ -181,12 +195,18 @@ class PowerSampler(object):
     def __exit__(self, *a):
         self._stop.set()
         self._thread.join(timeout=10)
+        if self.vals:                                            # several candidates: the one this process loaded reads highest
+            best = max(self.vals, key=lambda k: sum(self.vals[k]) / len(self.vals[k]))
+            self.source = ("sysfs " + best if best.startswith("/") else best) + (" (highest of %d candidates)" % len(self.vals) if len(self.vals) > 1 else "")
+            self._best = self.vals[best]
+        else:
+            self._best = []
 
     def mean_watts(self):
-        return sum(self.vals) / len(self.vals) if self.vals else None
+        return sum(self._best) / len(self._best) if getattr(self, "_best", None) else None
 
     def count(self):
-        return len(self.vals)
+        return len(getattr(self, "_best", []) or [])
 
 
 def physical_cores():
@@ -229,6 +249,7 @@ def main(argv=None):
     ap.add_argument("--strict-f32-child", action="store_true", help=argparse.SUPPRESS)     # the f32_strict side run (a fresh process)
     ap.add_argument("--abi-child", action="store_true", help=argparse.SUPPRESS)            # the abi_path side run (a fresh process)
     ap.add_argument("--no-kernel-sampling", action="store_true")
+    ap.add_argument("--lanes", type=int, default=None, help="experiments: forwards in flight (default: the engine's own choice; the line says what ran)")
     ap.add_argument("--steady-steps", type=int, default=384, help="steps of the steady_state side run (at least 96)")
     ap.add_argument("--dry-run", action="store_true", help="CPU only: launch, scatter, gather and the JSON line with a stand-in engine")
     args = ap.parse_args(argv)
@@ -298,6 +319,8 @@ def main(argv=None):
             rec = Recognizer(model=model)                # greedy decoding: no language model
         eng = rec.danspeech_recognizer
         eng.keep_last_output = True
+        if args.lanes:
+            eng.pipeline_lanes = args.lanes
 
     # ---- inputs: rank 0 synthesises, shards go out over RCCL as int16 (utterance-level data parallelism)
     if rank == 0:

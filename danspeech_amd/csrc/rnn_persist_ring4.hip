@@ -6,9 +6,11 @@
 // Same arithmetic, packed weights, x-projection order, state layout and hand-off protocol as rnn_persist16.hip /
 // rnn_persist_duo.hip (split-fp16 products on v_mfma_f32_16x16x32_f16, sc1 stores / sc1 loads, sharded agent-scope counter per
 // (chain, step), bounded spins); replaces reference danspeech/deepspeech/model.py:114-122 (the nn.GRU / nn.LSTM / nn.RNN call
-// inside BatchRNN.forward on a packed batch).  Against the eight-wave form it replaces (two halves taking turns on the matrix
-// pipe, each with its own cell slot: a slot was as long as a GRU cell's dependent chain in ONE wave per SIMD, 0.90 us, of
-// which the partner's 63 MFMAs needed 0.58):
+// inside BatchRNN.forward on a packed batch).  Beside the eight-wave form (rnn_persist_ring.hip: two halves taking turns on the
+// matrix pipe, each with a cell slot of its own -- a slot as long as a GRU cell's dependent chain in ONE wave per SIMD, 0.90 us, of
+// which the partner's 63 MFMAs needed 0.58): 6.4 against 7.2 us per step of a four-tile window of cfgA alone on the chip.  The
+// eight-wave form stays for windows of one or two tiles (this form's phase has no branch: it multiplies phantom tiles like real
+// ones): api.hip picks.  Every form measured on the way, and what bounds this one: profiles/r05_ring_experiments.txt, DESIGN.md 4.
 //
 //   * Wave (mh, kh): the 16-unit group mh of the workgroup's two ADJACENT groups (virtual workgroups 2 w and 2 w + 1 of the
 //     16-unit geometry) and the half kh of the k-blocks.  Its W_hh -- up to 14 k-blocks x G gates x 2 planes x 4 registers = 336
@@ -17,12 +19,17 @@
 //     the rest in VGPRs.  One wave per SIMD is what makes the file 512 registers deep.
 //   * One phase per item q = (step s, tile j) = NT s + j, one workgroup barrier per phase:
 //
-//        P_q:  signal item q - 2  |  x-projection request for item q  |  MFMAs of item q (B operands from ring slot q & 1)
-//              with the cell of item q - 1 (K-split reduction, cell, publish, output row) and the state DMA requests of item q + 1
-//              between them  |  partial tiles -> LDS  |  wait for everything requested  |  poll for item q + 2  |  barrier
+//        P_q:  signal item q - 2  |  MFMAs of item q (B operands from ring slot q & 1, read two k-blocks ahead) with the cell of
+//              item q - 1 (K-split reduction, cell, publish, output row), the state requests of item q + 1 and the poll's first
+//              read for item q + 2 between them  |  drain: vmcnt(0)  |  x-projection requests for item q + 1  |  partial tiles
+//              -> LDS  |  poll answered  |  barrier
 //
 //     so the matrix pipe of every SIMD works in every phase, and a chain's hand-off (cell -> store drain -> signal -> everybody's
 //     signal visible -> state DMA -> MFMAs) lies under the other tiles' phases: NT - 1 of them.
+//   * No vector-memory LOAD in the loop is visible to the compiler (state, x-projection and polls all arrive by LDS-DMA issued
+//     from assembly): the compiler's wait for a load it knows of is vmcnt(0) wherever the value is used, and would wait for
+//     everything in flight.  The kernel waits ONCE per phase, at the drain.  Stores and loads do not complete in order against
+//     each other (loads do among themselves), so a counted wait cannot leave a load in flight past a store that must be drained.
 //   * The K-split reduction is two-way (the eight-wave form: four-way): a lane writes its 4 units x 1 clip of a gate as one
 //     16-byte store, the cell's thread -- (clip, two adjacent units) -- reads 8 bytes per gate and K-half.  Reduce buffers and the
 //     x-projection's landing zone are double-buffered by the item's parity, which is what lets ONE barrier per phase order them.
@@ -407,7 +414,10 @@ __global__ __launch_bounds__(XNT) void rnn_persist_ring4_kernel(Ring4Args p) {
                 __builtin_amdgcn_sched_barrier(0);
                 const f16x8 b0 = bq[i % 3][0], b1 = bq[i % 3][1];
                 dma_half(i >> 1, i & 1);          // block i of the wave's share behind k-block i's operand reads
-                if (DUTY && NT == 4 && i == ((SKIP >> 8) ? (SKIP >> 8) : (NKW * 5) / 8) && pon) poll_request();      // (SKIP >> 8: timing experiments)
+                // (not in front of the state requests' last block: a request pair's second block reuses the M0 of its first, the
+                // poll writes M0;  SKIP >> 8: timing experiments)
+                constexpr int POLL_I = (SKIP >> 8) ? (SKIP >> 8) : ((NKW * 9) / 16 > NKD - 1 ? (NKW * 9) / 16 : NKD - 1);
+                if (DUTY && NT == 4 && i == POLL_I && pon) poll_request();
                 if (i == NKW - 1) {
 #pragma unroll
                     for (int k = NKW; k < NKD; ++k) dma_half(k >> 1, k & 1);

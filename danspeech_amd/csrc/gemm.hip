@@ -213,6 +213,7 @@ struct GemmSplitArgs {
     int M, N, K, lda, ldc, B, T, ys, tiles_per_b, ktiles;
     int ntiles, mtiles;       // output tiles (gemm kernel's XCD-aware tile order)
     int pn;                   // n-tiles of a W panel: what an XCD keeps in its L2 while it walks the m-tiles (gemm_panel_width)
+    int pn2;                  // the same in PAIRS of n-tiles (the 128 x 256 form)
 };
 
 // Pass 1: form the A operand ONCE (producer transforms + two-term split) as tiled fp16 planes
@@ -282,8 +283,12 @@ __global__ __launch_bounds__(256) void split_a_kernel(GemmSplitArgs p, uint16_t*
 // two to four stages, 256 x 128, 256 x 256 with register double buffering -- cost the same 0.38-0.40 ms; the 16 x 16 x 32 MFMA
 // does the same products at a higher sustained clock: 0.340 against 0.398 ms for this very loop on 32 x 32 x 16, 8.15 against
 // 8.45 ms per bench step (tools/exp/retired/gemm_32x32x16_forms.hip.inc).
-template <bool CONV_ROWS>
-__global__ __launch_bounds__(256, 3) void gemm_f16x3_kernel(GemmSplitArgs p, const uint16_t* a_sp) {
+// STAGES = 2 (round 5): two LDS stages (64 KB, two workgroups per CU); the k-tile TWO ahead is requested into the stage whose
+// fragments everybody has just taken into registers, so a request has two k-tiles' MFMAs (1500 cycles) to land instead of one --
+// the one-stage form waits at the end of every k-tile for a request issued 48 MFMAs earlier (MFMA busy 0.6).  A/B:
+// DSMI_DEBUG_GEMM_STAGES, tools/exp/gemm_stages_time.py.
+template <bool CONV_ROWS, int STAGES = 1>
+__global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_f16x3_kernel(GemmSplitArgs p, const uint16_t* a_sp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -305,16 +310,18 @@ __global__ __launch_bounds__(256, 3) void gemm_f16x3_kernel(GemmSplitArgs p, con
     const int doff = (16 * wid + drow) * 64 + (((lane & 3) ^ ((drow >> 1) & 3) ^ ((drow >> 2) & 3)) * 16);
     const unsigned char* asrc = reinterpret_cast<const unsigned char*>(a_sp) + (size_t)mt * p.ktiles * 16384 + doff;
     const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(p.w_sp) + (size_t)nt * p.ktiles * 16384 + doff;
-    unsigned char* lds = smem3;                 // [A hi, A lo, W hi, W lo][128 rows][64 B]
+    unsigned char* lds = smem3;                 // [stage][A hi, A lo, W hi, W lo][128 rows][64 B]
     auto dma = [&](int kt) {
+        unsigned char* st = lds + (STAGES == 2 ? (kt & 1) * 32768 : 0);
 #pragma unroll
         for (int i = 0; i < 8; ++i)             // i: operand i >> 2, plane (i >> 1) & 1, 64-row half i & 1; this wave's 16 rows of it
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(((i >> 2) ? wsrc : asrc) + (size_t)kt * 16384 +
                                                                                                ((i >> 1) & 1) * 8192 + (i & 1) * 4096),
-                                             (__attribute__((address_space(3))) void*)(lds + (i >> 1) * 8192 + (i & 1) * 4096 + wid * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(st + (i >> 1) * 8192 + (i & 1) * 4096 + wid * 1024), 16, 0, 0);
     };
+    int stage_off = 0;                          // byte offset of the stage the fragments are read from
     auto frag = [&](int plane_base, int row, int chunk) {
-        return *reinterpret_cast<const f16x8*>(lds + plane_base + row * 64 + ((chunk ^ ((row >> 1) & 3) ^ ((row >> 2) & 3)) * 16));
+        return *reinterpret_cast<const f16x8*>(lds + stage_off + plane_base + row * 64 + ((chunk ^ ((row >> 1) & 3) ^ ((row >> 2) & 3)) * 16));
     };
     f32x4 acc[4][4];
 #pragma unroll
@@ -323,8 +330,10 @@ __global__ __launch_bounds__(256, 3) void gemm_f16x3_kernel(GemmSplitArgs p, con
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     dma(0);
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (STAGES == 2 && p.ktiles > 1) { dma(1); asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory"); }     // (loads complete in issue order: all but the newest eight)
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     for (int kt = 0; kt < p.ktiles; ++kt) {
+        if (STAGES == 2) stage_off = (kt & 1) * 32768;
         f16x8 af[4][2], wf[4][2];        // [tile][plane]: lane l holds row l & 15 of the tile, k = 8 (l >> 4) ..
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -334,7 +343,7 @@ __global__ __launch_bounds__(256, 3) void gemm_f16x3_kernel(GemmSplitArgs p, con
                 wf[q][pl] = frag(16384 + pl * 8192, wc * 64 + q * 16 + (lane & 15), lane >> 4);
             }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");        // everybody holds its fragments: the stage is free
-        if (kt + 1 < p.ktiles) dma(kt + 1);
+        if (kt + STAGES < p.ktiles) dma(kt + STAGES);
 #pragma unroll
         for (int pp = 0; pp < 3; ++pp)          // hi.hi, hi.lo, lo.hi: plane pair by plane pair across the sixteen tiles
 #pragma unroll
@@ -342,7 +351,9 @@ __global__ __launch_bounds__(256, 3) void gemm_f16x3_kernel(GemmSplitArgs p, con
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi][pp == 2 ? 1 : 0], wf[ni][pp == 1 ? 1 : 0], acc[mi][ni], 0, 0, 0);
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");           // the next tile has landed, for everybody
+        // the next tile has landed, for everybody (two stages: all but the eight requests just issued -- unless none were)
+        if (STAGES == 2 && kt + 2 < p.ktiles) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     }
 
     // ---- epilogue.  D[i][j] of a 16 x 16 tile: j = lane & 15 (column n), i = 4 (lane >> 4) + register: stored as it stands, a wave
@@ -385,6 +396,123 @@ __global__ __launch_bounds__(256, 3) void gemm_f16x3_kernel(GemmSplitArgs p, con
                     if (ncol + q < p.N) dst[q] = v[q];
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the reads are done before the next sixteen rows overwrite them
+    }
+}
+
+// The same GEMM on a 128 x 256 workgroup tile (round 5): one A tile against TWO adjacent n-tiles of W.  What bounds the 128 x 128
+// form is not the requests' latency (two LDS stages: -4 %, DSMI_DEBUG_GEMM_STAGES) but the fragments' way from LDS to the
+// registers: 16 ds_read_b128 per wave and 48 MFMAs = 64 KB per workgroup and k-tile against the LDS's 128 B per clock -- 512 of the
+// 768 cycles the MFMAs take.  Here a wave's four A fragments (per plane) serve eight W tiles instead of four: 24 reads per 96 MFMAs
+// (-25 % per MFMA), 48 KB requested per k-tile for twice the products (-25 %), half the barriers per MFMA.  One LDS stage (48 KB)
+// and the registers as the second buffer, as before; 224 registers of fragments and accumulators: two workgroups per CU.
+template <bool CONV_ROWS>
+__global__ __launch_bounds__(256, 2) void gemm_f16x3_wide_kernel(GemmSplitArgs p, const uint16_t* a_sp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 1, wc = wid & 1;
+    int nt2, mt;
+    const int ntiles2 = (p.ntiles + 1) >> 1;
+    {
+        const int mtiles = p.mtiles, total = ntiles2 * mtiles;
+        const int share = (total + 7) / 8;
+        const int idx = (blockIdx.x & 7) * share + (blockIdx.x >> 3);
+        if ((int)(blockIdx.x >> 3) >= share || idx >= total) return;
+        const int PN = p.pn2;
+        const int panel = idx / (PN * mtiles), rem = idx - panel * (PN * mtiles);
+        const int pw = min(PN, ntiles2 - panel * PN);
+        mt = rem / pw; nt2 = panel * PN + (rem - mt * pw);
+    }
+    const int nta = 2 * nt2, ntb = min(2 * nt2 + 1, p.ntiles - 1);      // (an odd number of n-tiles: the last pair multiplies its tile twice, stores it once)
+    const int drow = lane >> 2;
+    const int doff = (16 * wid + drow) * 64 + (((lane & 3) ^ ((drow >> 1) & 3) ^ ((drow >> 2) & 3)) * 16);
+    const unsigned char* asrc = reinterpret_cast<const unsigned char*>(a_sp) + (size_t)mt * p.ktiles * 16384 + doff;
+    const unsigned char* wsa = reinterpret_cast<const unsigned char*>(p.w_sp) + (size_t)nta * p.ktiles * 16384 + doff;
+    const unsigned char* wsb = reinterpret_cast<const unsigned char*>(p.w_sp) + (size_t)ntb * p.ktiles * 16384 + doff;
+    unsigned char* lds = smem3;                 // [A, W tile a, W tile b][hi, lo][128 rows][64 B]
+    auto dma = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {          // i: operand i >> 2 (A, Wa, Wb), plane (i >> 1) & 1, 64-row half i & 1; this wave's 16 rows of it
+            const unsigned char* src = (i >> 2) == 0 ? asrc : ((i >> 2) == 1 ? wsa : wsb);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)kt * 16384 + ((i >> 1) & 1) * 8192 + (i & 1) * 4096),
+                                             (__attribute__((address_space(3))) void*)(lds + (i >> 1) * 8192 + (i & 1) * 4096 + wid * 1024), 16, 0, 0);
+        }
+    };
+    auto frag = [&](int plane_base, int row, int chunk) {
+        return *reinterpret_cast<const f16x8*>(lds + plane_base + row * 64 + ((chunk ^ ((row >> 1) & 3) ^ ((row >> 2) & 3)) * 16));
+    };
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    dma(0);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int kt = 0; kt < p.ktiles; ++kt) {
+        f16x8 af[4][2], wf[8][2];        // [tile][plane]: lane l holds row l & 15 of the tile, k = 8 (l >> 4) ..; W tiles 0-3 of n-tile a, 4-7 of n-tile b
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) af[q][pl] = frag(pl * 8192, wr * 64 + q * 16 + (lane & 15), lane >> 4);
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) wf[q][pl] = frag(16384 + (q >> 2) * 16384 + pl * 8192, wc * 64 + (q & 3) * 16 + (lane & 15), lane >> 4);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");        // everybody holds its fragments: the stage is free
+        if (kt + 1 < p.ktiles) dma(kt + 1);
+#pragma unroll
+        for (int pp = 0; pp < 3; ++pp)          // hi.hi, hi.lo, lo.hi: plane pair by plane pair across the thirty-two tiles
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 8; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi][pp == 2 ? 1 : 0], wf[ni][pp == 1 ? 1 : 0], acc[mi][ni], 0, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");           // the next tile has landed, for everybody
+    }
+
+    // ---- epilogue: as the 128 x 128 form's, once per n-tile of the pair
+    int m0 = mt * BM, bb = 0, t0 = 0;
+    if (CONV_ROWS) { bb = mt / p.tiles_per_b; t0 = (mt % p.tiles_per_b) * BM; }
+    constexpr int TP = 68;
+    float* turn = reinterpret_cast<float*>(lds) + wid * (16 * TP);
+    const int cn = (lane & 15) * 4, cr = lane >> 4;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (2 * nt2 + h >= p.ntiles) break;
+        const int n0 = (2 * nt2 + h) * BN;
+        const int ncol = n0 + wc * 64 + cn;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias && ncol + 3 < p.N) bv = *reinterpret_cast<const f32x4*>(p.bias + ncol);
+        else if (p.bias)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bv[q] = ncol + q < p.N ? p.bias[ncol + q] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) turn[((lane >> 4) * 4 + r) * TP + ni * 16 + (lane & 15)] = acc[mi][4 * h + ni][r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // (wave-private region: no barrier)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = wr * 64 + mi * 16 + cr + 4 * j;           // row of the workgroup tile
+                f32x4 v = *reinterpret_cast<const f32x4*>(turn + (cr + 4 * j) * TP + cn);
+                v = v * (1.f / kGemmWScale) + bv;
+                size_t crow;
+                bool ok;
+                if (CONV_ROWS) { ok = t0 + i < p.T; crow = (size_t)(t0 + i) * p.B + bb; }
+                else { ok = m0 + i < p.M; crow = (size_t)(m0 + i); }
+                if (!ok) continue;
+                float* dst = p.c + crow * p.ldc + ncol;
+                if (ncol + 3 < p.N) *reinterpret_cast<f32x4*>(dst) = v;
+                else
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (ncol + q < p.N) dst[q] = v[q];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the reads are done before the next sixteen rows overwrite them
+        }
     }
 }
 
@@ -437,9 +565,37 @@ void launch_gemm(const GemmLaunch& g, hipStream_t s) {
         a.ntiles = ceil_div(g.N, BN); a.mtiles = mtiles3;
         a.pn = gemm_panel_width(a.ktiles);
         const dim3 grid3(8 * ceil_div(a.ntiles * a.mtiles, 8));
+        // the 128 x 256 form (default); DSMI_DEBUG_GEMM_WIDE=0: the 128 x 128 form (A/B runs)
+        static const int wide = [] { const char* e = std::getenv("DSMI_DEBUG_GEMM_WIDE"); return e ? std::atoi(e) : 1; }();
+        // pairs of n-tiles per W panel: three (fetch per 64-clip launch, tools/exp/gemm_wide_fetch.sh: two 1.21 / 2.01 GB (K = 800 / 1312),
+        // three 1.03 / 1.99, four 0.91 / 1.84 -- but 637 against 613 us alone; the 128 x 128 form at its best width, five n-tiles:
+        // 1.29 / 2.90 GB, 640 us); DSMI_DEBUG_GEMM_PN (n-tiles) overrides
+        static const bool pn_forced = std::getenv("DSMI_DEBUG_GEMM_PN") != nullptr;
+        a.pn2 = pn_forced ? std::max(1, (a.pn + 1) / 2) : 3;
+        if (wide) {
+            const int ntiles2 = (a.ntiles + 1) / 2;
+            const dim3 gridw(8 * ceil_div(ntiles2 * a.mtiles, 8));
+            const size_t ldsw = 49152;                  // one stage: A and two W tiles, two 8-KiB planes each
+            if (g.mode == GEMM_A_CONV) DSMI_LAUNCH(gemm_f16x3_wide_kernel<true>, gridw, dim3(256), ldsw, s, g.ev, a, (const uint16_t*)g.a_sp);
+            else DSMI_LAUNCH(gemm_f16x3_wide_kernel<false>, gridw, dim3(256), ldsw, s, g.ev, a, (const uint16_t*)g.a_sp);
+            return;
+        }
+        static const int stages = [] { const char* e = std::getenv("DSMI_DEBUG_GEMM_STAGES"); return e && std::atoi(e) == 2 ? 2 : 1; }();
+        if (stages == 2) {
+            const size_t lds2 = 65536;                  // two stages
+            static bool attr = false;
+            if (!attr) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x3_kernel<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16x3_kernel<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+                attr = true;
+            }
+            if (g.mode == GEMM_A_CONV) DSMI_LAUNCH((gemm_f16x3_kernel<true, 2>), grid3, dim3(256), lds2, s, g.ev, a, (const uint16_t*)g.a_sp);
+            else DSMI_LAUNCH((gemm_f16x3_kernel<false, 2>), grid3, dim3(256), lds2, s, g.ev, a, (const uint16_t*)g.a_sp);
+            return;
+        }
         const size_t lds3 = 32768;                      // one stage: four 8-KiB operand planes of a 32-deep k-tile
-        if (g.mode == GEMM_A_CONV) DSMI_LAUNCH(gemm_f16x3_kernel<true>, grid3, dim3(256), lds3, s, g.ev, a, (const uint16_t*)g.a_sp);
-        else DSMI_LAUNCH(gemm_f16x3_kernel<false>, grid3, dim3(256), lds3, s, g.ev, a, (const uint16_t*)g.a_sp);
+        if (g.mode == GEMM_A_CONV) DSMI_LAUNCH((gemm_f16x3_kernel<true, 1>), grid3, dim3(256), lds3, s, g.ev, a, (const uint16_t*)g.a_sp);
+        else DSMI_LAUNCH((gemm_f16x3_kernel<false, 1>), grid3, dim3(256), lds3, s, g.ev, a, (const uint16_t*)g.a_sp);
         return;
     }
     GemmArgs a;

@@ -59,9 +59,10 @@ class _env:
 
 # (kind, H, B, inflight): inflight 2 = one window on the handle's own gate slot; inflight 1 with more than 32 clips = the
 # tiles spread over up to four windows side by side.  B 64 = two 32-clip batches in one launch (four real tiles); 17 / 32 =
-# one or two real tiles padded with phantom ones; 40 / 72 = a partial last tile; 128 = eight tiles in one window;
-# H 800 / 896 = seven k-blocks per wave (the benchmarked shape and the widest); 48 units = an odd number of 16-unit groups
-# (the last workgroup's second half idle); H 16 = one k-block, two waves of a half without any.
+# one or two real tiles (the eight-wave form by itself; padded with phantom tiles in the four-wave form); 40 / 72 = a partial
+# last tile; 128 with inflight 2 = two launches of four tiles one after the other; H 800 / 896 = 13 / 14 k-blocks per wave of the
+# four-wave form (the benchmarked shape and the widest), 7 of the eight-wave form; 48 units = an odd number of 16-unit groups
+# (the last workgroup's second group idle); H 16 = one k-block (waves without any).
 CASES = [("gru", 800, 64, 2), ("gru", 800, 32, 2), ("gru", 64, 17, 2), ("lstm", 512, 48, 2), ("rnn", 96, 64, 2),
          ("gru", 896, 40, 2), ("lstm", 64, 32, 2), ("gru", 800, 128, 2), ("gru", 800, 72, 1), ("gru", 800, 128, 1),
          ("gru", 48, 70, 2), ("gru", 16, 33, 2), ("rnn", 160, 100, 1)]

@@ -158,19 +158,6 @@ static bool persist_process_lock(int device) {
 
 constexpr float kF16Safe = 60000.f;    // below fp16's 65504 with room for rounding
 
-// the handle's high-priority stream for ring windows (DSMI_RING_PRIORITY=1), made on first use
-static bool ring_prio_stream(dsmi_model* m) {
-    if (m->ring_stream) return true;
-    int lo = 0, hi = 0;
-    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return false;
-    if (hipStreamCreateWithPriority(&m->ring_stream, hipStreamNonBlocking, hi) != hipSuccess) { m->ring_stream = nullptr; return false; }
-    if (hipEventCreateWithFlags(&m->ring_ev_in, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&m->ring_ev_out, hipEventDisableTiming) != hipSuccess) {
-        (void)hipStreamDestroy(m->ring_stream); m->ring_stream = nullptr; return false;
-    }
-    return true;
-}
-
 static int fail(dsmi_model* m, int code, const std::string& msg) {
     m->err = msg;
     return code;
@@ -221,7 +208,6 @@ extern "C" int dsmi_model_create(const dsmi_model_desc* d, int device, dsmi_mode
         const char* rk = std::getenv("DSMI_RNN_KERNEL");
         m->rnn_kernel = (rk && std::string(rk) == "duo") ? 1 : ((rk && std::string(rk) == "ring") ? 2 : 0);
         m->ring8 = rk && std::string(rk) == "ring8";      // the eight-wave form of the ring kernel everywhere (A/B runs)
-        { const char* rp = std::getenv("DSMI_RING_PRIORITY"); m->ring_prio = rp && std::atoi(rp) == 1; }
         m->ring4 = rk && std::string(rk) == "ring4";      // the four-wave form everywhere (also for windows of one or two tiles)
         // DSMI_DENSE_MODE=f32: GEMM and conv layers on the plain fp32-MFMA kernels (the round-1 path, and where a model whose
         // weights leave fp16's range ends up by itself); with DSMI_RNN_MODE=steps the whole forward is the second, independent
@@ -531,7 +517,6 @@ extern "C" void dsmi_model_destroy(dsmi_model* m) {
     if (m->lens_stage) (void)hipHostFree(m->lens_stage);
     for (hipEvent_t e : m->stage_ev) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : m->kt.free_events) (void)hipEventDestroy(e);
-    if (m->ring_stream) { (void)hipStreamDestroy(m->ring_stream); (void)hipEventDestroy(m->ring_ev_in); (void)hipEventDestroy(m->ring_ev_out); }
     delete m;
 }
 
@@ -666,16 +651,6 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
             std::lock_guard<std::mutex> lk(gate->mu);
             const int first = nw == 1 ? m->lane % ring_slots : 0;      // a handle's own slot; several windows: from slot 0
             const int rcus = rnn_persist_ring_cus(m->geom16);
-            // DSMI_RING_PRIORITY=1 (experiment, round 5): the window goes out on a stream of the handle's own with the highest
-            // priority, ordered behind and in front of the forward's stream by events -- its 50 workgroups must all be resident
-            // before any of them gets anywhere, and on the forward's own stream they queue for CUs behind the other forwards'
-            // thousands of dense workgroups.
-            hipStream_t fs = s;
-            if (m->ring_prio && ring_prio_stream(m)) {
-                (void)hipEventRecord(m->ring_ev_in, fs);
-                s = m->ring_stream;
-                (void)hipStreamWaitEvent(s, m->ring_ev_in, 0);
-            }
             ring_gate_wait(gate, s, first, nw, rcus, m->n_cus);
             // Which form of the ring kernel.  Four waves (one per SIMD, the cell in the MFMAs' shadows) where a window walks three
             // tiles or more: 6.4 against 7.2 us per step of four tiles (cfgA, alone on the chip).  The four-wave form multiplies
@@ -685,11 +660,6 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
             const bool eight = m->ring8 || (!m->ring4 && std::min(ring_ntw, ntiles - t0) <= 2 && rnn_persist_ring_tiles(m->geom16, B, rcus) > 0);
             ok = eight ? launch_rnn_persist_ring(pl, s) : launch_rnn_persist_ring4(pl, s);
             ring_gate_record(gate, s, first, nw, rcus);
-            if (s != fs) {
-                (void)hipEventRecord(m->ring_ev_out, s);
-                (void)hipStreamWaitEvent(fs, m->ring_ev_out, 0);
-                s = fs;
-            }
         }
         if (ring_ntw && ok) return;
         for (int p0 = 0; !ring_ntw && p0 < (duo ? total_pairs : 1) && ok; p0 += window) {

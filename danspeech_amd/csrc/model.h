@@ -98,8 +98,6 @@ struct dsmi_model {
     int conv_mode = 1;            // 1: split-fp16 conv for the 32-input-channel layers, 0: fp32 MFMA conv
     int gemm_mode = 1;            // 1: split-fp16 GEMM, 0: fp32 MFMA GEMM
     int rnn_mode = 1;             // 1: persistent layer kernel when eligible, 0: one launch per step
-    bool ring_prio = false;       // DSMI_RING_PRIORITY=1: ring windows on a high-priority stream of the handle's own (experiment)
-    hipStream_t ring_stream = nullptr; hipEvent_t ring_ev_in = nullptr, ring_ev_out = nullptr;
     bool ring4 = false;           // DSMI_RNN_KERNEL=ring4: the four-wave ring kernel also for windows of one or two tiles
     bool ring8 = false;           // DSMI_RNN_KERNEL=ring8: the eight-wave ring kernel where the four-wave one would run
     int rnn_kernel = 0;           // DSMI_RNN_KERNEL: 0 auto, 1 "duo" (never the ring kernel), 2 "ring" (also for a lone batch <= 32 clips)

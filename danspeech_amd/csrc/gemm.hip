@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_f16x3_kernel(Ge
 // 768 cycles the MFMAs take.  Here a wave's four A fragments (per plane) serve eight W tiles instead of four: 24 reads per 96 MFMAs
 // (-25 % per MFMA), 48 KB requested per k-tile for twice the products (-25 %), half the barriers per MFMA.  One LDS stage (48 KB)
 // and the registers as the second buffer, as before; 224 registers of fragments and accumulators: two workgroups per CU.
-template <bool CONV_ROWS>
+template <bool CONV_ROWS, int GAP = 6>
 __global__ __launch_bounds__(256, 2) void gemm_f16x3_wide_kernel(GemmSplitArgs p, const uint16_t* a_sp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -430,13 +430,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_wide_kernel(GemmSplitArgs p
     const unsigned char* wsa = reinterpret_cast<const unsigned char*>(p.w_sp) + (size_t)nta * p.ktiles * 16384 + doff;
     const unsigned char* wsb = reinterpret_cast<const unsigned char*>(p.w_sp) + (size_t)ntb * p.ktiles * 16384 + doff;
     unsigned char* lds = smem3;                 // [A, W tile a, W tile b][hi, lo][128 rows][64 B]
+    // request i of a k-tile (12 per wave): operand i >> 2 (A, Wa, Wb), plane (i >> 1) & 1, 64-row half i & 1; this wave's 16 rows of it
+    auto dma_piece = [&](int kt, int i) {
+        const unsigned char* src = (i >> 2) == 0 ? asrc : ((i >> 2) == 1 ? wsa : wsb);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)kt * 16384 + ((i >> 1) & 1) * 8192 + (i & 1) * 4096),
+                                         (__attribute__((address_space(3))) void*)(lds + (i >> 1) * 8192 + (i & 1) * 4096 + wid * 1024), 16, 0, 0);
+    };
     auto dma = [&](int kt) {
 #pragma unroll
-        for (int i = 0; i < 12; ++i) {          // i: operand i >> 2 (A, Wa, Wb), plane (i >> 1) & 1, 64-row half i & 1; this wave's 16 rows of it
-            const unsigned char* src = (i >> 2) == 0 ? asrc : ((i >> 2) == 1 ? wsa : wsb);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)kt * 16384 + ((i >> 1) & 1) * 8192 + (i & 1) * 4096),
-                                             (__attribute__((address_space(3))) void*)(lds + (i >> 1) * 8192 + (i & 1) * 4096 + wid * 1024), 16, 0, 0);
-        }
+        for (int i = 0; i < 12; ++i) dma_piece(kt, i);
     };
     auto frag = [&](int plane_base, int row, int chunk) {
         return *reinterpret_cast<const f16x8*>(lds + plane_base + row * 64 + ((chunk ^ ((row >> 1) & 3) ^ ((row >> 2) & 3)) * 16));
@@ -460,14 +462,25 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_wide_kernel(GemmSplitArgs p
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) wf[q][pl] = frag(16384 + (q >> 2) * 16384 + pl * 8192, wc * 64 + (q & 3) * 16 + (lane & 15), lane >> 4);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");        // everybody holds its fragments: the stage is free
-        if (kt + 1 < p.ktiles) dma(kt + 1);
+        // The next k-tile's twelve requests go out BETWEEN the MFMAs, one per GAP of them from the first: an LDS-DMA piece holds the wave's
+        // issue port for 60 cycles and more -- twelve of them in front of the MFMAs are 700 cycles in which this wave's matrix pipe stands
+        // (the 96 MFMAs take 1536) --, and the last request has the remaining MFMAs to land under.  The last k-tile requests itself again
+        // (into the stage nobody reads any more): no branch in the block.  (One per eight: 580 us per layer GEMM; in front: 613.)
+        const int ktn = kt + 1 < p.ktiles ? kt + 1 : kt;
 #pragma unroll
-        for (int pp = 0; pp < 3; ++pp)          // hi.hi, hi.lo, lo.hi: plane pair by plane pair across the thirty-two tiles
+        for (int e = 0; e < 96; ++e) {          // hi.hi, hi.lo, lo.hi: plane pair by plane pair across the thirty-two tiles
+            const int pp = e >> 5, mi = (e >> 3) & 3, ni = e & 7;
+            if (e < 12 * GAP && e % GAP == 0) dma_piece(ktn, e / GAP);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi][pp == 2 ? 1 : 0], wf[ni][pp == 1 ? 1 : 0], acc[mi][ni], 0, 0, 0);
+        }
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 8; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mi][pp == 2 ? 1 : 0], wf[ni][pp == 1 ? 1 : 0], acc[mi][ni], 0, 0, 0);
+        for (int g = 0; g < 12; ++g) {          // ... and the scheduler is told to keep it that way
+            __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);     // one vector-memory instruction
+            __builtin_amdgcn_sched_group_barrier(0x008, GAP, 0);   // GAP MFMAs
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 96 - 12 * GAP, 0);
+        // (the MFMAs behind the last request are NOT pinned in front of the wait by a sched_barrier: the compiler then moves them behind
+        // the barrier, where they run beside the next k-tile's fragment reads -- 558 against 573 us per layer GEMM with them pinned)
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");           // the next tile has landed, for everybody
     }
 
@@ -576,8 +589,20 @@ void launch_gemm(const GemmLaunch& g, hipStream_t s) {
             const int ntiles2 = (a.ntiles + 1) / 2;
             const dim3 gridw(8 * ceil_div(ntiles2 * a.mtiles, 8));
             const size_t ldsw = 49152;                  // one stage: A and two W tiles, two 8-KiB planes each
-            if (g.mode == GEMM_A_CONV) DSMI_LAUNCH(gemm_f16x3_wide_kernel<true>, gridw, dim3(256), ldsw, s, g.ev, a, (const uint16_t*)g.a_sp);
-            else DSMI_LAUNCH(gemm_f16x3_wide_kernel<false>, gridw, dim3(256), ldsw, s, g.ev, a, (const uint16_t*)g.a_sp);
+            static const int gap = [] { const char* e = std::getenv("DSMI_DEBUG_GEMM_GAP"); return e ? std::atoi(e) : 6; }();     // (experiments)
+#define LAUNCH_W(G)                                                                                                                      \
+    do {                                                                                                                                 \
+        if (g.mode == GEMM_A_CONV) DSMI_LAUNCH((gemm_f16x3_wide_kernel<true, G>), gridw, dim3(256), ldsw, s, g.ev, a, (const uint16_t*)g.a_sp);   \
+        else DSMI_LAUNCH((gemm_f16x3_wide_kernel<false, G>), gridw, dim3(256), ldsw, s, g.ev, a, (const uint16_t*)g.a_sp);                       \
+    } while (0)
+            switch (gap) {
+                case 3: LAUNCH_W(3); break;
+                case 4: LAUNCH_W(4); break;
+                case 5: LAUNCH_W(5); break;
+                case 7: LAUNCH_W(7); break;
+                default: LAUNCH_W(6); break;
+            }
+#undef LAUNCH_W
             return;
         }
         static const int stages = [] { const char* e = std::getenv("DSMI_DEBUG_GEMM_STAGES"); return e && std::atoi(e) == 2 ? 2 : 1; }();

@@ -465,7 +465,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_wide_kernel(GemmSplitArgs p
         // The next k-tile's twelve requests go out BETWEEN the MFMAs, one per GAP of them from the first: an LDS-DMA piece holds the wave's
         // issue port for 60 cycles and more -- twelve of them in front of the MFMAs are 700 cycles in which this wave's matrix pipe stands
         // (the 96 MFMAs take 1536) --, and the last request has the remaining MFMAs to land under.  The last k-tile requests itself again
-        // (into the stage nobody reads any more): no branch in the block.  (One per eight: 580 us per layer GEMM; in front: 613.)
+        // (into the stage nobody reads any more): no branch in the block.  Per layer GEMM, one box (profiles/r05_gemm_forms.txt; commit
+        // 292020c holds the sweep build): all twelve in front 613 us; one per 3 MFMAs 637, 4: 626, 5: 612, 6: 594, 7: 587, 8: 580 - 596.
         const int ktn = kt + 1 < p.ktiles ? kt + 1 : kt;
 #pragma unroll
         for (int e = 0; e < 96; ++e) {          // hi.hi, hi.lo, lo.hi: plane pair by plane pair across the thirty-two tiles
@@ -480,7 +481,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_wide_kernel(GemmSplitArgs p
         }
         __builtin_amdgcn_sched_group_barrier(0x008, 96 - 12 * GAP, 0);
         // (the MFMAs behind the last request are NOT pinned in front of the wait by a sched_barrier: the compiler then moves them behind
-        // the barrier, where they run beside the next k-tile's fragment reads -- 558 against 573 us per layer GEMM with them pinned)
+        // the barrier, where they run beside the next k-tile's fragment reads -- 558 against 573 us per layer GEMM with them pinned,
+        // on the box that gave both)
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");           // the next tile has landed, for everybody
     }
 
@@ -589,20 +591,8 @@ void launch_gemm(const GemmLaunch& g, hipStream_t s) {
             const int ntiles2 = (a.ntiles + 1) / 2;
             const dim3 gridw(8 * ceil_div(ntiles2 * a.mtiles, 8));
             const size_t ldsw = 49152;                  // one stage: A and two W tiles, two 8-KiB planes each
-            static const int gap = [] { const char* e = std::getenv("DSMI_DEBUG_GEMM_GAP"); return e ? std::atoi(e) : 6; }();     // (experiments)
-#define LAUNCH_W(G)                                                                                                                      \
-    do {                                                                                                                                 \
-        if (g.mode == GEMM_A_CONV) DSMI_LAUNCH((gemm_f16x3_wide_kernel<true, G>), gridw, dim3(256), ldsw, s, g.ev, a, (const uint16_t*)g.a_sp);   \
-        else DSMI_LAUNCH((gemm_f16x3_wide_kernel<false, G>), gridw, dim3(256), ldsw, s, g.ev, a, (const uint16_t*)g.a_sp);                       \
-    } while (0)
-            switch (gap) {
-                case 3: LAUNCH_W(3); break;
-                case 4: LAUNCH_W(4); break;
-                case 5: LAUNCH_W(5); break;
-                case 7: LAUNCH_W(7); break;
-                default: LAUNCH_W(6); break;
-            }
-#undef LAUNCH_W
+            if (g.mode == GEMM_A_CONV) DSMI_LAUNCH(gemm_f16x3_wide_kernel<true>, gridw, dim3(256), ldsw, s, g.ev, a, (const uint16_t*)g.a_sp);
+            else DSMI_LAUNCH(gemm_f16x3_wide_kernel<false>, gridw, dim3(256), ldsw, s, g.ev, a, (const uint16_t*)g.a_sp);
             return;
         }
         static const int stages = [] { const char* e = std::getenv("DSMI_DEBUG_GEMM_STAGES"); return e && std::atoi(e) == 2 ? 2 : 1; }();

@@ -25,9 +25,7 @@ ks = m.kernel_stats()
 print(" | ".join("%%s %%.0f us = %%.0f TF-equiv" %% (k, ks[k]["avg_us"], ks[k]["flops_per_launch"] / (ks[k]["avg_us"] * 1e-6) / 1e12) for k in ("gemm_l0", "gemm", "conv2", "rnn_layer_persistent")))
 ''' % os.path.join(here, "x.py")
 outs = []
-forms = (("128 x 128, one stage", {"DSMI_DEBUG_GEMM_WIDE": "0"}), ("128 x 128, two stages", {"DSMI_DEBUG_GEMM_WIDE": "0", "DSMI_DEBUG_GEMM_STAGES": "2"}), ("128 x 256, panel of 3 pairs (default)", {}), ("128 x 256, panel of 4 pairs", {"DSMI_DEBUG_GEMM_PN": "8"}),
-         ("128 x 256, a request per 3 MFMAs", {"DSMI_DEBUG_GEMM_GAP": "3"}), ("128 x 256, a request per 4 MFMAs", {"DSMI_DEBUG_GEMM_GAP": "4"}),
-         ("128 x 256, a request per 5 MFMAs", {"DSMI_DEBUG_GEMM_GAP": "5"}), ("128 x 256, a request per 7 MFMAs", {"DSMI_DEBUG_GEMM_GAP": "7"}))
+forms = (("128 x 128, one stage", {"DSMI_DEBUG_GEMM_WIDE": "0"}), ("128 x 128, two stages", {"DSMI_DEBUG_GEMM_WIDE": "0", "DSMI_DEBUG_GEMM_STAGES": "2"}), ("128 x 256, panel of 3 pairs (default)", {}), ("128 x 256, panel of 4 pairs", {"DSMI_DEBUG_GEMM_PN": "8"}))
 for k, (name, extra) in enumerate(forms):
     env = dict(os.environ, **extra)
     f = "/tmp/gemm_form_%d.npy" % k

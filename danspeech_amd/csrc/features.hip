@@ -175,6 +175,74 @@ __global__ __launch_bounds__(256) void stft_logmag_kernel(const void* pcm, int d
     }
 }
 
+// The same transform on the matrix pipe, for the even n_fft the models use (320): v_mfma_f64_16x16x4_f64, float64 in and out -- the
+// precision ladder above is kept (a split-fp16 product with float32 accumulation is not: the partial sums of a frame are as large as
+// the frame, a quiet bin 50 dB below it is then off by 5e-4 in log1p -- measured, profiles/r05_stft_forms.txt).
+// The direct kernel above is bound by LDS bandwidth: every multiply-add reads its sample from LDS (a b128 per two), four SIMDs
+// against one LDS port -- a quarter of the float64 rate, and 95 of a workgroup's 256 lanes have no bin.  Here a wave OWNS a tile of 16
+// frames: their folded samples (even part e, odd part o, 81 k-steps of four taps) live in its registers as the MFMAs' B operands for
+// all eleven 16-bin tiles; the A operand is the twiddle of (bin, tap), read from a 5-KB table by index (bin * tap mod n_fft, carried
+// by one add and one wrap per k-step).  D[bin][frame]: sixteen lanes of a result register are sixteen consecutive frames of one bin.
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+constexpr int MF = 64;   // frames per workgroup: four waves, one 16-frame tile each
+
+template <int NFFT, typename T>          // T: double, float or int16_t samples (one channel); the other WAV-frame types take the direct kernel
+__global__ __launch_bounds__(256, 2) void stft_mfma_kernel(const T* pcm, const int64_t* offs, const int64_t* nsamp,
+                                                           const double* tw, const double* win, int hop, int pad_mode, float* feat, int t_stride) {
+    constexpr int NH = NFFT / 2, NFREQ = NH + 1, KO = NH / 4, KE = KO + 1;
+    static_assert(NH % 4 == 0, "taps in k-steps of four");
+    __shared__ __attribute__((aligned(16))) double s_tw[2 * NFFT];     // [idx][cos, sin]
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int64_t N = nsamp[b], off = offs[b];
+    const bool centred = pad_mode != PAD_NONE;
+    const int nfr = centred ? 1 + (int)(N / hop) : 1 + (int)((N - NFFT) / hop);
+    const int t0 = blockIdx.x * MF;
+    if (t0 >= nfr) return;
+    for (int i = tid; i < 2 * NFFT; i += 256) s_tw[i] = tw[i];
+    const int half = centred ? NH : 0;
+    const int t = t0 + wid * 16 + (lane & 15), j = lane >> 4;          // B operand: lane holds (tap 4 ks + j, frame lane & 15)
+    const bool live = t < nfr;
+    // x[n] and x[NFFT - n] meet the same cosine and opposite sines: e[n] = x[n] + x[NFFT - n], o[n] = x[n] - x[NFFT - n] (n = 1 .. NH - 1),
+    // e[0] = x[0], e[NH] = x[NH]
+    auto xw = [&](int n) -> double {                                    // windowed sample n of this lane's frame
+        int64_t sidx = (int64_t)t * hop + n - half;
+        bool ok = live;
+        if (sidx < 0) { sidx = -sidx; ok = ok && pad_mode == DSMI_PAD_REFLECT; }
+        else if (sidx >= N) { sidx = 2 * (N - 1) - sidx; ok = ok && pad_mode == DSMI_PAD_REFLECT; }
+        return ok ? (double)pcm[off + sidx] * win[n] : 0.0;
+    };
+    double E[KE], O[KO];
+#pragma unroll
+    for (int ks = 0; ks < KO; ++ks) {
+        const int n = 4 * ks + j;
+        const double a = xw(n), c = n == 0 ? 0.0 : xw(NFFT - n);
+        E[ks] = a + c;
+        O[ks] = n == 0 ? 0.0 : a - c;
+    }
+    E[KO] = j == 0 ? xw(NH) : 0.0;
+    __syncthreads();
+    const int to = t0 + wid * 16 + (lane & 15);
+    for (int bt = 0; bt < (NFREQ + 15) / 16; ++bt) {
+        const int bin = bt * 16 + (lane & 15);                         // A operand: lane holds (bin lane & 15, tap 4 ks + j); bins past NFREQ: not stored
+        int idx = (bin * j) % NFFT;
+        const int step = (4 * bin) % NFFT;
+        f64x4 re = {0.0, 0.0, 0.0, 0.0}, im = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < KE; ++ks) {
+            const double2 cs = *reinterpret_cast<const double2*>(&s_tw[2 * idx]);
+            re = __builtin_amdgcn_mfma_f64_16x16x4f64(cs.x, E[ks], re, 0, 0, 0);
+            if (ks < KO) im = __builtin_amdgcn_mfma_f64_16x16x4f64(cs.y, O[ks], im, 0, 0, 0);
+            idx += step;
+            idx = idx >= NFFT ? idx - NFFT : idx;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                                   // D: column lane & 15 (frame), row (lane >> 4) + 4 r (bin of the tile)
+            const int k = bt * 16 + (lane >> 4) + 4 * r;
+            if (k < NFREQ && to < nfr) feat[((size_t)b * NFREQ + k) * t_stride + to] = log1pf(hypotf((float)re[r], (float)im[r]));
+        }
+    }
+}
+
 __device__ double block_sum(double v, double* sh) {
     const int tid = threadIdx.x;
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -281,6 +349,21 @@ __global__ __launch_bounds__(256) void hop_energy_kernel(const void* pcm, int dt
     if (lane == 0) energy[hop] = sqrt(part[0] / (double)step);
 }
 
+// the matrix-pipe form serves n_fft = 320 (every shipped audio_conf: 16 kHz, 20 ms) and one-channel float64 / float32 / int16 samples
+// (float64 is what load_audio and the recognizer hand over); any other window length or WAV-frame type, or DSMI_DEBUG_STFT=direct
+// (experiments, the parity tests' second form), takes the direct kernel
+bool stft_on_mfma(int n_fft, int dtype) {
+    static const bool direct = [] { const char* e = std::getenv("DSMI_DEBUG_STFT"); return e && std::string(e) == "direct"; }();
+    return n_fft == 320 && !direct && (dtype == DSMI_PCM_F64 || dtype == DSMI_PCM_F32 || dtype == DSMI_PCM_I16);
+}
+
+void launch_stft_mfma(dim3 grid, hipStream_t s, const void* pcm, int dtype, const int64_t* offs, const int64_t* nsamp, const double* tw,
+                      const double* win, int hop, int pad_mode, float* feat, int t_stride) {
+    if (dtype == DSMI_PCM_F64) hipLaunchKernelGGL((stft_mfma_kernel<320, double>), grid, dim3(256), 0, s, (const double*)pcm, offs, nsamp, tw, win, hop, pad_mode, feat, t_stride);
+    else if (dtype == DSMI_PCM_F32) hipLaunchKernelGGL((stft_mfma_kernel<320, float>), grid, dim3(256), 0, s, (const float*)pcm, offs, nsamp, tw, win, hop, pad_mode, feat, t_stride);
+    else hipLaunchKernelGGL((stft_mfma_kernel<320, int16_t>), grid, dim3(256), 0, s, (const int16_t*)pcm, offs, nsamp, tw, win, hop, pad_mode, feat, t_stride);
+}
+
 }  // namespace
 
 extern "C" int dsmi_features_stream(dsmi_frontend* f, const void* pcm, int dtype, int64_t n_samples, double* state3, float* feat,
@@ -305,9 +388,13 @@ extern "C" int dsmi_features_stream(dsmi_frontend* f, const void* pcm, int dtype
     const int64_t host[2] = {0, n_samples};
     if (!fe_stage_copy(f, f->offs, &host[0], 1, s) || !fe_stage_copy(f, f->offs + f->cap, &host[1], 1, s))
         return bad(DSMI_ERR_HIP, "staging the chunk's offset / length failed");
-    const size_t lds = sizeof(double) * ((size_t)2 * f->n_fft + (size_t)f->n_fft * FT);
-    hipLaunchKernelGGL(stft_logmag_kernel, dim3(ceil_div(nfr, FT), 1), dim3(256), lds, s, pcm, dtype, f->offs, f->offs + f->cap,
-                       f->tw, f->win, f->n_fft, f->hop, f->n_freq, PAD_NONE, feat, t_stride);
+    if (stft_on_mfma(f->n_fft, dtype)) {
+        launch_stft_mfma(dim3(ceil_div(nfr, MF), 1), s, pcm, dtype, f->offs, f->offs + f->cap, f->tw, f->win, f->hop, PAD_NONE, feat, t_stride);
+    } else {
+        const size_t lds = sizeof(double) * ((size_t)2 * f->n_fft + (size_t)f->n_fft * FT);
+        hipLaunchKernelGGL(stft_logmag_kernel, dim3(ceil_div(nfr, FT), 1), dim3(256), lds, s, pcm, dtype, f->offs, f->offs + f->cap,
+                           f->tw, f->win, f->n_fft, f->hop, f->n_freq, PAD_NONE, feat, t_stride);
+    }
     double* stats_dev = nullptr;
     if (hipMalloc((void**)&stats_dev, 2 * sizeof(double)) != hipSuccess) return bad(DSMI_ERR_NOMEM, "hipMalloc failed");
     hipLaunchKernelGGL(chunk_stats_kernel, dim3(1), dim3(1024), 0, s, feat, f->n_freq, nfr, t_stride, stats_dev);
@@ -456,10 +543,14 @@ extern "C" int dsmi_features(dsmi_frontend* m, const void* pcm, int dtype, const
     }
     if (!fe_stage_copy(f, f->offs, host.data(), B, s) || !fe_stage_copy(f, f->offs + f->cap, host.data() + B, B, s))
         return bad(DSMI_ERR_HIP, "staging the clips' offsets / lengths failed");
-    const size_t lds = sizeof(double) * ((size_t)2 * m->n_fft + (size_t)m->n_fft * FT);
     EvPair ev;
-    DSMI_LAUNCH(stft_logmag_kernel, dim3(ceil_div(maxfr, FT), B), dim3(256), lds, s, ev, pcm, dtype, f->offs, f->offs + f->cap,
-                f->tw, f->win, m->n_fft, m->hop, m->n_freq, m->desc.pad_mode, feat, t_stride);
+    if (stft_on_mfma(m->n_fft, dtype)) {
+        launch_stft_mfma(dim3(ceil_div(maxfr, MF), B), s, pcm, dtype, f->offs, f->offs + f->cap, f->tw, f->win, m->hop, m->desc.pad_mode, feat, t_stride);
+    } else {
+        const size_t lds = sizeof(double) * ((size_t)2 * m->n_fft + (size_t)m->n_fft * FT);
+        DSMI_LAUNCH(stft_logmag_kernel, dim3(ceil_div(maxfr, FT), B), dim3(256), lds, s, ev, pcm, dtype, f->offs, f->offs + f->cap,
+                    f->tw, f->win, m->n_fft, m->hop, m->n_freq, m->desc.pad_mode, feat, t_stride);
+    }
     double* stats = reinterpret_cast<double*>(f->offs + 2 * (size_t)f->cap);       // [B][NSL][2] behind the offsets / lengths
     if (m->desc.normalize) {
         hipLaunchKernelGGL(clip_stats_kernel, dim3(NSL, B), dim3(1024), 0, s, feat, f->offs + f->cap, m->hop, m->n_freq, t_stride, stats);

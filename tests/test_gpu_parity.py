@@ -213,6 +213,29 @@ def test_features_window_and_pad_variants(native):
     fe.close()
 
 
+def test_features_both_stft_kernels(native):
+    """n_fft = 320 with float64 / float32 / int16 samples runs on the float64 matrix pipe (stft_mfma_kernel); every other window
+    length takes the direct kernel (stft_logmag_kernel): 8 kHz audio_conf -> n_fft = 160, against the oracle; and a clip whose frame
+    count is one past a 64-frame workgroup and a 16-frame tile of the matrix-pipe form."""
+    from oracle import features as of
+    clip = syn.make_clip(7, 30000)
+    n = np.array([len(clip)], dtype=np.int64)
+    fe = native.NativeFrontend(dict(sampling_rate=8000))
+    feat, fr = fe.features(_dev(clip), n)
+    ref = of.spectrogram(clip, sample_rate=8000)
+    assert fr[0] == ref.shape[1]
+    np.testing.assert_allclose(feat.cpu().numpy()[0, 0, :, :fr[0]], ref, rtol=0, atol=2e-5)
+    fe.close()
+    fe = native.NativeFrontend()
+    for ns in (64 * 160, 64 * 160 - 1, 80 * 160, 16 * 160 + 5):          # 65, 64, 81, 17 frames
+        c = syn.make_clip(8, ns)
+        feat, fr = fe.features(_dev(c), np.array([ns], dtype=np.int64))
+        ref = of.spectrogram(c)
+        assert fr[0] == ref.shape[1]
+        np.testing.assert_allclose(feat.cpu().numpy()[0, 0, :, :fr[0]], ref, rtol=0, atol=2e-5)
+    fe.close()
+
+
 @pytest.mark.parametrize("H,why,gen1_launches", [
     (904, "not a multiple of 16: first-generation persistent kernel, 10 k-pairs per wave", 1),
     (1200, "config 4 width: second generation, 75 workgroups x 2 directions, batch tiles walked in turn", None),

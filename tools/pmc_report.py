@@ -16,7 +16,7 @@ import sys
 KINDS = [("rnn_persist", "rnn_layer_persistent"), ("gemm_f16x3_kernel<true", "gemm_l0"), ("gemm_f16x3_kernel<false", "gemm"),
          ("gemm_f16x3_wide_kernel<true", "gemm_l0"), ("gemm_f16x3_wide_kernel<false", "gemm"),
          ("conv_f16x3_kernel", "conv2"), ("conv1_f16x3", "conv1"), ("conv_kernel<0>", "conv1"), ("head_kernel", "head"),
-         ("stft_logmag", "stft"), ("split_a_kernel", "split_a"), ("greedy_kernel", "greedy"), ("normalize_kernel", "normalize"),
+         ("stft_logmag", "stft"), ("stft_mfma", "stft"), ("split_a_kernel", "split_a"), ("greedy_kernel", "greedy"), ("normalize_kernel", "normalize"),
          ("clip_stats", "clip_stats")]
 
 

@@ -12,7 +12,7 @@ rows.sort()
 t0 = rows[0][0]
 def short(k):
     for key in ("rnn_persist_ring", "rnn_persist_duo", "rnn_persist16", "conv1_f16x3", "conv_f16x3", "gemm_f16x3_kernel<true>", "gemm_f16x3_kernel<false>",
-                "split_a_kernel", "stft_logmag", "normalize", "head_kernel", "greedy_kernel", "beam_kernel", "copyBuffer", "fillBuffer"):
+                "gemm_f16x3_wide_kernel<true", "gemm_f16x3_wide_kernel<false", "split_a_kernel", "stft_logmag", "stft_mfma", "normalize", "head_kernel", "greedy_kernel", "beam_kernel", "copyBuffer", "fillBuffer"):
         if key in k:
             return key
     return k[:40]
@@ -41,7 +41,7 @@ tot = sum(acc.values())
 print("persistent recurrent kernels running at the same time: " + ", ".join("%d: %.0f%%" % (k, 100.0 * v / tot) for k, v in sorted(acc.items())))
 # per queue: how long it stands idle between two forwards (from the end of a forward's last kernel to the next forward's first)
 for q, ks in sorted(by_q.items()):
-    starts = [i for i, (s_, e_, k) in enumerate(ks) if "stft_logmag" in k and lo <= s_ <= hi]
+    starts = [i for i, (s_, e_, k) in enumerate(ks) if ("stft_logmag" in k or "stft_mfma" in k) and lo <= s_ <= hi]
     if len(starts) < 2:
         continue
     idle, span = [], []

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void stft_logmag_kernel(const void* pcm, int d
 // The direct kernel above is bound by LDS bandwidth: every multiply-add reads its sample from LDS (a b128 per two), four SIMDs
 // against one LDS port -- a quarter of the float64 rate, and 95 of a workgroup's 256 lanes have no bin.  Here a wave OWNS a tile of 16
 // frames: their folded samples (even part e, odd part o, 81 k-steps of four taps) live in its registers as the MFMAs' B operands for
-// all eleven 16-bin tiles; the A operand is the twiddle of (bin, tap), read from a 5-KB table by index (bin * tap mod n_fft, carried
+// the ten 16-bin tiles of bins 0 .. 159 (bin 160 is a signed sum on the vector pipe); the A operand is the twiddle of (bin, tap), read from a 5-KB table by index (bin * tap mod n_fft, carried
 // by one add and one wrap per k-step).  D[bin][frame]: sixteen lanes of a result register are sixteen consecutive frames of one bin.
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 constexpr int MF = 64;   // frames per workgroup: four waves, one 16-frame tile each
@@ -190,7 +190,7 @@ template <int NFFT, typename T>          // T: double, float or int16_t samples 
 __global__ __launch_bounds__(256, 2) void stft_mfma_kernel(const T* pcm, const int64_t* offs, const int64_t* nsamp,
                                                            const double* tw, const double* win, int hop, int pad_mode, float* feat, int t_stride) {
     constexpr int NH = NFFT / 2, NFREQ = NH + 1, KO = NH / 4, KE = KO + 1;
-    static_assert(NH % 4 == 0, "taps in k-steps of four");
+    static_assert(NH % 16 == 0, "taps in k-steps of four, bins 0 .. NH - 1 in tiles of sixteen");
     __shared__ __attribute__((aligned(16))) double s_tw[2 * NFFT];     // [idx][cos, sin]
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int64_t N = nsamp[b], off = offs[b];
@@ -221,9 +221,21 @@ __global__ __launch_bounds__(256, 2) void stft_mfma_kernel(const T* pcm, const i
     }
     E[KO] = j == 0 ? xw(NH) : 0.0;
     __syncthreads();
+    if (t0 + wid * 16 >= nfr) return;                                   // a clip's last workgroup: tiles past its last frame
     const int to = t0 + wid * 16 + (lane & 15);
-    for (int bt = 0; bt < (NFREQ + 15) / 16; ++bt) {
-        const int bin = bt * 16 + (lane & 15);                         // A operand: lane holds (bin lane & 15, tap 4 ks + j); bins past NFREQ: not stored
+    // The last bin (k = NH) is a tile of its own for one bin: on the vector pipe instead.  cos(pi n) = (-1)^n and a lane's taps 4 ks + j
+    // share the parity of j: the lane's even parts summed, signed, and added across the four tap groups of a frame; the sine is zero.
+    {
+        double ny = 0.0;
+#pragma unroll
+        for (int ks = 0; ks < KE; ++ks) ny += E[ks];
+        ny = (j & 1) ? -ny : ny;
+        ny += __shfl_xor(ny, 16, 64);
+        ny += __shfl_xor(ny, 32, 64);
+        if (j == 0 && to < nfr) feat[((size_t)b * NFREQ + NH) * t_stride + to] = log1pf(fabsf((float)ny));
+    }
+    for (int bt = 0; bt < NH / 16; ++bt) {
+        const int bin = bt * 16 + (lane & 15);                         // A operand: lane holds (bin lane & 15, tap 4 ks + j)
         int idx = (bin * j) % NFFT;
         const int step = (4 * bin) % NFFT;
         f64x4 re = {0.0, 0.0, 0.0, 0.0}, im = {0.0, 0.0, 0.0, 0.0};
@@ -238,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void stft_mfma_kernel(const T* pcm, const i
 #pragma unroll
         for (int r = 0; r < 4; ++r) {                                   // D: column lane & 15 (frame), row (lane >> 4) + 4 r (bin of the tile)
             const int k = bt * 16 + (lane >> 4) + 4 * r;
-            if (k < NFREQ && to < nfr) feat[((size_t)b * NFREQ + k) * t_stride + to] = log1pf(hypotf((float)re[r], (float)im[r]));
+            if (to < nfr) feat[((size_t)b * NFREQ + k) * t_stride + to] = log1pf(hypotf((float)re[r], (float)im[r]));
         }
     }
 }

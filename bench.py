@@ -345,9 +345,7 @@ def main(argv=None):
     def run(steps):
         """`steps` batches through recognize_batches; the transcripts of every step gathered to rank 0."""
         out = None
-        # a LIST of batches: the call knows where its input ends and plans its last forwards (one per lane instead of merged pairs on half
-        # of the lanes: DanSpeechRecognizer.pipeline_balance_tail), as a caller transcribing a folder of files would hand it over
-        for res in rec.recognize_batches([host_clips] * steps):
+        for res in rec.recognize_batches(host_clips for _ in range(steps)):
             if world > 1:
                 with (torch.cuda.stream(gather_stream) if gather_stream is not None else contextlib.nullcontext()):
                     out = parallel.gather_texts(res, positions, B * world, cap, rank, world, dev)
@@ -364,8 +362,9 @@ def main(argv=None):
     warmup_done = max(args.warmup, 16 if not dry else 0)
     # warm-up in TWO calls: the second recognize_batches call of a process still pays a one-off, host-blocking first upload on each
     # replica lane (5.5 ms each, tools/exp/pipeline_fill_log.py, profiles/r05_fill_drain.txt); from the third call on none does
-    out = run(warmup_done // 2)
-    out = run(warmup_done - warmup_done // 2) or out
+    out = run(warmup_done)
+    out = run(warmup_done) or out
+    warmup_done *= 2
     if eng is not None:
         handles = [eng.model._native] + [r[0]._native for r in eng._replicas]
     if not args.no_kernel_sampling:

@@ -243,7 +243,6 @@ class DanSpeechRecognizer(object):
     # 16-clip tiles per workgroup, and its cost per clip falls with the tiles it walks)
     pipeline_lanes = 4
     pipeline_merge_clips = 64
-    pipeline_balance_tail = True
 
     def _lanes(self, count):
         """The model handles, parsers and streams of the pipeline's forwards in flight: the engine's own and `count - 1` replicas."""
@@ -279,10 +278,7 @@ class DanSpeechRecognizer(object):
         other mode ``batches`` is advanced on a HELPER THREAD (one, the same for the whole call), concurrently with the
         consumer's loop body: a source with thread-affine state (a GUI toolkit's objects, a thread-local CUDA stream of its own)
         must be wrapped accordingly or use the sequential mode.  Latency: with the defaults (four forwards of up to 64 clips in
-        flight and one staged) a result comes out eight to ten batches of 32 clips after its batch was read.  The END of the call: a
-        source with a length (a list of batches) has its last ``lanes`` batches run as one forward each, on every lane; a
-        generator is merged to its last batch and ends on half of the lanes (``pipeline_balance_tail``; 2 % of a 20-batch
-        call, profiles/r05_fill_drain.txt)."""
+        flight and one staged) a result comes out eight to ten batches of 32 clips after its batch was read."""
         import torch
         import collections
         auto_lanes = lanes is None
@@ -308,20 +304,12 @@ class DanSpeechRecognizer(object):
         end = object()
         source = iter(batches)
         held = [end, False]                      # a batch read from the source that did not fit the group being put together
-        # A source that knows its length (a list of batches) lets the call's END be planned: the last `lanes` batches are not
-        # merged -- one forward each, on every lane, instead of half as many 64-clip forwards on half of the lanes while the
-        # other lanes stand empty (pipeline_balance_tail; a generator's end is not known ahead: it is merged to its last batch).
-        left = [len(batches) if self.pipeline_balance_tail and hasattr(batches, "__len__") else None]
-        width = [lanes]                          # forwards in flight, once the lanes are set up
 
         def next_batch():
             if held[1]:
                 held[1] = False
                 return held[0]
-            got = next(source, end)
-            if got is not end and left[0] is not None:
-                left[0] -= 1
-            return got
+            return next(source, end)
 
         def fetch(parser):
             """The next forward: consecutive batches of one kind (host clips / device-resident clips) up to merge_clips clips.
@@ -330,8 +318,7 @@ class DanSpeechRecognizer(object):
             if first is end:
                 return None
             parts, total, on_device = [first], len(first), isinstance(first, DeviceClips)
-            tail = left[0] is not None and width[0] > 1 and left[0] + (1 if held[1] else 0) < width[0]     # with `first`: at most `lanes` batches to go
-            while total and total < merge_clips and not tail:
+            while total and total < merge_clips:
                 nxt = next_batch()
                 if nxt is end:
                     break
@@ -392,7 +379,6 @@ class DanSpeechRecognizer(object):
                 lanes = self._lanes_that_pay(lanes, sum(len(b) for b in group[0]))
             handles, parsers, streams = set_up(lanes)
             lanes = len(handles)
-            width[0] = lanes
             depth = lanes + 1 if searching else lanes
             while group is not None:
                 parts, merged, staged = group

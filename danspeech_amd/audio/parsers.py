@@ -122,8 +122,19 @@ class SpectrogramAudioParser(AudioParser):
             slot["done"].synchronize()                    # the upload issued two batches ago
         if getattr(self, "upload_on_compute_stream", False) and slot["used"] is not None:
             slot["used"].synchronize()                    # ... or the forward that uploaded from this buffer itself
-        if slot["buf"] is None or slot["buf"].numel() < nbytes:
-            slot["buf"] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8).pin_memory()
+        # Sized by the largest forward ANY parser of the process has staged, not by this slot's own history: a pipeline's lanes take
+        # forwards of different sizes in turn (merged pairs, single batches at a call's end), and a slot that met only small ones
+        # re-pinned 82 MB (16 ms on the staging thread, the device buffer and a blocking first upload behind it) in the middle of a
+        # later call, when its first large forward arrived (profiles/r05_fill_drain.txt).
+        cls = SpectrogramAudioParser
+        cls._stage_high = high = max(getattr(cls, "_stage_high", 1 << 20), nbytes)
+        if slot["buf"] is None or slot["buf"].numel() < high:
+            slot["buf"] = torch.empty(high, dtype=torch.uint8).pin_memory()
+        if slot["dev"] is not None and slot["dev"].numel() < high:
+            if slot["used"] is not None:
+                slot["used"].synchronize()   # the kernels that read the buffer being given back
+            slot["dev"] = None               # (re-made at `high` where it is next needed)
+        slot["high"] = high
         return slot
 
     def stage(self, recordings):
@@ -162,7 +173,7 @@ class SpectrogramAudioParser(AudioParser):
             # five streams in the process (no two on one hardware queue): one shared upload stream 7.33 ms per batch, one per parser
             # 7.58, this 5.89-5.98.
             if slot["dev"] is None or slot["dev"].numel() < nbytes:
-                slot["dev"] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device="cuda:%d" % self.device)
+                slot["dev"] = torch.empty(max(nbytes, slot["high"]), dtype=torch.uint8, device="cuda:%d" % self.device)
             return StagedClips(slot["buf"][:nbytes], n, dtype.itemsize, None, slot)
         if getattr(self, "share_copy_stream", False):
             up = _shared_copy_stream(self.device)
@@ -174,7 +185,7 @@ class SpectrogramAudioParser(AudioParser):
             # the slot's own device buffer (not a fresh allocation per batch: tens of megabytes allocated on the copy stream and
             # released on the compute stream go round the caching allocator's cross-stream bookkeeping every batch)
             if slot["dev"] is None or slot["dev"].numel() < nbytes:
-                slot["dev"] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device="cuda:%d" % self.device)
+                slot["dev"] = torch.empty(max(nbytes, slot["high"]), dtype=torch.uint8, device="cuda:%d" % self.device)
             if slot["used"] is not None:
                 up.wait_event(slot["used"])                  # the kernels that read this buffer two batches ago
             pcm = slot["dev"][:nbytes]

@@ -148,35 +148,6 @@ def test_sequential_mode_reads_a_batch_only_after_the_previous_result():
         assert seen == [want, want, want[:1], want, want]
 
 
-def test_a_list_of_batches_ends_with_one_forward_per_lane():
-    """A source that knows its length lets the call plan its end: the last ``lanes`` batches run as one forward each (every lane
-    busy) instead of merged pairs on half of the lanes; a generator is merged to its last batch.  Results are the same strings."""
-    from danspeech_amd import Recognizer
-    model, sd, cfg = _model("small", 64, 3, seed=12)
-    rec = Recognizer(model=model)
-    eng = rec.danspeech_recognizer
-    clips = [syn.make_clip(i, n) for i, n in enumerate([9000, 8000, 7000, 6000])]
-    want = rec.recognize_batch(clips)
-    sizes = []
-    inner = eng._enqueue_batch
-
-    def counting(recordings, *a, **k):
-        sizes.append(len(recordings))
-        return inner(recordings, *a, **k)
-    eng._enqueue_batch = counting
-    try:
-        for source, expect in (([clips] * 7, [8, 8, 4, 4, 4]), ((clips for _ in range(7)), [8, 8, 8, 4]), ([clips] * 2, [4, 4])):
-            del sizes[:]
-            assert list(eng.transcribe_batches(source, lanes=3, merge_clips=8)) == [want] * (7 if expect[0] == 8 else 2)
-            assert sizes == expect, (sizes, expect)
-        eng.pipeline_balance_tail = False
-        del sizes[:]
-        assert list(eng.transcribe_batches([clips] * 7, lanes=3, merge_clips=8)) == [want] * 7 and sizes == [8, 8, 8, 4]
-    finally:
-        eng._enqueue_batch = inner
-        eng.pipeline_balance_tail = True
-
-
 def test_wide_model_stream_of_batches_runs_clean():
     """Config 4's width (H = 1200: the tile-walking recurrent kernel, four tiles per workgroup) as a stream of 64-clip batches, with the
     forwards in flight the engine picks and with four: every batch equals the single call, and no hand-off of any handle timed out

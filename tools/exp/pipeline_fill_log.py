@@ -59,14 +59,25 @@ def timed_copy(self, *a, **k):
         log.append(("    copy_ %d bytes" % (self.numel() * self.element_size()), threading.current_thread().name[:12], (s - t0[0]) * 1e3, (e - t0[0]) * 1e3))
     return r
 torch.Tensor.copy_ = timed_copy
+# PIPE_WARM="8,8": the warm-up calls before every timed call (lists of that many batches; default one generator of 16);
+# PIPE_PROF=1: per-dispatch timestamps on (set_profiling(2)) as bench.py has them in its timed call;  PIPE_LIST=1: the timed call gets a list
+warm = [int(v) for v in os.environ.get("PIPE_WARM", "").split(",") if v]
 for rep in range(2):
-    for res in rec.recognize_batches(host for _ in range(16)):
-        pass
+    if warm:
+        for n in warm:
+            for res in rec.recognize_batches([host] * n):
+                pass
+    else:
+        for res in rec.recognize_batches(host for _ in range(16)):
+            pass
     torch.cuda.synchronize()
+    if os.environ.get("PIPE_PROF"):
+        for h in [eng.model._native] + [r[0]._native for r in eng._replicas]:
+            h.set_profiling(2); h.reset_kernel_stats()
     del log[:]
     t0[0] = time.perf_counter()
     outs = []
-    for res in rec.recognize_batches(host for _ in range(steps)):
+    for res in rec.recognize_batches([host] * steps if os.environ.get("PIPE_LIST") else (host for _ in range(steps))):
         outs.append((time.perf_counter() - t0[0]) * 1e3)
     torch.cuda.synchronize()
     total = (time.perf_counter() - t0[0]) * 1e3

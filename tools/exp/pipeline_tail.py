@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """The end of a short recognize_batches call: the last `lanes` batches of a LIST of batches as one forward each (pipeline_balance_tail)
 against merged to the end; ms for 20 (or argv[1]) batches of 32 x 10 s float64 host clips, cfgA, alternating, after two warm-up calls
-(a process's second call pays a one-off blocking upload per lane: pipeline_fill_log.py)."""
+(a process's second call pays a one-off blocking upload per lane: pipeline_fill_log.py).
+NOT ADOPTED (profiles/r05_fill_drain.txt): the switch exists in commit 0d2b105 only; on a later tree both rows measure the merged form."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch

@@ -36,6 +36,11 @@ EvPair timer_arm(dsmi_model* m, int kind, bool sample, double flops, double byte
     t.flops[kind] += flops;
     t.bytes[kind] += bytes;
     if (!sample) return ev;
+    // Every launch of the recurrent kernels is stamped (bench.py's roofline kernel: its mean duration is over ALL its launches of the timed
+    // region); of the other kinds every fourth -- a stamped launch is a hipExtLaunchKernelGGL with two events, and stamping all sixteen
+    // launches of every forward costs the four-lane pipeline 2 - 4 % of a 20-batch call (DSMI_DEBUG_SAMPLE_EVERY: experiments)
+    static const int every = [] { const char* e = std::getenv("DSMI_DEBUG_SAMPLE_EVERY"); const int v = e ? std::atoi(e) : 4; return v < 1 ? 1 : v; }();
+    if (kind != KK_PERSIST && kind != KK_STEP && (t.launches[kind] - 1) % every != 0) return ev;
     hipEvent_t e[2];
     for (int i = 0; i < 2; ++i) {
         if (!t.free_events.empty()) { e[i] = t.free_events.back(); t.free_events.pop_back(); }

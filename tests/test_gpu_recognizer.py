@@ -148,6 +148,28 @@ def test_sequential_mode_reads_a_batch_only_after_the_previous_result():
         assert seen == [want, want, want[:1], want, want]
 
 
+def test_staging_slots_are_sized_by_the_largest_forward_of_the_process():
+    """A lane's pinned staging slot that has met only small forwards must not re-pin in the middle of a later call when its first
+    large forward arrives (82 MB: 16 ms on the staging thread and a blocking upload behind it): every slot in use is as large as
+    the largest forward any parser of the process has staged."""
+    from danspeech_amd import Recognizer
+    from danspeech_amd.audio.parsers import SpectrogramAudioParser
+    model, sd, cfg = _model("small", 64, 3, seed=12)
+    rec = Recognizer(model=model)
+    eng = rec.danspeech_recognizer
+    big = [syn.make_clip(i, 20000) for i in range(8)]
+    small = big[:2]
+    want_big, want_small = rec.recognize_batch(big), rec.recognize_batch(small)
+    # three lanes, no merging: the large batch lands on lane 0 only, lanes 1 and 2 see small ones
+    outs = list(eng.transcribe_batches([big, small, small, small, small, small], lanes=3, merge_clips=0))
+    assert outs == [want_big] + [want_small] * 5
+    high = SpectrogramAudioParser._stage_high
+    assert high >= sum(len(c) for c in big) * 8
+    parsers = [eng.audio_parser] + [r[1] for r in eng._replicas]
+    used = [sl for p in parsers for sl in (getattr(p, "_slots", None) or []) if sl["buf"] is not None]
+    assert len(used) >= 4 and all(sl["buf"].numel() >= high for sl in used[1:]), [sl["buf"].numel() for sl in used]
+
+
 def test_wide_model_stream_of_batches_runs_clean():
     """Config 4's width (H = 1200: the tile-walking recurrent kernel, four tiles per workgroup) as a stream of 64-clip batches, with the
     forwards in flight the engine picks and with four: every batch equals the single call, and no hand-off of any handle timed out

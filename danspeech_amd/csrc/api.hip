@@ -610,6 +610,8 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
     if (use16 && m->rnn_kernel != 1 && (m->inflight >= 2 || B > 32 || m->rnn_kernel == 2)) {
         const int rcus = rnn_persist_ring_cus(m->geom16);
         ring_slots = rcus > 0 ? std::min(kRingSlots, m->n_cus / rcus) : 0;        // windows the device holds side by side
+        static const int slot_cap = [] { const char* e = std::getenv("DSMI_DEBUG_RING_SLOTS"); return e ? std::atoi(e) : 0; }();      // (experiments)
+        if (slot_cap >= 2 && ring_slots > slot_cap) ring_slots = slot_cap;
         const int cap = ring_slots >= 2 ? (m->ring8 ? rnn_persist_ring_tiles(m->geom16, B, rcus) : rnn_persist_ring4_tiles(m->geom16, B, rcus)) : 0;
         if (cap > 0) {
             const int ntiles = ceil_div(B, 16);

@@ -125,7 +125,8 @@ class SpectrogramAudioParser(AudioParser):
         # Sized by the largest forward ANY parser of the process has staged, not by this slot's own history: a pipeline's lanes take
         # forwards of different sizes in turn (merged pairs, single batches at a call's end), and a slot that met only small ones
         # re-pinned 82 MB (16 ms on the staging thread, the device buffer and a blocking first upload behind it) in the middle of a
-        # later call, when its first large forward arrived (profiles/r05_fill_drain.txt).
+        # later call, when its first large forward arrived (profiles/r05_fill_drain.txt).  (The mark never falls: slots made after one
+        # very large forward are all that large -- two per lane, pinned and on the device.)
         cls = SpectrogramAudioParser
         cls._stage_high = high = max(getattr(cls, "_stage_high", 1 << 20), nbytes)
         if slot["buf"] is None or slot["buf"].numel() < high:

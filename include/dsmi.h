@@ -231,6 +231,7 @@ int dsmi_greedy_collect(dsmi_decoder* d, int32_t* ids_host, int32_t* offsets_hos
  * level 0: off.  level 1: per-stage hipEvents around the last dsmi_forward (synchronises).
  * level 2: sampled launches of each kernel kind are dispatched with their own begin/end
  * timestamps (hipExtLaunchKernelGGL), fully asynchronous; read back with dsmi_kernel_stats.
+ * Sampled = every launch of the recurrent kinds (6, 10), every fourth of the others.
  * stage for dsmi_stage_time_us: 0 conv, 2 input GEMMs + recurrent steps, 3 head, 4 total. */
 int dsmi_set_profiling(dsmi_model* m, int level);
 /* kind: 0 stft, 1 conv1, 2 conv2, 3 conv3, 4 layer-0 input GEMM, 5 input GEMM (layers >= 1),

@@ -180,17 +180,17 @@ __global__ __launch_bounds__(256) void stft_logmag_kernel(const void* pcm, int d
 // the frame, a quiet bin 50 dB below it is then off by 5e-4 in log1p -- measured, profiles/r05_stft_forms.txt).
 // The direct kernel above is bound by LDS bandwidth: every multiply-add reads its sample from LDS (a b128 per two), four SIMDs
 // against one LDS port -- a quarter of the float64 rate, and 95 of a workgroup's 256 lanes have no bin.  Here a wave OWNS a tile of 16
-// frames: their folded samples (even part e, odd part o, 81 k-steps of four taps) live in its registers as the MFMAs' B operands for
-// the ten 16-bin tiles of bins 0 .. 159 (bin 160 is a signed sum on the vector pipe); the A operand is the twiddle of (bin, tap), read from a 5-KB table by index (bin * tap mod n_fft, carried
-// by one add and one wrap per k-step).  D[bin][frame]: sixteen lanes of a result register are sixteen consecutive frames of one bin.
+// frames: their twice-folded samples (four sequences of 20 or 21 k-steps of four taps: see the kernel) live in its registers as the
+// MFMAs' B operands for the five tiles of even and the five of odd bins below 160 (bin 160 is a signed sum on the vector pipe); the A
+// operand is the twiddle of (bin, tap), read from a 5-KB table by index (bin * tap mod n_fft, carried by one add and one wrap per k-step).  D[bin][frame]: sixteen lanes of a result register are sixteen consecutive frames of one bin.
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 constexpr int MF = 64;   // frames per workgroup: four waves, one 16-frame tile each
 
 template <int NFFT, typename T>          // T: double, float or int16_t samples (one channel); the other WAV-frame types take the direct kernel
 __global__ __launch_bounds__(256, 2) void stft_mfma_kernel(const T* pcm, const int64_t* offs, const int64_t* nsamp,
                                                            const double* tw, const double* win, int hop, int pad_mode, float* feat, int t_stride) {
-    constexpr int NH = NFFT / 2, NFREQ = NH + 1, KO = NH / 4, KE = KO + 1;
-    static_assert(NH % 16 == 0, "taps in k-steps of four, bins 0 .. NH - 1 in tiles of sixteen");
+    constexpr int NH = NFFT / 2, NQ = NFFT / 4, NFREQ = NH + 1, KQ = NQ / 4;       // NQ taps after the second fold: KQ k-steps of four (+ 1)
+    static_assert(NQ % 16 == 0, "taps in k-steps of four; even and odd bins in tiles of sixteen each");
     __shared__ __attribute__((aligned(16))) double s_tw[2 * NFFT];     // [idx][cos, sin]
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int64_t N = nsamp[b], off = offs[b];
@@ -202,8 +202,6 @@ __global__ __launch_bounds__(256, 2) void stft_mfma_kernel(const T* pcm, const i
     const int half = centred ? NH : 0;
     const int t = t0 + wid * 16 + (lane & 15), j = lane >> 4;          // B operand: lane holds (tap 4 ks + j, frame lane & 15)
     const bool live = t < nfr;
-    // x[n] and x[NFFT - n] meet the same cosine and opposite sines: e[n] = x[n] + x[NFFT - n], o[n] = x[n] - x[NFFT - n] (n = 1 .. NH - 1),
-    // e[0] = x[0], e[NH] = x[NH]
     auto xw = [&](int n) -> double {                                    // windowed sample n of this lane's frame
         int64_t sidx = (int64_t)t * hop + n - half;
         bool ok = live;
@@ -211,47 +209,68 @@ __global__ __launch_bounds__(256, 2) void stft_mfma_kernel(const T* pcm, const i
         else if (sidx >= N) { sidx = 2 * (N - 1) - sidx; ok = ok && pad_mode == DSMI_PAD_REFLECT; }
         return ok ? (double)pcm[off + sidx] * win[n] : 0.0;
     };
-    double E[KE], O[KO];
+    // Two folds.  (1) x[n] and x[NFFT - n] meet the same cosine and opposite sines: e[n] = x[n] + x[NFFT - n], o[n] = x[n] - x[NFFT - n]
+    // (n = 1 .. NH - 1), e[0] = x[0], e[NH] = x[NH]; re[k] = sum_{n <= NH} e[n] cos(2 pi k n / NFFT), im[k] = sum o[n] sin(...).
+    // (2) tap NH - n meets (-1)^k times tap n's cosine and -(-1)^k times its sine, so even and odd bins see different halves:
+    //        even k:  re = sum_{n <= NQ} F[n] cos,  F[n] = e[n] + e[NH - n] (F[NQ] = e[NQ]);   im = sum_{n < NQ} P[n] sin,  P[n] = o[n] - o[NH - n]
+    //        odd k:   re = sum_{n <  NQ} G[n] cos,  G[n] = e[n] - e[NH - n];                   im = sum_{n <= NQ} Q[n] sin, Q[n] = o[n] + o[NH - n] (Q[NQ] = o[NQ])
+    // A quarter of the direct transform's multiply-adds; the twiddle of (bin, tap) is the same table entry (k n mod NFFT) in all four.
+    double F[KQ + 1], G[KQ], P[KQ], Q[KQ + 1];
 #pragma unroll
-    for (int ks = 0; ks < KO; ++ks) {
-        const int n = 4 * ks + j;
-        const double a = xw(n), c = n == 0 ? 0.0 : xw(NFFT - n);
-        E[ks] = a + c;
-        O[ks] = n == 0 ? 0.0 : a - c;
+    for (int ks = 0; ks < KQ; ++ks) {
+        const int n = 4 * ks + j;                                       // 0 .. NQ - 1
+        const double x0 = xw(n), x1 = n == 0 ? 0.0 : xw(NFFT - n), x2 = xw(NH - n), x3 = n == 0 ? 0.0 : xw(NH + n);
+        const double en = x0 + x1, em = n == 0 ? x2 : x2 + x3;          // e[n], e[NH - n]   (e[NH] = x[NH])
+        const double on = n == 0 ? 0.0 : x0 - x1, om = n == 0 ? 0.0 : x2 - x3;      // o[n], o[NH - n]   (o[0] = o[NH] = 0)
+        F[ks] = en + em; G[ks] = en - em;
+        P[ks] = on - om; Q[ks] = on + om;
     }
-    E[KO] = j == 0 ? xw(NH) : 0.0;
+    {
+        const double xa = j == 0 ? xw(NQ) : 0.0, xb = j == 0 ? xw(NFFT - NQ) : 0.0;      // tap NQ: lane group 0 of the last k-step
+        F[KQ] = xa + xb; Q[KQ] = xa - xb;
+    }
     __syncthreads();
     if (t0 + wid * 16 >= nfr) return;                                   // a clip's last workgroup: tiles past its last frame
     const int to = t0 + wid * 16 + (lane & 15);
-    // The last bin (k = NH) is a tile of its own for one bin: on the vector pipe instead.  cos(pi n) = (-1)^n and a lane's taps 4 ks + j
-    // share the parity of j: the lane's even parts summed, signed, and added across the four tap groups of a frame; the sine is zero.
+    // The last bin (k = NH, even) would be a tile of its own: on the vector pipe instead.  cos(pi n) = (-1)^n and a lane's taps 4 ks + j
+    // share the parity of j: the lane's F summed, signed, and added across the four tap groups of a frame; the sine is zero.
     {
         double ny = 0.0;
 #pragma unroll
-        for (int ks = 0; ks < KE; ++ks) ny += E[ks];
+        for (int ks = 0; ks <= KQ; ++ks) ny += F[ks];
         ny = (j & 1) ? -ny : ny;
         ny += __shfl_xor(ny, 16, 64);
         ny += __shfl_xor(ny, 32, 64);
         if (j == 0 && to < nfr) feat[((size_t)b * NFREQ + NH) * t_stride + to] = log1pf(fabsf((float)ny));
     }
-    for (int bt = 0; bt < NH / 16; ++bt) {
-        const int bin = bt * 16 + (lane & 15);                         // A operand: lane holds (bin lane & 15, tap 4 ks + j)
+    auto tile = [&](int bt, auto odd_tag) {                             // bins 2 (16 bt + i) (+ 1), i = 0 .. 15
+        constexpr int ODD = decltype(odd_tag)::value;
+        const int bin = 2 * (bt * 16 + (lane & 15)) + ODD;              // A operand: lane holds (bin of row lane & 15, tap 4 ks + j)
         int idx = (bin * j) % NFFT;
         const int step = (4 * bin) % NFFT;
         f64x4 re = {0.0, 0.0, 0.0, 0.0}, im = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int ks = 0; ks < KE; ++ks) {
+        for (int ks = 0; ks <= KQ; ++ks) {
             const double2 cs = *reinterpret_cast<const double2*>(&s_tw[2 * idx]);
-            re = __builtin_amdgcn_mfma_f64_16x16x4f64(cs.x, E[ks], re, 0, 0, 0);
-            if (ks < KO) im = __builtin_amdgcn_mfma_f64_16x16x4f64(cs.y, O[ks], im, 0, 0, 0);
+            if (ODD) {
+                if (ks < KQ) re = __builtin_amdgcn_mfma_f64_16x16x4f64(cs.x, G[ks], re, 0, 0, 0);
+                im = __builtin_amdgcn_mfma_f64_16x16x4f64(cs.y, Q[ks], im, 0, 0, 0);
+            } else {
+                re = __builtin_amdgcn_mfma_f64_16x16x4f64(cs.x, F[ks], re, 0, 0, 0);
+                if (ks < KQ) im = __builtin_amdgcn_mfma_f64_16x16x4f64(cs.y, P[ks], im, 0, 0, 0);
+            }
             idx += step;
             idx = idx >= NFFT ? idx - NFFT : idx;
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {                                   // D: column lane & 15 (frame), row (lane >> 4) + 4 r (bin of the tile)
-            const int k = bt * 16 + (lane >> 4) + 4 * r;
+            const int k = 2 * (bt * 16 + (lane >> 4) + 4 * r) + ODD;
             if (to < nfr) feat[((size_t)b * NFREQ + k) * t_stride + to] = log1pf(hypotf((float)re[r], (float)im[r]));
         }
+    };
+    for (int bt = 0; bt < NQ / 16; ++bt) {
+        tile(bt, std::integral_constant<int, 0>{});
+        tile(bt, std::integral_constant<int, 1>{});
     }
 }
 

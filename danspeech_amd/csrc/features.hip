@@ -186,7 +186,8 @@ __global__ __launch_bounds__(256) void stft_logmag_kernel(const void* pcm, int d
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 constexpr int MF = 64;   // frames per workgroup: four waves, one 16-frame tile each
 
-template <int NFFT, typename T>          // T: double, float or int16_t samples (one channel); the other WAV-frame types take the direct kernel
+// SKIP (timing experiments, DSMI_DEBUG_STFT_SKIP; results are garbage): 1 no hypotf / log1pf, 2 no MFMAs, 4 no sample / window loads
+template <int NFFT, typename T, int SKIP = 0>          // T: double, float or int16_t samples (one channel); the other WAV-frame types take the direct kernel
 __global__ __launch_bounds__(256, 2) void stft_mfma_kernel(const T* pcm, const int64_t* offs, const int64_t* nsamp,
                                                            const double* tw, const double* win, int hop, int pad_mode, float* feat, int t_stride) {
     constexpr int NH = NFFT / 2, NQ = NFFT / 4, NFREQ = NH + 1, KQ = NQ / 4;       // NQ taps after the second fold: KQ k-steps of four (+ 1)
@@ -207,6 +208,7 @@ __global__ __launch_bounds__(256, 2) void stft_mfma_kernel(const T* pcm, const i
         bool ok = live;
         if (sidx < 0) { sidx = -sidx; ok = ok && pad_mode == DSMI_PAD_REFLECT; }
         else if (sidx >= N) { sidx = 2 * (N - 1) - sidx; ok = ok && pad_mode == DSMI_PAD_REFLECT; }
+        if (SKIP & 4) return ok ? (double)(sidx & 255) * (double)(n + 1) : 0.0;
         return ok ? (double)pcm[off + sidx] * win[n] : 0.0;
     };
     // Two folds.  (1) x[n] and x[NFFT - n] meet the same cosine and opposite sines: e[n] = x[n] + x[NFFT - n], o[n] = x[n] - x[NFFT - n]
@@ -252,7 +254,8 @@ __global__ __launch_bounds__(256, 2) void stft_mfma_kernel(const T* pcm, const i
 #pragma unroll
         for (int ks = 0; ks <= KQ; ++ks) {
             const double2 cs = *reinterpret_cast<const double2*>(&s_tw[2 * idx]);
-            if (ODD) {
+            if (SKIP & 2) { re[0] += cs.x * (ks < KQ ? G[ks] : 0.0) + F[ks]; im[0] += cs.y * Q[ks] + (ks < KQ ? P[ks] : 0.0); }
+            else if (ODD) {
                 if (ks < KQ) re = __builtin_amdgcn_mfma_f64_16x16x4f64(cs.x, G[ks], re, 0, 0, 0);
                 im = __builtin_amdgcn_mfma_f64_16x16x4f64(cs.y, Q[ks], im, 0, 0, 0);
             } else {
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void stft_mfma_kernel(const T* pcm, const i
 #pragma unroll
         for (int r = 0; r < 4; ++r) {                                   // D: column lane & 15 (frame), row (lane >> 4) + 4 r (bin of the tile)
             const int k = 2 * (bt * 16 + (lane >> 4) + 4 * r) + ODD;
-            if (to < nfr) feat[((size_t)b * NFREQ + k) * t_stride + to] = log1pf(hypotf((float)re[r], (float)im[r]));
+            if (to < nfr) feat[((size_t)b * NFREQ + k) * t_stride + to] = (SKIP & 1) ? (float)re[r] + (float)im[r] : log1pf(hypotf((float)re[r], (float)im[r]));
         }
     };
     for (int bt = 0; bt < NQ / 16; ++bt) {
@@ -390,6 +393,12 @@ bool stft_on_mfma(int n_fft, int dtype) {
 
 void launch_stft_mfma(dim3 grid, hipStream_t s, const void* pcm, int dtype, const int64_t* offs, const int64_t* nsamp, const double* tw,
                       const double* win, int hop, int pad_mode, float* feat, int t_stride) {
+    static const int skip = [] { const char* e = std::getenv("DSMI_DEBUG_STFT_SKIP"); return e ? std::atoi(e) : 0; }();
+    if (skip && dtype == DSMI_PCM_F64) {
+#define STFT_SKIP(S) case S: hipLaunchKernelGGL((stft_mfma_kernel<320, double, S>), grid, dim3(256), 0, s, (const double*)pcm, offs, nsamp, tw, win, hop, pad_mode, feat, t_stride); return;
+        switch (skip) { STFT_SKIP(1) STFT_SKIP(2) STFT_SKIP(4) STFT_SKIP(3) STFT_SKIP(6) STFT_SKIP(7) default: break; }
+#undef STFT_SKIP
+    }
     if (dtype == DSMI_PCM_F64) hipLaunchKernelGGL((stft_mfma_kernel<320, double>), grid, dim3(256), 0, s, (const double*)pcm, offs, nsamp, tw, win, hop, pad_mode, feat, t_stride);
     else if (dtype == DSMI_PCM_F32) hipLaunchKernelGGL((stft_mfma_kernel<320, float>), grid, dim3(256), 0, s, (const float*)pcm, offs, nsamp, tw, win, hop, pad_mode, feat, t_stride);
     else hipLaunchKernelGGL((stft_mfma_kernel<320, int16_t>), grid, dim3(256), 0, s, (const int16_t*)pcm, offs, nsamp, tw, win, hop, pad_mode, feat, t_stride);

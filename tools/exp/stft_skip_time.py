@@ -20,7 +20,7 @@ for _ in range(20): feat, fr = fe.features(pcm, n)
 ev[1].record(); torch.cuda.synchronize()
 print("%%.0f" %% (ev[0].elapsed_time(ev[1]) * 1000 / 20))
 ''' % root
-for skip, what in ((0, "the kernel"), (1, "no hypotf / log1pf"), (2, "no MFMAs"), (4, "no sample / window loads"), (3, "loads only (+ stores)"),
-                   (6, "epilogue only"), (7, "stores only")):
+for skip, what in ((0, "the kernel"), (1, "no hypotf / log1pf"), (2, "MFMAs -> f64 vector ops (slower: says nothing)"), (4, "no sample / window loads"), (3, "no epilogue, MFMAs -> vector ops"),
+                   (6, "no loads, MFMAs -> vector ops"), (7, "stores + vector ops only")):
     r = subprocess.run([sys.executable, "-c", child], env=dict(os.environ, DSMI_DEBUG_STFT_SKIP=str(skip)), capture_output=True, text=True)
-    print("%-28s %s us per dsmi_features call" % (what, r.stdout.strip() or r.stderr.strip()[-300:]), flush=True)
+    print("%-48s %s us per dsmi_features call" % (what, r.stdout.strip() or r.stderr.strip()[-300:]), flush=True)

@@ -7,7 +7,9 @@
 // |.| and log1p then run in float32.  The kernel keeps that precision ladder: the DFT sums
 // are float64 (direct O(n_fft^2) DFT against a host-computed float64 twiddle table: 161 bins
 // x 320 taps, far below an FFT's break-even on this machine and free of any library), the
-// real/imaginary parts are rounded to float32, then hypotf and log1pf.
+// real/imaginary parts are rounded to float32, then hypotf and log1pf.  Since round 5 the shipped window length (320) with
+// float64 / float32 / int16 samples runs the same float64 sums on the matrix pipe (stft_mfma_kernel below: v_mfma_f64_16x16x4_f64,
+// the frame folded twice); the direct kernel serves every other window length and the WAV-frame sample types.
 // Mean and unbiased std are accumulated in float64 per clip (two passes, fixed order).
 #include "common.h"
 #include "host_logic.h"

@@ -45,7 +45,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # as danspeech_amd/__init__.py: one hardware queue per stream of the pipeline
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # one hardware queue per stream of the pipeline (the engine asks for the same: _native.want_hw_queues)
 
 # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 PEAK_F32_MFMA_TFLOPS = 157.3
@@ -248,6 +248,8 @@ def main(argv=None):
                     help="profiling only: time the device-resident entry instead of the metric's host-array entry (the line says so)")
     ap.add_argument("--strict-f32-child", action="store_true", help=argparse.SUPPRESS)     # the f32_strict side run (a fresh process)
     ap.add_argument("--abi-child", action="store_true", help=argparse.SUPPRESS)            # the abi_path side run (a fresh process)
+    ap.add_argument("--other-config-child", type=int, default=0, help=argparse.SUPPRESS)   # one of other_configs (a fresh process)
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the side runs of BASELINE.json configs 3, 4 and 5's per-GPU share")
     ap.add_argument("--no-kernel-sampling", action="store_true")
     ap.add_argument("--lanes", type=int, default=None, help="experiments: forwards in flight (default: the engine's own choice; the line says what ran)")
     ap.add_argument("--steady-steps", type=int, default=384, help="steps of the steady_state side run (at least 96)")
@@ -256,6 +258,9 @@ def main(argv=None):
 
     if args.gpus > 1 and "RANK" not in os.environ:
         raise SystemExit(launch_ranks(args.gpus, argv))
+    if args.other_config_child:
+        print(json.dumps(other_config(args.other_config_child)), flush=True)
+        return 0
 
     import torch
     import torch.distributed as dist
@@ -495,6 +500,8 @@ def main(argv=None):
         failed = failed or not result["abi_path"]["same_strings_as_timed_path"]
         if not args.strict_f32_child:
             result["f32_strict"] = f32_strict_child(args)
+        if not args.strict_f32_child and not args.no_other_configs:
+            result["other_configs"] = other_configs_children()
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
@@ -567,6 +574,77 @@ def device_resident(rec, clips, host_clips, B, n_samples, steps, timed_strings):
             "entry": "Recognizer.recognize_batches(DeviceClips): float64 PCM resident in HBM -> strings on the host",
             "unpipelined_host_arrays_ms_per_step": round(dt1 * 1e3, 3),
             "same_strings_as_timed_path": bool(timed_strings is not None and res == timed_strings and one == timed_strings)}
+
+
+# BASELINE.json configs 3-5 as side figures of the line (never `value`): SURVEY 8(d) shapes, synthetic weights, a seeded synthetic ARPA
+# language model built in a temporary directory (the DSL .klm files are unobtainable offline).  flops = SURVEY 8(d)'s algorithmic
+# figure per clip (cfgA 10 s 51.85, cfgB 10 s 132.9, cfgA 30 s 155.4 GFLOP).
+OTHER_CONFIGS = {
+    3: dict(key="config3", what="BASELINE.json configs[2]: cfgA (5 x BiGRU 800) + 3-gram, CTC beam 64, batch 32 x 10 s",
+            hidden=800, layers=5, lm_order=3, beam=64, alpha=1.3, beta=0.2, batch=32, seconds=10.0, gflop_per_clip=51.85, warm=32, steps=96),
+    4: dict(key="config4", what="BASELINE.json configs[3]: 7 x BiGRU 1200 + 5-gram, CTC beam 128, batch 64 x 10 s",
+            hidden=1200, layers=7, lm_order=5, beam=128, alpha=1.3, beta=0.2, batch=64, seconds=10.0, gflop_per_clip=132.9, warm=12, steps=24),
+    5: dict(key="config5_share", what="BASELINE.json configs[4], ONE GPU's share of 1024 x 30 s over 8 GPUs: cfgA + 3-gram, CTC beam 64, "
+            "batches of 128 x 30 s", hidden=800, layers=5, lm_order=3, beam=64, alpha=1.3, beta=0.2, batch=128, seconds=30.0,
+            gflop_per_clip=155.4, warm=6, steps=12),
+}
+
+
+def other_config(no):
+    """One of OTHER_CONFIGS through the metric's entry (Recognizer.recognize_batches, float64 host arrays -> every clip's best beam as a
+    string), as a stream of batches; in a process of its own (see abi_path_child on streams and hardware queues)."""
+    import contextlib
+    import io
+    import tempfile
+    import torch
+    from danspeech_amd import Recognizer, synthetic as syn
+    from danspeech_amd.deepspeech.model import DeepSpeech
+    c = OTHER_CONFIGS[no]
+    sd = syn.make_state_dict(2, "gru", c["hidden"], c["layers"], seed=0, **syn.TALKATIVE)
+    model = DeepSpeech("cfg", rnn_hidden_size=c["hidden"], rnn_layers=c["layers"], conv_layers=2).load_state_dict(sd)
+    with tempfile.TemporaryDirectory() as td, contextlib.redirect_stdout(io.StringIO()):
+        rec = Recognizer(model=model)
+        lm = os.path.join(td, "syn%d.arpa" % c["lm_order"])
+        syn.make_arpa(lm, order=c["lm_order"], n_words=5000, seed=11, ngrams_per_order=20000)
+        rec.update_decoder(lm=lm, alpha=c["alpha"], beta=c["beta"], beam_width=c["beam"])
+        B, n = c["batch"], int(c["seconds"] * 16000)
+        clips = [syn.make_clip(i, n) for i in range(B)]
+        one = rec.recognize_batch(clips)
+        for _ in range(2):                       # two warm-up calls: every lane's workspaces, staging slots and decoder slots exist
+            for res in rec.recognize_batches([clips] * c["warm"]):
+                pass
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        same = True
+        for res in rec.recognize_batches([clips] * c["steps"]):
+            same = same and res == one
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / c["steps"]
+    eng = rec.danspeech_recognizer
+    handles = [eng.model._native] + [r[0]._native for r in eng._replicas]
+    tflop = c["gflop_per_clip"] * B / 1e3
+    return {"workload": c["what"], "ms_per_batch": round(dt * 1e3, 3), "audio_s_per_s": round(B * c["seconds"] / dt, 1), "steps": c["steps"],
+            "whole_step_tflops": round(tflop / dt, 1), "whole_step_frac": round(tflop / dt / PEAK_SPLIT_TFLOPS, 4),
+            "forwards_in_flight": len(handles), "clips_per_forward": min(B, eng.pipeline_merge_clips),
+            "recomputed_batches": sum(h.recompute_count() for h in handles),
+            "every_batch_equals_the_single_call": bool(same), "sample_transcript_len": len(one[0]),
+            "lm": "synthetic %d-gram ARPA, 5000 words (danspeech_amd.synthetic.make_arpa, seed 11)" % c["lm_order"]}
+
+
+def other_configs_children():
+    """other_config(3 | 4 | 5), each in a fresh process (this one keeps the persistent kernels' per-device lock: DSMI_PERSIST_SHARED)."""
+    import subprocess
+    res = {"note": "side figures, never `value`: the other BASELINE.json configs through Recognizer.recognize_batches (host arrays in, best "
+                   "beam per clip out) as a stream of batches; whole_step_frac = SURVEY 8(d) algorithmic FLOPs per batch / time / 833 TFLOP/s"}
+    env = dict(os.environ, DSMI_PERSIST_SHARED="1")
+    for no, c in sorted(OTHER_CONFIGS.items()):
+        try:
+            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--other-config-child", str(no)], env=env, capture_output=True,
+                                 text=True, timeout=600)
+            res[c["key"]] = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        except Exception as e:      # (a side figure: reported as failed, the line still comes out)
+            res[c["key"]] = {"ms_per_batch": None, "error": repr(e)[:300]}
+    return res
 
 
 def f32_strict_child(args):

@@ -92,6 +92,8 @@ class DanSpeechRecognizer(object):
 
     def __init__(self, model_name=None, lm_name=None, alpha=1.3, beta=0.2, with_gpu=False, beam_width=64):
         import torch
+        from . import _native
+        _native.want_hw_queues(8)          # one hardware queue per stream of the batch pipeline, if the runtime can still be told
         self.device = torch.device("cuda")
         print("Using device: {0}".format(self.device))
         self.lm = None
@@ -266,6 +268,52 @@ class DanSpeechRecognizer(object):
         return most if ring and clips <= 64 else min(most, 2)
 
     def transcribe_batches(self, batches, show_all=False, lanes=None, merge_clips=None):
+        """Generator over ``transcribe_batch(b)`` for every ``b`` of ``batches`` through the pipeline of ``_transcribe_forwards``
+        (read its docstring for ``lanes`` / ``merge_clips``, the read-ahead and the helper thread).  What this layer adds: a
+        caller's batch of MORE than ``merge_clips`` clips is cut into forwards of at most that many -- longest clips first, so
+        that a forward's clips are of a kind -- and its results are put back in the caller's order: the recurrent kernel's cost
+        per clip is lowest at four 16-clip tiles per window, and four forwards of 64 clips side by side fill the chip where two
+        of 128 leave it to one recurrent window at a time (config 5's share, 128 x 30 s: DESIGN.md 6)."""
+        import collections
+        merge = self.pipeline_merge_clips if merge_clips is None else int(merge_clips)
+        shapes = collections.deque()          # per caller batch: None (handed through) or (clips, [caller positions of piece k])
+
+        def pieces():
+            for b in batches:
+                n = len(b)
+                if merge <= 0 or n <= merge:
+                    shapes.append(None)
+                    yield b
+                    continue
+                if isinstance(b, DeviceClips):       # longest first already: consecutive parts
+                    cuts = [np.arange(lo, min(lo + merge, n)) for lo in range(0, n, merge)]
+                    parts = [b.part(int(c[0]), int(c[-1]) + 1) for c in cuts]
+                else:
+                    order = np.argsort([-len(r) for r in b], kind="stable")
+                    cuts = [order[lo:lo + merge] for lo in range(0, n, merge)]
+                    parts = [[b[i] for i in c] for c in cuts]
+                shapes.append((n, cuts))
+                for part in parts:
+                    yield part
+
+        inner = self._transcribe_forwards(pieces(), show_all=show_all, lanes=lanes, merge_clips=merge_clips)
+        try:
+            for res in inner:
+                shape = shapes.popleft()
+                if shape is None:
+                    yield res
+                    continue
+                n, cuts = shape
+                whole = [None] * n
+                for k, cut in enumerate(cuts):
+                    part = res if k == 0 else next(inner)
+                    for pos, i in enumerate(cut):
+                        whole[int(i)] = part[pos]
+                yield whole
+        finally:
+            inner.close()
+
+    def _transcribe_forwards(self, batches, show_all=False, lanes=None, merge_clips=None):
         """Generator over ``transcribe_batch(b)`` for every ``b`` of ``batches``, software-pipelined: consecutive batches are
         merged into forwards of up to ``merge_clips`` clips (per-clip results do not depend on the batch they run in), and up to
         ``lanes`` forwards are in flight (default: ``pipeline_lanes``, or two where more do not pay: ``_lanes_that_pay``), each

@@ -8,11 +8,8 @@ import os
 import shutil
 import warnings
 
-# The batch pipeline keeps four forwards in flight on four streams beside a decode and an upload stream; the ROCm runtime maps
-# streams onto FOUR hardware queues by default, and two streams that share one run one after the other (a forward's persistent
-# recurrent kernel behind another forward's dense kernels: 9.7 against 5.9 ms per batch, tools/exp/pipeline_lanes.py).  Read by
-# the runtime when it initialises, i.e. at the first GPU call of the process; a value the caller has set is kept.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# (Importing the package changes nothing in the process: the one runtime setting the batch pipeline wants, GPU_MAX_HW_QUEUES, is
+# asked for when an engine is made -- _native.want_hw_queues.)
 
 
 class NoDefaultCacheDirForDanspeech(Warning):

@@ -11,7 +11,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdsmi.so")
+# DSMI_LIBRARY: another build of the same ABI -- tools/exp/ load lib/libdsmi_exp.so (`make -C danspeech_amd/csrc exp`: the timing
+# instantiations and A/B switches that libdsmi.so does not carry)
+LIB_PATH = os.environ.get("DSMI_LIBRARY") or os.path.join(_HERE, "lib", "libdsmi.so")
 
 RNN_TYPES = {"gru": 0, "lstm": 1, "rnn": 2}
 WINDOWS = {"hamming": 0, "hann": 1, "blackman": 2, "bartlett": 3}
@@ -141,6 +143,37 @@ def declared_symbols():
     return sorted(_PROTOS)
 
 
+_hw_queue_note = [False]
+
+
+def want_hw_queues(n=8):
+    """The batch pipeline keeps four forwards in flight on four streams beside a decode stream; the ROCm runtime maps a process's
+    streams onto FOUR hardware queues by default, and two streams that share one run one after the other (a forward's persistent
+    recurrent kernel behind another forward's dense kernels: 9.7 against 5.9 ms per batch, tools/exp/pipeline_lanes.py).  The
+    runtime reads GPU_MAX_HW_QUEUES once, at the process's first GPU call: an engine asks for ``n`` when it is made
+    (``DanSpeechRecognizer.__init__``), which takes effect if nothing has touched the GPU yet; a value the caller has set is kept;
+    otherwise one warning says what the pipeline will cost."""
+    if os.environ.get("GPU_MAX_HW_QUEUES"):
+        return
+    touched = _lib is not None and _handles[0] > 0
+    try:
+        import torch
+        touched = touched or torch.cuda.is_initialized()
+    except ImportError:
+        pass
+    if not touched:
+        os.environ["GPU_MAX_HW_QUEUES"] = str(n)
+    elif not _hw_queue_note[0]:
+        _hw_queue_note[0] = True
+        import warnings
+        warnings.warn("danspeech_amd: the GPU runtime was initialised before the recognizer was made and GPU_MAX_HW_QUEUES is not set: "
+                      "the batch pipeline's streams will share four hardware queues (recognize_batches runs up to 1.6x slower). "
+                      "Set GPU_MAX_HW_QUEUES=8 in the environment, or create the Recognizer before the first GPU call.", RuntimeWarning)
+
+
+_handles = [0]          # native handles made so far (any of them has initialised the GPU runtime)
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -181,6 +214,7 @@ class NativeModel:
         self.n_labels = int(n_labels)
         self.device = device
         h = _vp()
+        _handles[0] += 1
         rc = L.dsmi_model_create(C.byref(d), device, C.byref(h))
         if rc != 0:
             raise DsmiError(rc, (L.dsmi_last_error(None) or b"").decode())
@@ -355,6 +389,7 @@ class NativeFrontend:
         self.hop = int(d.sample_rate * d.window_stride)
         self.n_freq = self.n_fft // 2 + 1
         h = _vp()
+        _handles[0] += 1
         rc = L.dsmi_frontend_create(C.byref(d), device, C.byref(h))
         if rc != 0:
             raise DsmiError(rc, (L.dsmi_frontend_last_error(None) or b"").decode())
@@ -511,6 +546,7 @@ class NativeDecoder:
         self.device = device
         arr = (C.c_char_p * len(labels))(*[c.encode("utf-8") for c in labels])
         h = _vp()
+        _handles[0] += 1
         rc = L.dsmi_decoder_create(device, arr, len(labels), int(blank_index), C.byref(h))
         if rc != 0:
             raise DsmiError(rc, (L.dsmi_decoder_last_error(None) or b"").decode())

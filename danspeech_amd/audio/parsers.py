@@ -107,6 +107,10 @@ class SpectrogramAudioParser(AudioParser):
     # sample types dsmi_features reads directly; anything else (and mixed batches) goes up as float64, the type
     # load_audio hands to recognize() (reference resources.py:640) -- the conversion is exact for all three
     _NATIVE_PCM = (np.dtype(np.int16), np.dtype(np.float32), np.dtype(np.float64))
+    # staging slots of every parser of the process are sized alike (see _staging): the mark, its ceiling and its lock
+    _stage_high = 1 << 20
+    _STAGE_SHARED_CAP = 256 << 20
+    _stage_lock = __import__("threading").Lock()
 
     def _staging(self, nbytes):
         """Two pinned host buffers used alternately, each with the event of the upload that last read it: the host
@@ -125,10 +129,14 @@ class SpectrogramAudioParser(AudioParser):
         # Sized by the largest forward ANY parser of the process has staged, not by this slot's own history: a pipeline's lanes take
         # forwards of different sizes in turn (merged pairs, single batches at a call's end), and a slot that met only small ones
         # re-pinned 82 MB (16 ms on the staging thread, the device buffer and a blocking first upload behind it) in the middle of a
-        # later call, when its first large forward arrived (profiles/r05_fill_drain.txt).  (The mark never falls: slots made after one
-        # very large forward are all that large -- two per lane, pinned and on the device.)
+        # later call, when its first large forward arrived (profiles/r05_fill_drain.txt).  The shared mark stops at _STAGE_SHARED_CAP
+        # (a pipeline forward of 64 clips x 30 s as float64 is 246 MB): one very long recording staged as a single clip sizes the slot
+        # it went through, not every slot of every parser for the rest of the process.  Helper threads stage concurrently: locked.
         cls = SpectrogramAudioParser
-        cls._stage_high = high = max(getattr(cls, "_stage_high", 1 << 20), nbytes)
+        with cls._stage_lock:
+            if nbytes <= cls._STAGE_SHARED_CAP:
+                cls._stage_high = max(cls._stage_high, nbytes)
+            high = max(cls._stage_high, nbytes)
         if slot["buf"] is None or slot["buf"].numel() < high:
             slot["buf"] = torch.empty(high, dtype=torch.uint8).pin_memory()
         if slot["dev"] is not None and slot["dev"].numel() < high:

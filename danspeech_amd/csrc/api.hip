@@ -37,9 +37,12 @@ EvPair timer_arm(dsmi_model* m, int kind, bool sample, double flops, double byte
     t.bytes[kind] += bytes;
     if (!sample) return ev;
     // Every launch of the recurrent kernels is stamped (bench.py's roofline kernel: its mean duration is over ALL its launches of the timed
-    // region); of the other kinds every fourth -- a stamped launch is a hipExtLaunchKernelGGL with two events, and stamping all sixteen
-    // launches of every forward costs the four-lane pipeline 2 - 4 % of a 20-batch call (DSMI_DEBUG_SAMPLE_EVERY: experiments)
-    static const int every = [] { const char* e = std::getenv("DSMI_DEBUG_SAMPLE_EVERY"); const int v = e ? std::atoi(e) : 4; return v < 1 ? 1 : v; }();
+    // region); of the other kinds every FIFTH -- a stamped launch is a hipExtLaunchKernelGGL with two events, and stamping all sixteen
+    // launches of every forward costs the four-lane pipeline 2 - 4 % of a 20-batch call.  Five, not four: a kind's launches per
+    // forward (layer GEMM: 4 for five layers, 6 for seven, 8 for nine) share no factor with it, so the stamped launch walks through
+    // the layers instead of always being the same one; bench.py weights a kind's share by launches / samples.
+    // (DSMI_DEBUG_SAMPLE_EVERY: experiments)
+    static const int every = [] { const char* e = exp_env("DSMI_DEBUG_SAMPLE_EVERY"); const int v = e ? std::atoi(e) : 5; return v < 1 ? 1 : v; }();
     if (kind != KK_PERSIST && kind != KK_STEP && (t.launches[kind] - 1) % every != 0) return ev;
     hipEvent_t e[2];
     for (int i = 0; i < 2; ++i) {
@@ -78,13 +81,34 @@ static void timer_resolve(dsmi_model* m) {
 //    fits a quarter takes ONE slot (handle-affine: four batches in flight on four handles and streams run their recurrent
 //    layers side by side), one that fits half takes a PAIR of slots (two batches in flight), anything else all four.
 constexpr int kMaxLanes = 4;
+//  * Launches that take the WHOLE device (the tile-walking kernel of H > 896, the paired-tile windows, the first generation) of
+//    several handles take turns through a lock word IN DEVICE MEMORY, not through the events: an event wait orders a launch behind
+//    whatever was recorded when the wait was ENQUEUED, and a forward is enqueued whole -- forward B's first recurrent layer then
+//    waits for forward A's LAST one, the forwards' recurrent layers run strictly one forward after the other and B's x-projection
+//    GEMMs have nothing to run beside (config 4, round 5: 40.2 ms per batch = the sum of a forward's kernels).  With the lock a
+//    stream holds acquire (one wave spinning on an atomic compare-and-swap) -> the persistent launch -> release, so the turn goes to
+//    whichever forward's layer is READY: A's layer l + 1 waits for its own GEMM while B's layer l runs.  Events still order the
+//    whole-device launches against the slot-sized ones (two models of different widths in one process).
 // The ring kernel's windows (rnn_persist_ring.hip: H / 32 workgroups per direction, 50 CUs for cfgA) have slots of their own: as many as
 // fit the device side by side, at most kRingSlots; a ring launch is ordered behind every launch of the other kernels and vice versa
 // (the two families never share the device: the other kernels' grids are sized for halves and quarters of it).
 constexpr int kRingSlots = 5;
 struct PersistGate { std::mutex mu; hipEvent_t ev[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr}; hipEvent_t ring_ev[kRingSlots] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+                     hipEvent_t full_ev = nullptr;      // the whole-device launch recorded last (the slot-sized launches wait for it)
+                     unsigned* turn = nullptr;           // device word: 0 free, 1 a whole-device persistent launch is running
                      int ring_cus[kRingSlots] = {0, 0, 0, 0, 0};     // CUs of the window last recorded on each ring slot (it may still be running)
                      int lock_fd = -1; bool lock_tried = false; int next_lane = 0; };
+
+// acquire: one wave spins until it has swapped the word from 0 to 1.  (Bounded: after ~4 s it goes on regardless -- two persistent
+// kernels that then share the device time out at their hand-offs and their batches are recomputed on the per-step path.)
+__global__ void turn_acquire_kernel(unsigned* turn) {
+    if (threadIdx.x != 0) return;
+    unsigned spins = 0;
+    while (atomicCAS(turn, 0u, 1u) != 0u && ++spins < (1u << 22)) __builtin_amdgcn_s_sleep(32);
+}
+__global__ void turn_release_kernel(unsigned* turn) {
+    if (threadIdx.x == 0) __hip_atomic_store(turn, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // slots a launch of `width` (1, 2 or kMaxLanes) takes for a handle whose home slot is `lane`: [first, first + width)
 static int gate_first(int lane, int width) { return width >= kMaxLanes ? 0 : (width == 2 ? 2 * (lane & 1) : (lane % kMaxLanes)); }
@@ -94,6 +118,11 @@ static void gate_wait(PersistGate* g, hipStream_t s, int lane, int width) {
         if (g->ev[i]) (void)hipStreamWaitEvent(s, g->ev[i], 0);
     for (int i = 0; i < kRingSlots; ++i)
         if (g->ring_ev[i]) (void)hipStreamWaitEvent(s, g->ring_ev[i], 0);
+    if (width >= kMaxLanes && g->turn) {      // whole device: behind the slot-sized launches by events, among themselves by the lock
+        hipLaunchKernelGGL(turn_acquire_kernel, dim3(1), dim3(64), 0, s, g->turn);
+        return;
+    }
+    if (g->full_ev) (void)hipStreamWaitEvent(s, g->full_ev, 0);
 }
 // The same for `n` windows of the ring kernel, `cus` CUs each, on ring slots [first, first + n).  Slots are counted per model
 // (n_cus / cus of ITS geometry), but they index one set of events per device: two models of different widths in one process
@@ -114,6 +143,7 @@ static void ring_gate_wait(PersistGate* g, hipStream_t s, int first, int n, int 
     }
     for (int i = 0; i < kMaxLanes; ++i)
         if (g->ev[i]) (void)hipStreamWaitEvent(s, g->ev[i], 0);
+    if (g->full_ev) (void)hipStreamWaitEvent(s, g->full_ev, 0);
 }
 static void ring_gate_record(PersistGate* g, hipStream_t s, int first, int n, int cus) {
     for (int i = first; i < first + n && i < kRingSlots; ++i) {
@@ -123,6 +153,11 @@ static void ring_gate_record(PersistGate* g, hipStream_t s, int first, int n, in
 }
 // ... and publish the launch on them.
 static void gate_record(PersistGate* g, hipStream_t s, int lane, int width) {
+    if (width >= kMaxLanes && g->turn) {
+        hipLaunchKernelGGL(turn_release_kernel, dim3(1), dim3(64), 0, s, g->turn);
+        if (g->full_ev) (void)hipEventRecord(g->full_ev, s);
+        return;
+    }
     for (int i = gate_first(lane, width); i < gate_first(lane, width) + width && i < kMaxLanes; ++i)
         if (g->ev[i]) (void)hipEventRecord(g->ev[i], s);
 }
@@ -137,6 +172,16 @@ static PersistGate* persist_gate(int device) {
         if (hipEventCreateWithFlags(&g->ev[i], hipEventDisableTiming) != hipSuccess) g->ev[i] = nullptr;
     for (int i = 0; i < kRingSlots; ++i)
         if (hipEventCreateWithFlags(&g->ring_ev[i], hipEventDisableTiming) != hipSuccess) g->ring_ev[i] = nullptr;
+    if (hipEventCreateWithFlags(&g->full_ev, hipEventDisableTiming) != hipSuccess) g->full_ev = nullptr;
+    // (without the word, or with DSMI_PERSIST_TURNS=events, the whole-device launches chain through the events as before: A/B runs)
+    const char* turns = std::getenv("DSMI_PERSIST_TURNS");
+    if (!(turns && std::string(turns) == "events") && g->full_ev) {
+        int cur = -1;
+        (void)hipGetDevice(&cur);
+        if (hipSetDevice(device) != hipSuccess || hipMalloc((void**)&g->turn, sizeof(unsigned)) != hipSuccess ||
+            hipMemset(g->turn, 0, sizeof(unsigned)) != hipSuccess) g->turn = nullptr;
+        if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
+    }
     gates[device] = g;
     return g;
 }
@@ -489,7 +534,8 @@ extern "C" int dsmi_reserve(dsmi_model* m, int max_B, int max_T) {
         if ((rc = ws_alloc(m, &m->hpack16, n))) return rc;
         HIP_OK(m, hipMemset(m->hpack16, 0, n * sizeof(uint16_t)));
     }
-    if ((rc = ws_alloc(m, &m->pcnt, (size_t)m->geom.D * ceil_div(max_B, 16) * std::max(To, 1) * kPersist16CntWords))) return rc;
+    // (+ the ring kernel's direction tickets behind the counters: two words per window, zeroed by the same memset)
+    if ((rc = ws_alloc(m, &m->pcnt, (size_t)m->geom.D * ceil_div(max_B, 16) * std::max(To, 1) * kPersist16CntWords + 2 * ceil_div(max_B, 16) + 2))) return rc;
     if ((rc = ws_alloc(m, &m->perr, (size_t)4))) return rc;
     HIP_OK(m, hipMemset(m->perr, 0, 4 * sizeof(unsigned)));
     m->look_buf = nullptr;
@@ -610,7 +656,7 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
     if (use16 && m->rnn_kernel != 1 && (m->inflight >= 2 || B > 32 || m->rnn_kernel == 2)) {
         const int rcus = rnn_persist_ring_cus(m->geom16);
         ring_slots = rcus > 0 ? std::min(kRingSlots, m->n_cus / rcus) : 0;        // windows the device holds side by side
-        static const int slot_cap = [] { const char* e = std::getenv("DSMI_DEBUG_RING_SLOTS"); return e ? std::atoi(e) : 0; }();      // (experiments)
+        static const int slot_cap = [] { const char* e = exp_env("DSMI_DEBUG_RING_SLOTS"); return e ? std::atoi(e) : 0; }();      // (experiments)
         if (slot_cap >= 2 && ring_slots > slot_cap) ring_slots = slot_cap;
         const int cap = ring_slots >= 2 ? (m->ring8 ? rnn_persist_ring_tiles(m->geom16, B, rcus) : rnn_persist_ring4_tiles(m->geom16, B, rcus)) : 0;
         if (cap > 0) {
@@ -643,7 +689,9 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
         pl.B = B; pl.T = To; pl.pgroups = pgroups; pl.waves = waves;
         pl.spin_limit = m->spin_limit;
         if (m->drop_layer == l) { pl.drop_wg = m->drop_wg; pl.drop_step = m->drop_step; }
-        (void)hipMemsetAsync(m->pcnt, 0, sizeof(unsigned) * (size_t)m->geom.D * ceil_div(B, 16) * To * kPersist16CntWords, s);
+        const size_t cnt_words = (size_t)m->geom.D * ceil_div(B, 16) * To * kPersist16CntWords;
+        (void)hipMemsetAsync(m->pcnt, 0, sizeof(unsigned) * (cnt_words + 2 * ceil_div(B, 16) + 2), s);
+        static const bool ring_xcd = [] { const char* e = std::getenv("DSMI_RING_XCD"); return !(e && e[0] == '0'); }();
         const int total_pairs = (ceil_div(B, 16) + 1) / 2;
         const int window = duo && duo_window > 0 ? duo_window : total_pairs;
         bool ok = true;
@@ -652,6 +700,7 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
             const int nw = std::min(ring_nwin, ceil_div(ntiles - t0, ring_ntw));
             const double part = (double)std::min(ring_ntw * nw, ntiles - t0) / ntiles;
             pl.tile0 = t0; pl.ntw = ring_ntw; pl.nwin = nw;
+            pl.tickets = ring_xcd ? m->pcnt + cnt_words + 2 * (t0 / ring_ntw) : nullptr;
             pl.ev = timer_arm(m, KK_PERSIST, true, part * 2.0 * Dd * GH * m->desc.rnn_hidden_size * sumlen,
                               part * 4.0 * Dd * (GH * m->desc.rnn_hidden_size + (double)To * B * (GH + 2.0 * m->desc.rnn_hidden_size)));
             PersistGate* gate = persist_gate(m->device);
@@ -665,6 +714,7 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
             // -- a lone 32-clip batch at the end of a stream -- is 4.3 / 5.4 us per step there against 5.8 / 6.0 (round 5,
             // tools/exp/ring_layer_time.py).  DSMI_RNN_KERNEL=ring8 / ring4: one form everywhere (A/B runs, the forms' own tests).
             const bool eight = m->ring8 || (!m->ring4 && std::min(ring_ntw, ntiles - t0) <= 2 && rnn_persist_ring_tiles(m->geom16, B, rcus) > 0);
+            if (eight) pl.ntw = std::min(ring_ntw, rnn_persist_ring_tiles(m->geom16, B, rcus));      // (its own cap: at most two real tiles are left)
             ok = eight ? launch_rnn_persist_ring(pl, s) : launch_rnn_persist_ring4(pl, s);
             ring_gate_record(gate, s, first, nw, rcus);
         }

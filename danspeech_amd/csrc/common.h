@@ -4,6 +4,7 @@
 #include <hip/hip_ext.h>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 #include <map>
@@ -27,6 +28,18 @@ struct EvPair { hipEvent_t start = nullptr, stop = nullptr; };
         if ((ev).start) hipExtLaunchKernelGGL(kern, grid, block, lds, stream, (ev).start, (ev).stop, 0, __VA_ARGS__); \
         else hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);                          \
     } while (0)
+
+// Experiment switches (timing builds with parts of a kernel removed, A/B forms that were measured and not adopted) exist only in a
+// library built with -DDSMI_EXPERIMENTS (`make exp` -> ../lib/libdsmi_exp.so, which tools/exp/ load through DSMI_LIBRARY); the
+// product library neither reads their environment variables nor carries their kernel instantiations.
+inline const char* exp_env(const char* name) {
+#ifdef DSMI_EXPERIMENTS
+    return std::getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
@@ -168,6 +181,7 @@ struct RnnPersist16Launch {
     int waves = 8;               // 8: one workgroup per CU; 4: the half-CU variant (two batches in flight share every CU)
     int pair0 = 0, npairs = 0;   // paired-tile kernel: the window of tile pairs this launch carries (npairs 0: all of them)
     int tile0 = 0, ntw = 0, nwin = 1;   // ring kernel: nwin windows of ntw tiles each, from tile0, side by side (ntw 0: all tiles in one window)
+    unsigned* tickets = nullptr;        // four-wave ring kernel: [nwin][2] words zeroed before the launch -> directions by XCD half (null: by blockIdx)
     unsigned spin_limit = kPersistSpinLimit;
     int drop_wg = -1, drop_step = -1;    // test hook: see DSMI_DEBUG_DROP_SIGNAL in api.hip
     EvPair ev;

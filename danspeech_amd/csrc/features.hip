@@ -389,18 +389,20 @@ __global__ __launch_bounds__(256) void hop_energy_kernel(const void* pcm, int dt
 // (float64 is what load_audio and the recognizer hand over); any other window length or WAV-frame type, or DSMI_DEBUG_STFT=direct
 // (experiments, the parity tests' second form), takes the direct kernel
 bool stft_on_mfma(int n_fft, int dtype) {
-    static const bool direct = [] { const char* e = std::getenv("DSMI_DEBUG_STFT"); return e && std::string(e) == "direct"; }();
+    static const bool direct = [] { const char* e = exp_env("DSMI_DEBUG_STFT"); return e && std::string(e) == "direct"; }();
     return n_fft == 320 && !direct && (dtype == DSMI_PCM_F64 || dtype == DSMI_PCM_F32 || dtype == DSMI_PCM_I16);
 }
 
 void launch_stft_mfma(dim3 grid, hipStream_t s, const void* pcm, int dtype, const int64_t* offs, const int64_t* nsamp, const double* tw,
                       const double* win, int hop, int pad_mode, float* feat, int t_stride) {
-    static const int skip = [] { const char* e = std::getenv("DSMI_DEBUG_STFT_SKIP"); return e ? std::atoi(e) : 0; }();
+#ifdef DSMI_EXPERIMENTS
+    static const int skip = [] { const char* e = exp_env("DSMI_DEBUG_STFT_SKIP"); return e ? std::atoi(e) : 0; }();
     if (skip && dtype == DSMI_PCM_F64) {
 #define STFT_SKIP(S) case S: hipLaunchKernelGGL((stft_mfma_kernel<320, double, S>), grid, dim3(256), 0, s, (const double*)pcm, offs, nsamp, tw, win, hop, pad_mode, feat, t_stride); return;
         switch (skip) { STFT_SKIP(1) STFT_SKIP(2) STFT_SKIP(4) STFT_SKIP(3) STFT_SKIP(6) STFT_SKIP(7) default: break; }
 #undef STFT_SKIP
     }
+#endif
     if (dtype == DSMI_PCM_F64) hipLaunchKernelGGL((stft_mfma_kernel<320, double>), grid, dim3(256), 0, s, (const double*)pcm, offs, nsamp, tw, win, hop, pad_mode, feat, t_stride);
     else if (dtype == DSMI_PCM_F32) hipLaunchKernelGGL((stft_mfma_kernel<320, float>), grid, dim3(256), 0, s, (const float*)pcm, offs, nsamp, tw, win, hop, pad_mode, feat, t_stride);
     else hipLaunchKernelGGL((stft_mfma_kernel<320, int16_t>), grid, dim3(256), 0, s, (const int16_t*)pcm, offs, nsamp, tw, win, hop, pad_mode, feat, t_stride);

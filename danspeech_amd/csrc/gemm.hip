@@ -557,7 +557,7 @@ std::vector<uint16_t> pack_gemm_w_split(const float* w, int N, int K, int ldw) {
 // profiles/r04_gemm_panel_fetch.txt): eight n-tiles 1.46 GB (K = 800) / 3.75 GB (K = 1312), five 1.29 / 2.81, four 1.35 / 2.78, three
 // 1.58 / 3.16 -- five; the time does not move, alone or in the pipeline.  DSMI_DEBUG_GEMM_PN overrides.
 static int gemm_panel_width(int ktiles) {
-    static const int forced = [] { const char* e = std::getenv("DSMI_DEBUG_GEMM_PN"); return e ? std::atoi(e) : 0; }();
+    static const int forced = [] { const char* e = exp_env("DSMI_DEBUG_GEMM_PN"); return e ? std::atoi(e) : 0; }();
     (void)ktiles;
     return forced > 0 ? forced : 5;
 }
@@ -581,13 +581,18 @@ void launch_gemm(const GemmLaunch& g, hipStream_t s) {
         a.pn = gemm_panel_width(a.ktiles);
         const dim3 grid3(8 * ceil_div(a.ntiles * a.mtiles, 8));
         // the 128 x 256 form (default); DSMI_DEBUG_GEMM_WIDE=0: the 128 x 128 form (A/B runs)
-        static const int wide = [] { const char* e = std::getenv("DSMI_DEBUG_GEMM_WIDE"); return e ? std::atoi(e) : 1; }();
+        static const int wide = [] { const char* e = exp_env("DSMI_DEBUG_GEMM_WIDE"); return e ? std::atoi(e) : 1; }();
         // pairs of n-tiles per W panel: three (fetch per 64-clip launch, tools/exp/gemm_wide_fetch.sh: two 1.21 / 2.01 GB (K = 800 / 1312),
         // three 1.03 / 1.99, four 0.91 / 1.84 -- but 637 against 613 us alone; the 128 x 128 form at its best width, five n-tiles:
         // 1.29 / 2.90 GB, 640 us); DSMI_DEBUG_GEMM_PN (n-tiles) overrides
-        static const bool pn_forced = std::getenv("DSMI_DEBUG_GEMM_PN") != nullptr;
+        static const bool pn_forced = exp_env("DSMI_DEBUG_GEMM_PN") != nullptr;
         a.pn2 = pn_forced ? std::max(1, (a.pn + 1) / 2) : 3;
+#ifndef DSMI_EXPERIMENTS
+        (void)wide; (void)grid3;
+        {
+#else
         if (wide) {
+#endif
             const int ntiles2 = (a.ntiles + 1) / 2;
             const dim3 gridw(8 * ceil_div(ntiles2 * a.mtiles, 8));
             const size_t ldsw = 49152;                  // one stage: A and two W tiles, two 8-KiB planes each
@@ -595,7 +600,8 @@ void launch_gemm(const GemmLaunch& g, hipStream_t s) {
             else DSMI_LAUNCH(gemm_f16x3_wide_kernel<false>, gridw, dim3(256), ldsw, s, g.ev, a, (const uint16_t*)g.a_sp);
             return;
         }
-        static const int stages = [] { const char* e = std::getenv("DSMI_DEBUG_GEMM_STAGES"); return e && std::atoi(e) == 2 ? 2 : 1; }();
+#ifdef DSMI_EXPERIMENTS       // the 128 x 128 forms: rounds 3-4, kept for A/B runs
+        static const int stages = [] { const char* e = exp_env("DSMI_DEBUG_GEMM_STAGES"); return e && std::atoi(e) == 2 ? 2 : 1; }();
         if (stages == 2) {
             const size_t lds2 = 65536;                  // two stages
             static bool attr = false;
@@ -612,6 +618,7 @@ void launch_gemm(const GemmLaunch& g, hipStream_t s) {
         if (g.mode == GEMM_A_CONV) DSMI_LAUNCH((gemm_f16x3_kernel<true, 1>), grid3, dim3(256), lds3, s, g.ev, a, (const uint16_t*)g.a_sp);
         else DSMI_LAUNCH((gemm_f16x3_kernel<false, 1>), grid3, dim3(256), lds3, s, g.ev, a, (const uint16_t*)g.a_sp);
         return;
+#endif
     }
     GemmArgs a;
     a.a = g.a; a.a2 = g.a2; a.alpha = g.alpha; a.beta = g.beta; a.w = g.w; a.bias = g.bias; a.c = g.c;

@@ -626,11 +626,14 @@ bool launch16(const P16Args& a, hipStream_t s, const EvPair& ev, int waves) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pipe(N));                      \
         DSMI_LAUNCH((rnn_persist16_pipe_kernel<KIND, N>), grid, block, lds_pipe(N), s, ev, a);                        \
     } while (0)
+#ifdef DSMI_EXPERIMENTS
         if (a.skip && KIND == DSMI_RNN_GRU && nkw == 5) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rnn_persist16_pipe_kernel<DSMI_RNN_GRU, 5, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pipe(5));
             DSMI_LAUNCH((rnn_persist16_pipe_kernel<DSMI_RNN_GRU, 5, true>), grid, block, lds_pipe(5), s, ev, a);
-        } else if (nkw <= 2) LAUNCH_QP(2);
+        } else
+#endif
+        if (nkw <= 2) LAUNCH_QP(2);
         else if (nkw <= 4) LAUNCH_QP(4);
         else if (nkw <= 5 && KIND != DSMI_RNN_LSTM) LAUNCH_QP(5);
         else return false;
@@ -718,7 +721,7 @@ bool launch_rnn_persist16(const RnnPersist16Launch& p, hipStream_t s) {
     a.B = p.B; a.T = p.T; a.H = p.g.H; a.Hs = p.g.Kp; a.Np = p.g.Np; a.nwg = p.g.nwg; a.nkb = ceil_div(p.g.H, 32);
     a.ntiles = ceil_div(p.B, QB); a.pgroups = p.pgroups; a.D = p.g.D; a.dbg = p.dbg;
     a.spin_limit = p.spin_limit; a.drop_wg = p.drop_wg; a.drop_step = p.drop_step;
-    static const int skip_env = [] { const char* e = std::getenv("DSMI_DEBUG_PIPE_SKIP"); return e ? std::atoi(e) : 0; }();
+    static const int skip_env = [] { const char* e = exp_env("DSMI_DEBUG_PIPE_SKIP"); return e ? std::atoi(e) : 0; }();
     a.skip = skip_env;
     switch (p.g.kind) {
         case DSMI_RNN_GRU: return launch16<DSMI_RNN_GRU>(a, s, p.ev, p.waves);

@@ -503,6 +503,7 @@ bool launch_ring(const RingArgs& a, hipStream_t s, const EvPair& ev) {
         if constexpr (KIND == DSMI_RNN_GRU) { if (nkw == 7) { LAUNCH_R(7, true); return true; } }
         return false;
     }
+#ifdef DSMI_EXPERIMENTS
     if (a.skip) {           // timing experiments (DSMI_DEBUG_RING_SKIP): cfgA's shape only
         if constexpr (KIND == DSMI_RNN_GRU) {
             if (nkw == 7) {
@@ -513,6 +514,7 @@ bool launch_ring(const RingArgs& a, hipStream_t s, const EvPair& ev) {
         }
         return false;
     }
+#endif
     // NKW exact: every wave owns NKW or NKW - 1 k-blocks, so only the last block of the unrolled loops is conditional
     switch (nkw) {
         case 1: LAUNCH_R(1, false); break;
@@ -561,7 +563,7 @@ bool launch_rnn_persist_ring(const RnnPersist16Launch& p, hipStream_t s) {
     if (a.ntw < 1 || a.ntw > RMINT || a.tile_end <= a.tile0) return false;
     if ((size_t)p.T * p.B * p.g.Kp * 4 >= (1ull << 31)) return false;          // a direction's output rows below 2 GiB (store offsets, see OOR)
     a.spin_limit = p.spin_limit; a.drop_wg = p.drop_wg; a.drop_step = p.drop_step; a.dbg = p.dbg;
-    static const int skip = std::getenv("DSMI_DEBUG_RING_SKIP") ? std::atoi(std::getenv("DSMI_DEBUG_RING_SKIP")) : 0;
+    static const int skip = exp_env("DSMI_DEBUG_RING_SKIP") ? std::atoi(exp_env("DSMI_DEBUG_RING_SKIP")) : 0;
     a.skip = skip;
     switch (p.g.kind) {
         case DSMI_RNN_GRU: return launch_ring<DSMI_RNN_GRU>(a, s, p.ev);

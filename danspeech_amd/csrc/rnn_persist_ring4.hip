@@ -73,6 +73,7 @@ struct Ring4Args {
     int tile0, ntw, tile_end;  // window z (blockIdx.z) walks tiles tile0 + z * ntw .. + ntw - 1, below tile_end
     unsigned spin_limit;
     int drop_wg, drop_step;
+    unsigned* tickets;         // [windows][2 directions] zeroed before the launch (null: a workgroup is (blockIdx.x, blockIdx.y)): see the prologue
     unsigned long long* dbg;   // diagnostics build only: per wave, 100 MHz ticks: [0] phase work (to the end of the partial tiles),
                                // [1] (unused), [2] poll spin (wave 0), [3] barrier; [4] shader cycles of the phase work; [5] polls whose first read was too early, [6] re-reads; [7] phases
 };
@@ -117,7 +118,29 @@ __global__ __launch_bounds__(XNT) void rnn_persist_ring4_kernel(Ring4Args p) {
     const int v = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int mh = v & 1, kh = v >> 1;
     const int ln = lane & 15, lg = lane >> 4;
-    const int w32 = blockIdx.x, d = blockIdx.y;
+    // Which (direction, unit group) this workgroup is.  A tile's packed state is read by every workgroup of its direction every
+    // step, and every XCD's L2 that holds one of them fetches it from the fabric: the launch's workgroups land on the eight XCDs
+    // round-robin, so with (blockIdx.x, blockIdx.y) a direction's workgroups sit on all eight.  With tickets, the workgroups that
+    // find themselves on XCDs 0-3 (HW_REG_XCC_ID) take direction 0's unit groups in the order they arrive, those on 4-7 direction
+    // 1's; whoever finds its direction full takes the other (speed only: any bijection is correct).  Four L2s fetch a tile's state
+    // per step instead of eight.
+    int w32 = blockIdx.x, d = blockIdx.y;
+    if (p.tickets && p.D == 2) {
+        const int nw = (p.nwg16 + 1) >> 1;
+        if (tid == 0) {
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            unsigned* tk = p.tickets + 2 * blockIdx.z;
+            unsigned want = (xcc >> 2) & 1u;
+            unsigned t = atomicAdd(&tk[want], 1u);
+            if (t >= (unsigned)nw) { want ^= 1u; t = atomicAdd(&tk[want], 1u); }
+            sync[30] = (int)want; sync[31] = (int)t;
+        }
+        ring4_barrier();
+        d = __builtin_amdgcn_readfirstlane(sync[30]);
+        w32 = __builtin_amdgcn_readfirstlane(sync[31]);
+        ring4_barrier();         // (sync[] is zeroed below)
+    }
     const int tile0 = p.tile0 + (int)blockIdx.z * p.ntw;
     const int nt = min(min(p.ntw, p.tile_end - tile0), NT);
     const int w16 = 2 * w32 + mh;
@@ -545,7 +568,8 @@ bool launch_ring4_nt(const Ring4Args& a, hipStream_t s, const EvPair& ev) {
         if constexpr (KIND == DSMI_RNN_GRU) { if (nkw == 13) { LAUNCH_X(13, true); return true; } }
         return false;
     }
-    static const int skip = std::getenv("DSMI_DEBUG_RING_SKIP") ? std::atoi(std::getenv("DSMI_DEBUG_RING_SKIP")) : 0;
+#ifdef DSMI_EXPERIMENTS
+    static const int skip = exp_env("DSMI_DEBUG_RING_SKIP") ? std::atoi(exp_env("DSMI_DEBUG_RING_SKIP")) : 0;
     if (skip) {           // timing experiments: cfgA's shape only, a fixed list of masks
         if constexpr (KIND == DSMI_RNN_GRU && NT == 4) {
             if (nkw != 13) return false;
@@ -564,6 +588,7 @@ bool launch_ring4_nt(const Ring4Args& a, hipStream_t s, const EvPair& ev) {
         }
         return false;
     }
+#endif
     switch (nkw) {
         case 1: LAUNCH_X(1, false); break;
         case 2: LAUNCH_X(2, false); break;
@@ -606,7 +631,7 @@ int rnn_persist_ring4_tiles(const RnnGeom& g16, int B, int n_cus) {
     if ((size_t)g16.D * ceil_div(B, XB) * nkb * 2048 * 2 >= (1ull << 31)) return 0;      // packed state below 2 GiB (store offsets, see OOR)
     // tiles per window: four (a 64-clip forward); DSMI_RING_TILES=6|8 lets a window walk more (a chain's hand-off then lies under
     // five or seven other phases instead of three)
-    static const int most = [] { const char* e = std::getenv("DSMI_RING_TILES"); const int v = e ? std::atoi(e) : 4; return v >= 4 && v <= XMAXT ? v : 4; }();
+    static const int most = [] { const char* e = exp_env("DSMI_RING_TILES"); const int v = e ? std::atoi(e) : 4; return v >= 4 && v <= XMAXT ? v : 4; }();
     return std::min(ceil_div(B, XB), nkw == 14 ? 4 : most);
 }
 
@@ -620,13 +645,17 @@ bool launch_rnn_persist_ring4(const RnnPersist16Launch& p, hipStream_t s) {
     a.tile_end = std::min(a.ntiles, a.tile0 + a.ntw * std::max(p.nwin, 1));
     if (a.ntw < 1 || a.ntw > XMAXT || a.tile_end <= a.tile0) return false;
     if ((size_t)p.T * p.B * p.g.Kp * 4 >= (1ull << 31)) return false;          // a direction's output rows below 2 GiB (store offsets, see OOR)
-    a.spin_limit = p.spin_limit; a.drop_wg = p.drop_wg; a.drop_step = p.drop_step; a.dbg = p.dbg;
-    if (a.ntw > 4) {          // more than four tiles per window: the eight-tile schedule (six: two phantom tiles)
+    a.spin_limit = p.spin_limit; a.drop_wg = p.drop_wg; a.drop_step = p.drop_step; a.dbg = p.dbg; a.tickets = p.tickets;
+    if (a.ntw > 4) {          // more than four tiles per window: the eight-tile schedule (six: two phantom tiles); measured, no gain
+#ifndef DSMI_EXPERIMENTS
+        return false;         // (DSMI_RING_TILES=6|8 exists in the experiments build only: rnn_persist_ring4_tiles never says more than four)
+#else
         switch (p.g.kind) {
             case DSMI_RNN_GRU: return launch_ring4_nt<DSMI_RNN_GRU, 8>(a, s, p.ev);
             case DSMI_RNN_LSTM: return launch_ring4_nt<DSMI_RNN_LSTM, 8>(a, s, p.ev);
             default: return launch_ring4_nt<DSMI_RNN_TANH, 8>(a, s, p.ev);
         }
+#endif
     }
     switch (p.g.kind) {
         case DSMI_RNN_GRU: return launch_ring4_nt<DSMI_RNN_GRU, 4>(a, s, p.ev);

@@ -34,6 +34,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* libdsmi.so is built with -fvisibility=hidden: the declarations between this push and the pop at the end of the file are its whole
+ * export list (tests/test_abi.py compares `nm -D` with them). */
+#if defined(DSMI_BUILD) && defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 typedef enum {
     DSMI_OK = 0,
@@ -355,6 +360,9 @@ int dsmi_comm_scatter(dsmi_comm* c, int root, const void* const* clips_host, con
 int dsmi_comm_gather_text(dsmi_comm* c, int root, const char* text, int text_stride, const int32_t* shard_index, int shard_count,
                           int total_count, char* all_text, void* stream);
 
+#if defined(DSMI_BUILD) && defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -29,6 +29,19 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), name
 
 
+def test_library_exports_nothing_but_the_abi():
+    """-fvisibility=hidden + the linker's export list (csrc/libdsmi.map): the dynamic symbol table holds the functions of
+    include/dsmi.h and nothing else -- no C++ helper, no kernel handle."""
+    import shutil
+    import subprocess
+    from danspeech_amd import _native
+    if not shutil.which("nm"):
+        pytest.skip("no nm")
+    out = subprocess.run(["nm", "-D", "--defined-only", _native.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    assert exported == _header_functions()
+
+
 def test_create_rejects_bad_conv_layers_without_gpu():
     """Argument validation happens before any HIP call (reference ConvError, model.py:344-348)."""
     from danspeech_amd import _native

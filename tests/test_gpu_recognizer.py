@@ -105,9 +105,12 @@ def test_forwards_in_flight_follow_the_first_forward():
     eng = rec.danspeech_recognizer
     want = rec.recognize_batch(clips)
     assert eng._lanes_that_pay(4, 64) == 4 and eng._lanes_that_pay(4, 65) == 2 and eng._lanes_that_pay(1, 65) == 1
-    big = clips * 14                                             # 70 clips: one forward of more than a window
-    assert list(rec.recognize_batches([big, clips, big])) == [want * 14, want, want * 14]
+    big = clips * 14                                             # 70 clips: one forward of more than a window where the caller allows it
+    assert list(eng.transcribe_batches([big, clips, big], merge_clips=128)) == [want * 14, want, want * 14]
     assert len(eng._replicas) == 1
+    # by default such a batch is cut into forwards of at most 64 clips (round 6), each one ring window: four in flight
+    assert list(rec.recognize_batches([big, clips, big])) == [want * 14, want, want * 14]
+    assert len(eng._replicas) == 3
     assert list(rec.recognize_batches([clips] * 6)) == [want] * 6
     assert len(eng._replicas) == 3
     wide, _, _ = _model("wide", 912, 1, seed=13)                 # 912 units: no ring form

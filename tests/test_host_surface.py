@@ -188,3 +188,46 @@ def test_plan_shards():
         l = [lens[i] for i in s]
         assert l == sorted(l, reverse=True)
     assert [lens[i] for i in shards[0]] == [9, 7, 3] and [lens[i] for i in shards[1]] == [8, 5, 1]
+
+
+def test_transcribe_batches_cuts_large_batches_and_restores_the_callers_order():
+    """``transcribe_batches``: a caller's batch of more than ``merge_clips`` clips runs as forwards of at most that many, longest
+    clips first, and comes back as ONE list in the caller's order; smaller batches pass through untouched.  The pipeline below it
+    is replaced by a stand-in that "transcribes" a clip to (its length, its first sample) and checks what it is handed."""
+    from danspeech_amd.DanSpeechRecognizer import DanSpeechRecognizer
+    eng = object.__new__(DanSpeechRecognizer)
+    seen = []
+
+    def forwards(batches, show_all=False, lanes=None, merge_clips=None):
+        for b in batches:
+            seen.append([len(c) for c in b])
+            yield [(len(c), float(c[0])) for c in b]
+    eng._transcribe_forwards = forwards
+    rng = np.random.default_rng(5)
+    mk = lambda n: [np.full(int(rng.integers(5, 400)), float(rng.integers(0, 1000))) for _ in range(n)]
+    batches = [mk(3), mk(150), [], mk(64), mk(65), mk(1)]
+    out = list(eng.transcribe_batches(batches, merge_clips=64))
+    assert [len(o) for o in out] == [3, 150, 0, 64, 65, 1]
+    for b, o in zip(batches, out):
+        assert o == [(len(c), float(c[0])) for c in b]
+    assert [len(s) for s in seen] == [3, 64, 64, 22, 0, 64, 64, 1, 1]
+    for s in seen[1:4] + seen[6:8]:
+        assert s == sorted(s, reverse=True)                     # every piece longest first ...
+    assert seen[1][-1] >= seen[2][0] and seen[2][-1] >= seen[3][0]      # ... and the pieces of a batch in that order too
+    # merge_clips=0 (the strictly sequential mode): nothing is cut
+    seen.clear()
+    assert [len(o) for o in eng.transcribe_batches([mk(150)], lanes=1, merge_clips=0)] == [150] and [len(s) for s in seen] == [150]
+    # a consumer that stops early closes the pipeline below
+    closed = []
+
+    def forwards2(batches, **kw):
+        try:
+            for b in batches:
+                yield [0] * len(b)
+        finally:
+            closed.append(True)
+    eng._transcribe_forwards = forwards2
+    g = eng.transcribe_batches([mk(200), mk(3)], merge_clips=64)
+    next(g)
+    g.close()
+    assert closed == [True]

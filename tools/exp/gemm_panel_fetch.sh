@@ -1,4 +1,6 @@
 #!/bin/bash
+# (the A/B switches live in the experiments build: make -C danspeech_amd/csrc exp)
+export DSMI_LIBRARY=$PWD/danspeech_amd/lib/libdsmi_exp.so
 # HBM fetch and time of the split-fp16 GEMMs against the width of the W panel (DSMI_DEBUG_GEMM_PN), bench workload, dispatches serialised by the
 # counter pass (run on the GPU box, from the repo root):   bash tools/exp/gemm_panel_fetch.sh "3 4 5 6 8"
 export TMPDIR=/tmp

@@ -3,6 +3,8 @@
 with one and with two LDS stages (DSMI_DEBUG_GEMM_WIDE=0, DSMI_DEBUG_GEMM_STAGES), the 128 x 256 tile (default); the whole forward's
 probabilities compared between the forms.  gemm_stages_time.py"""
 import os, sys, subprocess
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from explib import exp_env
 here = os.path.dirname(os.path.abspath(__file__))
 code = r'''
 import os, sys
@@ -27,7 +29,7 @@ print(" | ".join("%%s %%.0f us = %%.0f TF-equiv" %% (k, ks[k]["avg_us"], ks[k]["
 outs = []
 forms = (("128 x 128, one stage", {"DSMI_DEBUG_GEMM_WIDE": "0"}), ("128 x 128, two stages", {"DSMI_DEBUG_GEMM_WIDE": "0", "DSMI_DEBUG_GEMM_STAGES": "2"}), ("128 x 256, panel of 3 pairs (default)", {}), ("128 x 256, panel of 4 pairs", {"DSMI_DEBUG_GEMM_PN": "8"}))
 for k, (name, extra) in enumerate(forms):
-    env = dict(os.environ, **extra)
+    env = exp_env(**extra)
     f = "/tmp/gemm_form_%d.npy" % k
     r = subprocess.run([sys.executable, "-c", code, f], env=env, capture_output=True, text=True)
     print("%-40s: %s" % (name, (r.stdout.strip().splitlines() or [r.stderr[-300:]])[-1]), flush=True)

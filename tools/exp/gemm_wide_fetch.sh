@@ -1,4 +1,6 @@
 #!/bin/bash
+# (the A/B switches live in the experiments build: make -C danspeech_amd/csrc exp)
+export DSMI_LIBRARY=$PWD/danspeech_amd/lib/libdsmi_exp.so
 # HBM fetch of the split-fp16 GEMMs: the 128 x 256 tile (pairs of n-tiles per W panel: DSMI_DEBUG_GEMM_PN = n-tiles, halved) against the 128 x 128
 # tile, bench workload, dispatches serialised by the counter pass (on the GPU box, from the repo root):  bash tools/exp/gemm_wide_fetch.sh
 export TMPDIR=/tmp

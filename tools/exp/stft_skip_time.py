@@ -3,6 +3,8 @@
 removed (DSMI_DEBUG_STFT_SKIP: 1 no hypotf / log1pf, 2 no MFMAs, 4 no sample / window loads; results are garbage), us per call
 (STFT + clip statistics + normalise; the last two are ~40 us)."""
 import os, subprocess, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from explib import exp_env
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 child = r'''
 import sys, numpy as np, torch
@@ -22,5 +24,5 @@ print("%%.0f" %% (ev[0].elapsed_time(ev[1]) * 1000 / 20))
 ''' % root
 for skip, what in ((0, "the kernel"), (1, "no hypotf / log1pf"), (2, "MFMAs -> f64 vector ops (slower: says nothing)"), (4, "no sample / window loads"), (3, "no epilogue, MFMAs -> vector ops"),
                    (6, "no loads, MFMAs -> vector ops"), (7, "stores + vector ops only")):
-    r = subprocess.run([sys.executable, "-c", child], env=dict(os.environ, DSMI_DEBUG_STFT_SKIP=str(skip)), capture_output=True, text=True)
+    r = subprocess.run([sys.executable, "-c", child], env=exp_env(DSMI_DEBUG_STFT_SKIP=skip), capture_output=True, text=True)
     print("%-48s %s us per dsmi_features call" % (what, r.stdout.strip() or r.stderr.strip()[-300:]), flush=True)

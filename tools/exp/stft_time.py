@@ -3,6 +3,8 @@
 direct DFT on the vector pipe; default: v_mfma_f64_16x16x4_f64), microseconds per launch by the library's dispatch timers, and the
 largest difference between the two forms' features.   stft_time.py [clips] [t_stride: row pitch of the feature tensor in frames, default 1001]"""
 import os, subprocess, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from explib import exp_env
 here = os.path.dirname(os.path.abspath(__file__))
 root = os.path.dirname(os.path.dirname(here))
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
@@ -28,7 +30,7 @@ print("%%.0f us per dsmi_features call (STFT + statistics + normalise, 20 calls 
 outs = []
 for name, extra in (("direct float64 DFT (vector pipe)", {"DSMI_DEBUG_STFT": "direct"}), ("v_mfma_f64_16x16x4_f64", {})):
     f = "/tmp/stft_form_%d.npy" % len(outs)
-    r = subprocess.run([sys.executable, "-c", child, f], env=dict(os.environ, **extra), capture_output=True, text=True)
+    r = subprocess.run([sys.executable, "-c", child, f], env=exp_env(**extra), capture_output=True, text=True)
     print("%-36s: %s" % (name, (r.stdout.strip() or r.stderr.strip()[-400:])))
     outs.append(f)
 import numpy as np

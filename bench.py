@@ -249,6 +249,7 @@ def main(argv=None):
     ap.add_argument("--strict-f32-child", action="store_true", help=argparse.SUPPRESS)     # the f32_strict side run (a fresh process)
     ap.add_argument("--abi-child", action="store_true", help=argparse.SUPPRESS)            # the abi_path side run (a fresh process)
     ap.add_argument("--other-config-child", type=int, default=0, help=argparse.SUPPRESS)   # one of other_configs (a fresh process)
+    ap.add_argument("--warmup-calls", type=int, default=1, help=argparse.SUPPRESS)          # experiments: the warm-up as this many calls
     ap.add_argument("--no-other-configs", action="store_true", help="skip the side runs of BASELINE.json configs 3, 4 and 5's per-GPU share")
     ap.add_argument("--no-kernel-sampling", action="store_true")
     ap.add_argument("--lanes", type=int, default=None, help="experiments: forwards in flight (default: the engine's own choice; the line says what ran)")
@@ -364,12 +365,15 @@ def main(argv=None):
         if not dry:
             torch.cuda.synchronize()
 
-    warmup_done = max(args.warmup, 16 if not dry else 0)
-    # warm-up in TWO calls: the second recognize_batches call of a process still pays a one-off, host-blocking first upload on each
-    # replica lane (5.5 ms each, tools/exp/pipeline_fill_log.py, profiles/r05_fill_drain.txt); from the third call on none does
-    out = run(warmup_done)
-    out = run(warmup_done) or out
-    warmup_done *= 2
+    # ONE warm-up call of at least 16 steps (every lane's workspaces and pinned staging slots are made on their first use).  Round 5
+    # needed two: a process's second call paid a blocking first upload on each replica lane -- the first copy a process hands a DMA
+    # engine holds the caller until it is done; the engine now meets its engines when its lanes are set up
+    # (DanSpeechRecognizer._warm_copy_engines, profiles/r06_second_call_stall.txt)
+    warmup_each = max(args.warmup, 16 if not dry else 0)
+    out = None
+    for _ in range(max(args.warmup_calls, 1)):
+        out = run(warmup_each) or out
+    warmup_done = warmup_each * max(args.warmup_calls, 1)
     if eng is not None:
         handles = [eng.model._native] + [r[0]._native for r in eng._replicas]
     if not args.no_kernel_sampling:
@@ -583,10 +587,10 @@ OTHER_CONFIGS = {
     3: dict(key="config3", what="BASELINE.json configs[2]: cfgA (5 x BiGRU 800) + 3-gram, CTC beam 64, batch 32 x 10 s",
             hidden=800, layers=5, lm_order=3, beam=64, alpha=1.3, beta=0.2, batch=32, seconds=10.0, gflop_per_clip=51.85, warm=32, steps=96),
     4: dict(key="config4", what="BASELINE.json configs[3]: 7 x BiGRU 1200 + 5-gram, CTC beam 128, batch 64 x 10 s",
-            hidden=1200, layers=7, lm_order=5, beam=128, alpha=1.3, beta=0.2, batch=64, seconds=10.0, gflop_per_clip=132.9, warm=12, steps=24),
+            hidden=1200, layers=7, lm_order=5, beam=128, alpha=1.3, beta=0.2, batch=64, seconds=10.0, gflop_per_clip=132.9, warm=12, steps=48),
     5: dict(key="config5_share", what="BASELINE.json configs[4], ONE GPU's share of 1024 x 30 s over 8 GPUs: cfgA + 3-gram, CTC beam 64, "
             "batches of 128 x 30 s", hidden=800, layers=5, lm_order=3, beam=64, alpha=1.3, beta=0.2, batch=128, seconds=30.0,
-            gflop_per_clip=155.4, warm=6, steps=12),
+            gflop_per_clip=155.4, warm=6, steps=16),
 }
 
 
@@ -610,9 +614,8 @@ def other_config(no):
         B, n = c["batch"], int(c["seconds"] * 16000)
         clips = [syn.make_clip(i, n) for i in range(B)]
         one = rec.recognize_batch(clips)
-        for _ in range(2):                       # two warm-up calls: every lane's workspaces, staging slots and decoder slots exist
-            for res in rec.recognize_batches([clips] * c["warm"]):
-                pass
+        for res in rec.recognize_batches([clips] * c["warm"]):      # every lane's workspaces, staging slots and decoder slots exist
+            pass
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         same = True

@@ -255,7 +255,47 @@ class DanSpeechRecognizer(object):
         handles = [self.model] + [r[0] for r in self._replicas[:count - 1]]
         parsers = [self.audio_parser] + [r[1] for r in self._replicas[:count - 1]]
         streams = [torch.cuda.current_stream(self._device_index())] + [self._side_stream("lane %d" % k) for k in range(1, len(handles))]
+        if len(streams) > getattr(self, "_copy_engines_warm", 1):
+            self._warm_copy_engines(streams)
+            self._copy_engines_warm = len(streams)
         return handles, parsers, streams
+
+    def _warm_copy_engines(self, streams):
+        """The runtime hands a host-to-device copy to the lowest DMA engine that is free, and the FIRST copy a process gives an
+        engine holds the calling thread until that copy is done (5.8 ms for a forward's 82 MB: profiles/r06_second_call_stall.txt
+        -- inside `hipMemcpyAsync`, behind `hsa_amd_memory_async_copy_on_engine`).  A pipeline's lanes upload side by side, so
+        engines 2, 3, 4 meet their first copy whenever the lanes' uploads first overlap: in the process's second call, as it
+        happened.  Here, once per set of lanes: one 64 MB copy per lane, issued from as many host threads AT THE SAME MOMENT (a
+        held thread must not keep the next lane's copy from starting: only copies in flight together reach the higher engines),
+        repeated until a whole round returns at once."""
+        import threading
+        import time
+        import torch
+        index = self._device_index()
+        dev = "cuda:%d" % index
+        size = 64 << 20
+        hosts = [torch.empty(size, dtype=torch.uint8).pin_memory() for _ in streams]
+        dst = [torch.empty(size, dtype=torch.uint8, device=dev) for _ in streams]
+        for _ in range(4):
+            gate = threading.Barrier(len(streams))
+            took = [0.0] * len(streams)
+
+            def one(k):
+                torch.cuda.set_device(index)
+                with torch.cuda.stream(streams[k]):
+                    gate.wait()
+                    t = time.perf_counter()
+                    dst[k].copy_(hosts[k], non_blocking=True)
+                    took[k] = time.perf_counter() - t
+            threads = [threading.Thread(target=one, args=(k,)) for k in range(len(streams))]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+            for s in streams:
+                s.synchronize()
+            if max(took) < 5e-4:
+                break
 
     def _lanes_that_pay(self, most, clips):
         """Forwards in flight when the caller did not say.  Several forwards side by side pay where the recurrent kernel of
@@ -296,7 +336,14 @@ class DanSpeechRecognizer(object):
                 for part in parts:
                     yield part
 
-        inner = self._transcribe_forwards(pieces(), show_all=show_all, lanes=lanes, merge_clips=merge_clips)
+        # a sized source (a list of lists): how many pieces the pipeline will see -- it then knows when it is enqueueing its last
+        # forwards and gives a forward that has the chip to itself the kernels of a lone batch (short calls: _transcribe_forwards)
+        total = None
+        try:
+            total = sum(1 if (merge <= 0 or len(b) <= merge) else -(-len(b) // merge) for b in batches) if hasattr(batches, "__len__") else None
+        except TypeError:
+            total = None
+        inner = self._transcribe_forwards(pieces(), show_all=show_all, lanes=lanes, merge_clips=merge_clips, total=total)
         try:
             for res in inner:
                 shape = shapes.popleft()
@@ -313,7 +360,7 @@ class DanSpeechRecognizer(object):
         finally:
             inner.close()
 
-    def _transcribe_forwards(self, batches, show_all=False, lanes=None, merge_clips=None):
+    def _transcribe_forwards(self, batches, show_all=False, lanes=None, merge_clips=None, total=None):
         """Generator over ``transcribe_batch(b)`` for every ``b`` of ``batches``, software-pipelined: consecutive batches are
         merged into forwards of up to ``merge_clips`` clips (per-clip results do not depend on the batch they run in), and up to
         ``lanes`` forwards are in flight (default: ``pipeline_lanes``, or two where more do not pay: ``_lanes_that_pay``), each
@@ -340,7 +387,7 @@ class DanSpeechRecognizer(object):
             hs, ps, ss = self._lanes(count)
             for h in hs:
                 if hasattr(h, "set_inflight"):
-                    h.set_inflight(max(2, len(hs)) if len(hs) > 1 else 1)
+                    h.set_inflight(max(2, len(hs)) if len(hs) > 1 else 1)     # (re-stated per forward in the loop below)
             for p in ps:
                 p.share_copy_stream = searching      # a search kernel on the decode stream: fewer streams
                 p.upload_on_compute_stream = True    # no copy stream in the pipeline: see SpectrogramAudioParser.stage
@@ -352,12 +399,29 @@ class DanSpeechRecognizer(object):
         end = object()
         source = iter(batches)
         held = [end, False]                      # a batch read from the source that did not fit the group being put together
+        taken = [0, False]                       # batches read from the source so far; the source has ended
 
         def next_batch():
             if held[1]:
                 held[1] = False
                 return held[0]
-            return next(source, end)
+            b = next(source, end)
+            if b is end:
+                taken[1] = True
+            else:
+                taken[0] += 1
+            return b
+
+        def forwards_to_come(per_forward):
+            """Forwards that will follow the one being enqueued (which merged `per_forward` batches), as far as this call can know
+            WITHOUT asking the source for anything (a live source must not be waited for here): from the batch count of a sized
+            source (`total`), otherwise none once the source has ended and 'plenty' before."""
+            if taken[1]:
+                return 1 if held[1] else 0
+            if total is not None:
+                left = total - taken[0] + (1 if held[1] else 0)
+                return min(-(-left // max(per_forward, 1)), lanes)
+            return lanes
 
         def fetch(parser):
             """The next forward: consecutive batches of one kind (host clips / device-resident clips) up to merge_clips clips.
@@ -435,6 +499,16 @@ class DanSpeechRecognizer(object):
                     for older in pending:            # this forward's model handle gives back its previous forward first
                         if older[1] is not None and older[1].model is handles[turn]:
                             older[1].collect_forward()
+                    # Kernel forms follow what will BE on the chip, not what the call was set up for: a forward that is enqueued
+                    # with nothing else running and nothing to come (a call of one or two batches) takes the forms of a lone batch
+                    # (the whole-device recurrent kernel, or two ring windows side by side); two forwards that will share the chip
+                    # between them (a call of three or four batches, the last forwards of a sized source) take two ring windows
+                    # each; anything more, one window each.  profiles/r06_short_calls.txt
+                    if lanes > 1 and hasattr(handles[turn], "set_ring_windows"):
+                        busy = sum(1 for _p, j in pending if j is not None and not j.collected and not j.model.ready())
+                        expect = busy + 1 + forwards_to_come(len(parts))
+                        handles[turn].set_inflight(1 if expect <= 1 else max(2, lanes))
+                        handles[turn].set_ring_windows(2 if expect == 2 else 0)
                     with torch.cuda.stream(streams[turn]):
                         if isinstance(merged, _UnmergedDeviceClips):
                             streams[turn].wait_event(staged)
@@ -480,6 +554,8 @@ class DanSpeechRecognizer(object):
             for h in handles:
                 if hasattr(h, "set_inflight"):
                     h.set_inflight(1)
+                if hasattr(h, "set_ring_windows"):
+                    h.set_ring_windows(0)
 
     def _abandon(self, job):
         """Wait for an enqueued batch and drop its results."""

@@ -93,6 +93,8 @@ _PROTOS = {
     "dsmi_forward_status": (C.c_int, [_vp]),
     "dsmi_recompute_count": (C.c_int, [_vp]),
     "dsmi_model_set_inflight": (C.c_int, [_vp, C.c_int]),
+    "dsmi_model_set_ring_windows": (C.c_int, [_vp, C.c_int]),
+    "dsmi_pack_pcm_i16": (C.c_int, [_vp, C.c_int64, _vp]),
     "dsmi_conv_stack": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
     "dsmi_rnn_layer": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
     "dsmi_greedy": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
@@ -312,6 +314,10 @@ class NativeModel:
         """How many batches the caller keeps in flight on this device (one handle + stream each): 2 selects the
         throughput variant of the recurrent kernel."""
         self._check(lib().dsmi_model_set_inflight(self._h, int(batches)))
+
+    def set_ring_windows(self, windows):
+        """Ring windows the next forwards' recurrent layers take side by side (0: what ``set_inflight`` implies)."""
+        self._check(lib().dsmi_model_set_ring_windows(self._h, int(windows)))
 
     def conv_stack(self, feat, lens):
         import torch

@@ -88,7 +88,10 @@ constexpr int kMaxLanes = 4;
 //    GEMMs have nothing to run beside (config 4, round 5: 40.2 ms per batch = the sum of a forward's kernels).  With the lock a
 //    stream holds acquire (one wave spinning on an atomic compare-and-swap) -> the persistent launch -> release, so the turn goes to
 //    whichever forward's layer is READY: A's layer l + 1 waits for its own GEMM while B's layer l runs.  Events still order the
-//    whole-device launches against the slot-sized ones (two models of different widths in one process).
+//    whole-device launches against the slot-sized ones (two models of different widths in one process).  Two forwards in flight
+//    is the count that pays: with three, every recurrent launch runs beside the dense kernels of two others and is slower for it
+//    (config 4: 4.1 ms per layer against 3.85 beside one and 3.55 alone; 35.0 ms per batch against 33.7 -- also when the third
+//    forward is kept out of the turns until one of the two has finished its layers: 35.3; profiles/r06_config4.txt).
 // The ring kernel's windows (rnn_persist_ring.hip: H / 32 workgroups per direction, 50 CUs for cfgA) have slots of their own: as many as
 // fit the device side by side, at most kRingSlots; a ring launch is ordered behind every launch of the other kernels and vice versa
 // (the two families never share the device: the other kernels' grids are sized for halves and quarters of it).
@@ -99,17 +102,16 @@ struct PersistGate { std::mutex mu; hipEvent_t ev[kMaxLanes] = {nullptr, nullptr
                      int ring_cus[kRingSlots] = {0, 0, 0, 0, 0};     // CUs of the window last recorded on each ring slot (it may still be running)
                      int lock_fd = -1; bool lock_tried = false; int next_lane = 0; };
 
-// acquire: one wave spins until it has swapped the word from 0 to 1.  (Bounded: after ~4 s it goes on regardless -- two persistent
+// acquire: one wave spins until it has swapped the word from 0 to 1.  (Bounded: after a second or two it goes on regardless -- two persistent
 // kernels that then share the device time out at their hand-offs and their batches are recomputed on the per-step path.)
 __global__ void turn_acquire_kernel(unsigned* turn) {
     if (threadIdx.x != 0) return;
     unsigned spins = 0;
-    while (atomicCAS(turn, 0u, 1u) != 0u && ++spins < (1u << 22)) __builtin_amdgcn_s_sleep(32);
+    while (atomicCAS(turn, 0u, 1u) != 0u && ++spins < (1u << 20)) __builtin_amdgcn_s_sleep(32);
 }
 __global__ void turn_release_kernel(unsigned* turn) {
     if (threadIdx.x == 0) __hip_atomic_store(turn, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
-
 // slots a launch of `width` (1, 2 or kMaxLanes) takes for a handle whose home slot is `lane`: [first, first + width)
 static int gate_first(int lane, int width) { return width >= kMaxLanes ? 0 : (width == 2 ? 2 * (lane & 1) : (lane % kMaxLanes)); }
 // Under g->mu: make stream `s` wait for the slots this launch needs ...
@@ -661,9 +663,12 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
         const int cap = ring_slots >= 2 ? (m->ring8 ? rnn_persist_ring_tiles(m->geom16, B, rcus) : rnn_persist_ring4_tiles(m->geom16, B, rcus)) : 0;
         if (cap > 0) {
             const int ntiles = ceil_div(B, 16);
-            const int slots = m->inflight >= 2 ? 1 : std::min(ring_slots, kMaxLanes);
+            // windows side by side: one with batches in flight, up to four for a lone batch -- or what the caller said
+            // (dsmi_model_set_ring_windows: two where only two forwards will share the chip)
+            const int slots = m->ring_windows > 0 ? std::min(std::min(m->ring_windows, ring_slots), kMaxLanes)
+                                                  : (m->inflight >= 2 ? 1 : std::min(ring_slots, kMaxLanes));
             ring_ntw = std::min(std::max(ceil_div(ntiles, slots), 1), cap);
-            if (m->inflight < 2) ring_ntw = std::max(ring_ntw, std::min(ntiles, 2));
+            if (m->inflight < 2 && m->ring_windows <= 0) ring_ntw = std::max(ring_ntw, std::min(ntiles, 2));
             ring_nwin = std::min(ceil_div(ntiles, ring_ntw), slots);
             duo = false;
         }
@@ -691,7 +696,9 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
         if (m->drop_layer == l) { pl.drop_wg = m->drop_wg; pl.drop_step = m->drop_step; }
         const size_t cnt_words = (size_t)m->geom.D * ceil_div(B, 16) * To * kPersist16CntWords;
         (void)hipMemsetAsync(m->pcnt, 0, sizeof(unsigned) * (cnt_words + 2 * ceil_div(B, 16) + 2), s);
-        static const bool ring_xcd = [] { const char* e = std::getenv("DSMI_RING_XCD"); return !(e && e[0] == '0'); }();
+        // the four-wave ring kernel's directions by XCD half (its prologue; profiles/r06_ring_experiments.txt: 2.29 -> 1.56 GB fetched per
+        // launch); DSMI_DEBUG_RING_XCD=0 in the experiments build: by blockIdx
+        static const bool ring_xcd = [] { const char* e = exp_env("DSMI_DEBUG_RING_XCD"); return !(e && e[0] == '0'); }();
         const int total_pairs = (ceil_div(B, 16) + 1) / 2;
         const int window = duo && duo_window > 0 ? duo_window : total_pairs;
         bool ok = true;
@@ -705,7 +712,9 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
                               part * 4.0 * Dd * (GH * m->desc.rnn_hidden_size + (double)To * B * (GH + 2.0 * m->desc.rnn_hidden_size)));
             PersistGate* gate = persist_gate(m->device);
             std::lock_guard<std::mutex> lk(gate->mu);
-            const int first = nw == 1 ? m->lane % ring_slots : 0;      // a handle's own slot; several windows: from slot 0
+            // a handle's own slot; a PAIR of windows with batches in flight: the handle's own pair of slots (consecutive forwards run on
+            // consecutive handles: their pairs differ); a lone batch's windows: from slot 0
+            const int first = nw == 1 ? m->lane % ring_slots : ((nw == 2 && m->inflight >= 2 && ring_slots >= 4) ? 2 * (m->lane & 1) : 0);
             const int rcus = rnn_persist_ring_cus(m->geom16);
             ring_gate_wait(gate, s, first, nw, rcus, m->n_cus);
             // Which form of the ring kernel.  Four waves (one per SIMD, the cell in the MFMAs' shadows) where a window walks three
@@ -1056,6 +1065,12 @@ extern "C" int dsmi_recompute_count(const dsmi_model* m) { return m ? m->recompu
 extern "C" int dsmi_model_set_inflight(dsmi_model* m, int batches) {
     if (!m || batches < 1) return DSMI_ERR_INVALID;
     m->inflight = batches;
+    return DSMI_OK;
+}
+
+extern "C" int dsmi_model_set_ring_windows(dsmi_model* m, int windows) {
+    if (!m || windows < 0) return DSMI_ERR_INVALID;
+    m->ring_windows = windows;
     return DSMI_OK;
 }
 

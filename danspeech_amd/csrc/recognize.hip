@@ -6,6 +6,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <numeric>
 #include <thread>
@@ -100,6 +101,24 @@ static int run_from_device(dsmi_session* s, const void* pcm_dev, const int64_t* 
     return DSMI_OK;
 }
 
+// See include/dsmi.h: float64 samples that are integers in int16's range, as int16 (branch-free blocks: the compiler vectorises them).
+extern "C" int dsmi_pack_pcm_i16(const double* src, int64_t n, int16_t* dst) {
+    if (!src || !dst || n < 0) return 0;
+    for (int64_t i0 = 0; i0 < n; i0 += 4096) {
+        const int64_t m = std::min<int64_t>(4096, n - i0);
+        int bad = 0;
+        for (int64_t i = 0; i < m; ++i) {
+            const double v = src[i0 + i];
+            const double c = (v >= -32768.0 && v <= 32767.0) ? v : 0.0;       // (a NaN fails both comparisons and then differs from c)
+            const int16_t q = (int16_t)(int32_t)c;
+            bad |= (int)((double)q != v);
+            dst[i0 + i] = q;
+        }
+        if (bad) return 0;
+    }
+    return 1;
+}
+
 // Stage, upload, spectrograms, network: everything up to the probabilities, asynchronous on the session's stream.
 extern "C" int dsmi_recognize_enqueue(dsmi_session* s, const void* const* clips_host, const int64_t* n_samples_host, int pcm_dtype, int B) {
     if (!s) return DSMI_ERR_INVALID;
@@ -132,21 +151,33 @@ extern "C" int dsmi_recognize_enqueue(dsmi_session* s, const void* const* clips_
     } else {
         (void)hipStreamSynchronize(s->stream);       // the previous batch's upload has left the staging buffer
     }
-    auto copy = [&](int lo, int hi) {
-        for (int pos = lo; pos < hi; ++pos)
-            std::memcpy(s->pin + off[(size_t)pos], clips_host[s->order[(size_t)pos]], off[(size_t)pos + 1] - off[(size_t)pos]);
+    // float64 clips (what load_audio returns) travel as int16 where that is exact (dsmi_pack_pcm_i16): a quarter of the upload
+    std::atomic<int> exact{pcm_dtype == DSMI_PCM_F64 ? 1 : 0};
+    auto copy = [&](int lo, int hi, bool pack) {
+        for (int pos = lo; pos < hi; ++pos) {
+            const void* src = clips_host[s->order[(size_t)pos]];
+            if (!pack) std::memcpy(s->pin + off[(size_t)pos], src, off[(size_t)pos + 1] - off[(size_t)pos]);
+            else if (exact.load(std::memory_order_relaxed) &&
+                     !dsmi_pack_pcm_i16((const double*)src, n[(size_t)pos], (int16_t*)(s->pin + off[(size_t)pos] / 4))) exact.store(0);
+        }
     };
-    if (bytes >= ((size_t)8 << 20) && B >= 8) {       // tens of megabytes: four host threads fill the pinned buffer
-        std::thread th[3];
-        for (int q = 0; q < 3; ++q) th[q] = std::thread(copy, B * (q + 1) / 4, B * (q + 2) / 4);
-        copy(0, B / 4);
-        for (auto& t : th) t.join();
-    } else {
-        copy(0, B);
-    }
-    if (!grow(s, &s->pcm, &s->pcm_cap, bytes)) return sfail(s, DSMI_ERR_NOMEM, "hipMalloc failed");
-    if (hipMemcpyAsync(s->pcm, s->pin, bytes, hipMemcpyHostToDevice, s->stream) != hipSuccess) return sfail(s, DSMI_ERR_HIP, "upload failed");
-    return run_from_device(s, s->pcm, n.data(), pcm_dtype, B);
+    auto fill = [&](bool pack) {
+        if (bytes >= ((size_t)8 << 20) && B >= 8) {       // tens of megabytes: four host threads fill the pinned buffer
+            std::thread th[3];
+            for (int q = 0; q < 3; ++q) th[q] = std::thread(copy, B * (q + 1) / 4, B * (q + 2) / 4, pack);
+            copy(0, B / 4, pack);
+            for (auto& t : th) t.join();
+        } else {
+            copy(0, B, pack);
+        }
+    };
+    if (exact.load()) fill(true);
+    const bool as_i16 = exact.load() != 0;
+    if (!as_i16) fill(false);
+    const size_t up = as_i16 ? bytes / 4 : bytes;
+    if (!grow(s, &s->pcm, &s->pcm_cap, up)) return sfail(s, DSMI_ERR_NOMEM, "hipMalloc failed");
+    if (hipMemcpyAsync(s->pcm, s->pin, up, hipMemcpyHostToDevice, s->stream) != hipSuccess) return sfail(s, DSMI_ERR_HIP, "upload failed");
+    return run_from_device(s, s->pcm, n.data(), as_i16 ? DSMI_PCM_I16 : pcm_dtype, B);
 }
 
 // The same for clips that already sit back to back in device memory, longest first -- a shard dsmi_comm_scatter delivered:

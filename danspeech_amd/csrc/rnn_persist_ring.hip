@@ -62,6 +62,7 @@ struct RingArgs {
     int tile0, ntw, tile_end;  // window z (blockIdx.z) walks tiles tile0 + z * ntw .. + ntw - 1, below tile_end
     unsigned spin_limit;
     int drop_wg, drop_step;
+    unsigned* tickets;         // [windows][2 directions] zeroed before the launch -> directions by XCD half (null: by blockIdx): rnn_persist_ring4.hip
     int skip;                  // timing experiments only (DSMI_DEBUG_RING_SKIP; results are garbage): 1 no state DMA, 2 no MFMAs, 4 no polls,
                                // 8 no x-projection requests, 16 no output / publish stores, 32 no wave priorities, 64 every slot ~500 cycles longer
                                // (128: nothing -- the build with the switches as it stands)
@@ -115,7 +116,24 @@ __global__ __launch_bounds__(RNT, 2) void rnn_persist_ring_kernel(RingArgs p) {
     const int hx = v >> 2, vh = v & 3;
     const int tidh = tid & 255;
     const int ln = lane & 15, lg = lane >> 4;
-    const int w32 = blockIdx.x, d = blockIdx.y;
+    // (direction, unit group) by XCD half, as in the four-wave form (rnn_persist_ring4.hip: four L2s fetch a tile's state, not eight)
+    int w32 = blockIdx.x, d = blockIdx.y;
+    if (p.tickets && p.D == 2) {
+        const int nw = (p.nwg16 + 1) >> 1;
+        if (tid == 0) {
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            unsigned* tk = p.tickets + 2 * blockIdx.z;
+            unsigned want = (xcc >> 2) & 1u;
+            unsigned t = atomicAdd(&tk[want], 1u);
+            if (t >= (unsigned)nw) { want ^= 1u; t = atomicAdd(&tk[want], 1u); }
+            sync[30] = (int)want; sync[31] = (int)t;
+        }
+        __syncthreads();
+        d = __builtin_amdgcn_readfirstlane(sync[30]);
+        w32 = __builtin_amdgcn_readfirstlane(sync[31]);
+        __syncthreads();         // (sync[] is zeroed below)
+    }
     const int tile0 = p.tile0 + (int)blockIdx.z * p.ntw;
     const int nt = min(min(p.ntw, p.tile_end - tile0), NT);
     const int w16 = 2 * w32 + hx;
@@ -562,7 +580,7 @@ bool launch_rnn_persist_ring(const RnnPersist16Launch& p, hipStream_t s) {
     a.tile_end = std::min(a.ntiles, a.tile0 + a.ntw * std::max(p.nwin, 1));
     if (a.ntw < 1 || a.ntw > RMINT || a.tile_end <= a.tile0) return false;
     if ((size_t)p.T * p.B * p.g.Kp * 4 >= (1ull << 31)) return false;          // a direction's output rows below 2 GiB (store offsets, see OOR)
-    a.spin_limit = p.spin_limit; a.drop_wg = p.drop_wg; a.drop_step = p.drop_step; a.dbg = p.dbg;
+    a.spin_limit = p.spin_limit; a.drop_wg = p.drop_wg; a.drop_step = p.drop_step; a.dbg = p.dbg; a.tickets = p.tickets;
     static const int skip = exp_env("DSMI_DEBUG_RING_SKIP") ? std::atoi(exp_env("DSMI_DEBUG_RING_SKIP")) : 0;
     a.skip = skip;
     switch (p.g.kind) {

@@ -164,6 +164,11 @@ class DeepSpeech(object):
         if self._native is not None:
             self._native.set_inflight(batches)
 
+    def set_ring_windows(self, windows):
+        """``dsmi_model_set_ring_windows``: 2 when only two forwards will share the chip (0: by ``set_inflight``)."""
+        if self._native is not None:
+            self._native.set_ring_windows(windows)
+
     def replica(self):
         """A second handle on the same weights and device (own workspaces): a caller that keeps two batches in flight
         alternates between the model and its replica, so that the recurrent layers of the two batches share the CUs

@@ -134,6 +134,12 @@ int dsmi_features(dsmi_frontend* f, const void* pcm_dev, int pcm_dtype, const in
  * 1.7552755216970917, :89-94).  The sample bookkeeping of :112-133 (hop carry-over) stays with the caller.
  * feat_dev [n_freq][t_stride]; *frames_host = frames written.  Synchronous (the statistics pass through
  * the host).  Start an utterance with state3 = {0, 0, 0} (parser.reset(), :166-170). */
+/* Host only.  load_audio hands recognize() float64 samples (reference resources.py:640) that are, for every audio FILE, integers in
+ * int16's range: such a clip travels to the device as int16 -- a quarter of the bytes, the same features bit for bit (dsmi_features
+ * widens to float64 exactly).  Returns 1 when every one of the n samples is an integer in [-32768, 32767] and dst holds them, 0
+ * when one is not (dst is then unspecified and the caller uploads the float64 samples).  Used by the staging of
+ * dsmi_recognize_enqueue and of the Python pipeline. */
+int dsmi_pack_pcm_i16(const double* src, int64_t n, int16_t* dst);
 int dsmi_features_stream(dsmi_frontend* f, const void* pcm_dev, int pcm_dtype, int64_t n_samples, double* state3,
                          float* feat_dev, int t_stride, int32_t* frames_host, void* stream);
 
@@ -199,6 +205,12 @@ int dsmi_forward_ready(dsmi_model* m);
  * BASELINE's 5 x BiGRU 800) where the shape allows it, so that the two batches' recurrent layers run side by side on
  * disjoint halves of the chip.  Results are the same either way (within the parity bound). */
 int dsmi_model_set_inflight(dsmi_model* m, int batches);
+/* How many ring windows (rnn_persist_ring*.hip: H / 32 workgroups per direction each, 50 CUs for 5 x BiGRU 800) the recurrent layers of
+ * this handle's NEXT forwards take side by side.  0 (default): what set_inflight implies -- one window with batches in flight, as
+ * many as the batch has tile pairs (up to four) for a lone batch.  2: a caller that knows that only two forwards will share the
+ * chip (the last forwards of a short call) gives each two windows of half the tiles: 2.7 instead of 3.2 ms per 64-clip layer.
+ * Shapes the ring kernels do not take ignore it.  Results are the same either way (within the parity bound). */
+int dsmi_model_set_ring_windows(dsmi_model* m, int windows);
 /* Number of batches / layers this handle had to recompute after a hand-off timeout (0 in normal operation). */
 int dsmi_recompute_count(const dsmi_model* m);
 

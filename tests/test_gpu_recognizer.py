@@ -173,6 +173,31 @@ def test_staging_slots_are_sized_by_the_largest_forward_of_the_process():
     assert len(used) >= 4 and all(sl["buf"].numel() >= high for sl in used[1:]), [sl["buf"].numel() for sl in used]
 
 
+def test_float64_clips_travel_as_int16_where_that_is_exact():
+    """``SpectrogramAudioParser.stage``: float64 clips whose samples are int16 integers (what ``load_audio`` returns for a file,
+    reference resources.py:640) are uploaded as int16 -- and give the SAME features, bit for bit, as the float64 upload; one
+    fractional sample anywhere in the batch and the whole batch travels as float64."""
+    from danspeech_amd.audio.parsers import SpectrogramAudioParser
+    clips = [syn.make_clip(i, n) for i, n in enumerate([48000, 40000, 40000, 33333, 16000, 16000, 9000, 8000, 8000])]
+    packed, plain = SpectrogramAudioParser(device=0), SpectrogramAudioParser(device=0)
+    plain.pack_int16 = False
+    a = packed.stage(clips)
+    b = plain.stage(clips)
+    assert a.itemsize == 2 and b.itemsize == 8
+    fa, na = packed.parse_batch(a)
+    fb, nb = plain.parse_batch(b)
+    torch.cuda.synchronize()
+    assert np.array_equal(na, nb) and torch.equal(fa, fb)
+    odd = [c.copy() for c in clips]
+    odd[6][1234] += 0.25
+    c = packed.stage(odd)
+    assert c.itemsize == 8
+    fc, _ = packed.parse_batch(c)
+    fd, _ = plain.parse_batch(plain.stage(odd))
+    torch.cuda.synchronize()
+    assert torch.equal(fc, fd) and not torch.equal(fc, fa)
+
+
 def test_wide_model_stream_of_batches_runs_clean():
     """Config 4's width (H = 1200: the tile-walking recurrent kernel, four tiles per workgroup) as a stream of 64-clip batches, with the
     forwards in flight the engine picks and with four: every batch equals the single call, and no hand-off of any handle timed out

@@ -198,7 +198,10 @@ def test_transcribe_batches_cuts_large_batches_and_restores_the_callers_order():
     eng = object.__new__(DanSpeechRecognizer)
     seen = []
 
-    def forwards(batches, show_all=False, lanes=None, merge_clips=None):
+    totals = []
+
+    def forwards(batches, show_all=False, lanes=None, merge_clips=None, total=None):
+        totals.append(total)
         for b in batches:
             seen.append([len(c) for c in b])
             yield [(len(c), float(c[0])) for c in b]
@@ -211,6 +214,7 @@ def test_transcribe_batches_cuts_large_batches_and_restores_the_callers_order():
     for b, o in zip(batches, out):
         assert o == [(len(c), float(c[0])) for c in b]
     assert [len(s) for s in seen] == [3, 64, 64, 22, 0, 64, 64, 1, 1]
+    assert totals == [9]                                        # a sized source: the pipeline is told how many pieces will come
     for s in seen[1:4] + seen[6:8]:
         assert s == sorted(s, reverse=True)                     # every piece longest first ...
     assert seen[1][-1] >= seen[2][0] and seen[2][-1] >= seen[3][0]      # ... and the pieces of a batch in that order too
@@ -231,3 +235,22 @@ def test_transcribe_batches_cuts_large_batches_and_restores_the_callers_order():
     next(g)
     g.close()
     assert closed == [True]
+
+
+def test_pack_pcm_i16_says_exactly_when_a_clip_is_int16():
+    """``dsmi_pack_pcm_i16`` (host only): float64 samples that are integers in int16's range come out as int16 and the call says 1;
+    one sample that is not -- a fraction, beyond the range on either side, NaN, infinity -- and it says 0."""
+    from danspeech_amd import _native
+    L = _native.lib()
+    rng = np.random.default_rng(3)
+    x = np.round(rng.normal(0, 9000, 70001)).clip(-32768, 32767)
+    x[:3] = (-32768.0, 32767.0, -0.0)
+    d = np.full(len(x), 77, dtype=np.int16)
+    assert L.dsmi_pack_pcm_i16(x.ctypes.data, len(x), d.ctypes.data) == 1 and np.array_equal(d.astype(np.float64), x)
+    for at in (0, 4095, 4096, 70000):
+        for bad in (0.5, -1e-9, 32768.0, -32769.0, 1e300, float("nan"), float("inf"), -float("inf")):
+            y = x.copy()
+            y[at] = bad
+            assert L.dsmi_pack_pcm_i16(y.ctypes.data, len(y), d.ctypes.data) == 0, (at, bad)
+    assert L.dsmi_pack_pcm_i16(x.ctypes.data, 0, d.ctypes.data) == 1           # nothing to say about no samples
+    assert L.dsmi_pack_pcm_i16(None, 5, d.ctypes.data) == 0

@@ -35,22 +35,23 @@ def run(name, rec, B, seconds, reps=3):
         out = rec.recognize_batch(clips)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
-    streams = []
-    nb = max(4 * reps + 2, 1024 // B)
-    for lanes in (2, 4):
-        rec.danspeech_recognizer.pipeline_lanes = lanes
-        for _ in rec.recognize_batches([clips] * max(6, 512 // B)):   # (the pipeline's own buffers: replica handles, decoder slots, allocator)
+    # a stream of batches with the forwards in flight the engine picks for this model and batch size (four where a forward is one
+    # ring window, see DanSpeechRecognizer._lanes_that_pay; batches of more than 64 clips are cut into 64-clip forwards)
+    nb = max(4 * reps + 2, 2048 // B)
+    eng = rec.danspeech_recognizer
+    for _ in range(2):
+        for _r in rec.recognize_batches([clips] * max(6, 512 // B)):   # (the pipeline's own buffers: replica handles, decoder slots, allocator)
             pass
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        n = 0
-        for res in rec.recognize_batches([clips] * nb):
-            n += 1
-            assert res == out
-        torch.cuda.synchronize()
-        streams.append((time.perf_counter() - t0) / n)
-    print("%-58s one call %7.1f ms = %7.0f audio-s/s | stream of %d batches, 2 / 4 forwards in flight %7.1f / %7.1f ms per batch = %7.0f audio-s/s"
-          % (name, dt * 1e3, B * seconds / dt, nb, streams[0] * 1e3, streams[1] * 1e3, B * seconds / min(streams)), flush=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 0
+    for res in rec.recognize_batches([clips] * nb):
+        n += 1
+        assert res == out
+    torch.cuda.synchronize()
+    stream = (time.perf_counter() - t0) / n
+    print("%-58s one call %7.1f ms = %7.0f audio-s/s | stream of %d batches, %d forwards of <= %d clips in flight %7.2f ms per batch = %7.0f audio-s/s"
+          % (name, dt * 1e3, B * seconds / dt, nb, 1 + len(eng._replicas), min(B, eng.pipeline_merge_clips), stream * 1e3, B * seconds / stream), flush=True)
     return out
 
 

@@ -255,47 +255,7 @@ class DanSpeechRecognizer(object):
         handles = [self.model] + [r[0] for r in self._replicas[:count - 1]]
         parsers = [self.audio_parser] + [r[1] for r in self._replicas[:count - 1]]
         streams = [torch.cuda.current_stream(self._device_index())] + [self._side_stream("lane %d" % k) for k in range(1, len(handles))]
-        if len(streams) > getattr(self, "_copy_engines_warm", 1):
-            self._warm_copy_engines(streams)
-            self._copy_engines_warm = len(streams)
         return handles, parsers, streams
-
-    def _warm_copy_engines(self, streams):
-        """The runtime hands a host-to-device copy to the lowest DMA engine that is free, and the FIRST copy a process gives an
-        engine holds the calling thread until that copy is done (5.8 ms for a forward's 82 MB: profiles/r06_second_call_stall.txt
-        -- inside `hipMemcpyAsync`, behind `hsa_amd_memory_async_copy_on_engine`).  A pipeline's lanes upload side by side, so
-        engines 2, 3, 4 meet their first copy whenever the lanes' uploads first overlap: in the process's second call, as it
-        happened.  Here, once per set of lanes: one 64 MB copy per lane, issued from as many host threads AT THE SAME MOMENT (a
-        held thread must not keep the next lane's copy from starting: only copies in flight together reach the higher engines),
-        repeated until a whole round returns at once."""
-        import threading
-        import time
-        import torch
-        index = self._device_index()
-        dev = "cuda:%d" % index
-        size = 64 << 20
-        hosts = [torch.empty(size, dtype=torch.uint8).pin_memory() for _ in streams]
-        dst = [torch.empty(size, dtype=torch.uint8, device=dev) for _ in streams]
-        for _ in range(4):
-            gate = threading.Barrier(len(streams))
-            took = [0.0] * len(streams)
-
-            def one(k):
-                torch.cuda.set_device(index)
-                with torch.cuda.stream(streams[k]):
-                    gate.wait()
-                    t = time.perf_counter()
-                    dst[k].copy_(hosts[k], non_blocking=True)
-                    took[k] = time.perf_counter() - t
-            threads = [threading.Thread(target=one, args=(k,)) for k in range(len(streams))]
-            for t in threads:
-                t.start()
-            for t in threads:
-                t.join()
-            for s in streams:
-                s.synchronize()
-            if max(took) < 5e-4:
-                break
 
     def _lanes_that_pay(self, most, clips):
         """Forwards in flight when the caller did not say.  Several forwards side by side pay where the recurrent kernel of
@@ -388,9 +348,14 @@ class DanSpeechRecognizer(object):
             for h in hs:
                 if hasattr(h, "set_inflight"):
                     h.set_inflight(max(2, len(hs)) if len(hs) > 1 else 1)     # (re-stated per forward in the loop below)
-            for p in ps:
+            for p, st in zip(ps, ss):
                 p.share_copy_stream = searching      # a search kernel on the decode stream: fewer streams
                 p.upload_on_compute_stream = True    # no copy stream in the pipeline: see SpectrogramAudioParser.stage
+                # ... and the upload is ISSUED where the clips are staged, on the helper thread, into the lane's own stream: the first
+                # copy a process hands a DMA engine holds its caller for 6-12 ms (hipMemcpyAsync creating the engine's queue; which
+                # engine a copy gets depends on which are busy, so new ones are met well into a process's second call:
+                # profiles/r06_second_call_stall.txt) -- the thread that feeds the other lanes must not be the one held
+                p.upload_stream = st
             return hs, ps, ss
         # Depth of the pipeline in forwards.  Greedy decoding is a short host-synchronous step.  A beam search is a kernel of its
         # own that starts when its forward ends: one more job in flight (the oldest forward's search) keeps every lane's forward

@@ -204,6 +204,15 @@ class SpectrogramAudioParser(AudioParser):
             # 7.58, this 5.89-5.98.
             if slot["dev"] is None or slot["dev"].numel() < nbytes:
                 slot["dev"] = torch.empty(max(nbytes, slot["high"]), dtype=torch.uint8, device="cuda:%d" % self.device)
+            up = getattr(self, "upload_stream", None)
+            if up is not None:
+                # the lane's stream is known: the upload goes into it from HERE (the staging thread), behind the lane's running
+                # forward and ahead of this one's kernels -- it starts the moment that forward ends, and a hipMemcpyAsync that
+                # holds its caller (see DanSpeechRecognizer.transcribe_batches) holds this thread, not the one that feeds the lanes
+                with torch.cuda.stream(up):
+                    pcm = slot["dev"][:nbytes]
+                    pcm.copy_(slot["buf"][:nbytes], non_blocking=True)
+                return StagedClips(pcm, n, dtype.itemsize, None, slot)
             return StagedClips(slot["buf"][:nbytes], n, dtype.itemsize, None, slot)
         if getattr(self, "share_copy_stream", False):
             up = _shared_copy_stream(self.device)

@@ -1077,6 +1077,14 @@ extern "C" int dsmi_model_set_ring_windows(dsmi_model* m, int windows) {
 extern "C" int dsmi_set_profiling(dsmi_model* m, int level) {
     if (!m) return DSMI_ERR_INVALID;
     m->profiling = level < 0 ? 0 : (level > 2 ? 2 : level);
+    // the events of the stamped launches are made HERE, not at the launches: an event's first creation is tens of microseconds of
+    // the caller's thread, and a region that is being timed would pay for a hundred of them (bench.py: 20 steps = 80 stamped launches)
+    if (m->profiling == 2 && hipSetDevice(m->device) == hipSuccess)
+        while (m->kt.free_events.size() < 256) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) break;
+            m->kt.free_events.push_back(e);
+        }
     return DSMI_OK;
 }
 

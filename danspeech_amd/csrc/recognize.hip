@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <immintrin.h>
 #include <cstring>
 #include <numeric>
 #include <thread>
@@ -101,9 +102,39 @@ static int run_from_device(dsmi_session* s, const void* pcm_dev, const int64_t* 
     return DSMI_OK;
 }
 
-// See include/dsmi.h: float64 samples that are integers in int16's range, as int16 (branch-free blocks: the compiler vectorises them).
+// See include/dsmi.h: float64 samples that are integers in int16's range, as int16.  Eight samples per step on AVX2 (the host code is
+// built for the x86-64 baseline; the wide path is chosen at run time): truncate to int32, widen back, compare with the sample (a
+// fraction, a NaN or anything beyond int32 differs), compare with int16's range, saturating pack.
+__attribute__((target("avx2"))) static int pack_i16_avx2(const double* src, int64_t n, int16_t* dst) {
+    const __m256d lo = _mm256_set1_pd(-32768.0), hi = _mm256_set1_pd(32767.0);
+    int64_t i = 0;
+    for (; i + 8 <= n;) {
+        const int64_t stop = std::min<int64_t>(n - 7, i + 4096);
+        __m256d bad = _mm256_setzero_pd();
+        for (; i < stop; i += 8) {
+            const __m256d a = _mm256_loadu_pd(src + i), b = _mm256_loadu_pd(src + i + 4);
+            const __m128i qa = _mm256_cvttpd_epi32(a), qb = _mm256_cvttpd_epi32(b);
+            bad = _mm256_or_pd(bad, _mm256_or_pd(_mm256_cmp_pd(_mm256_cvtepi32_pd(qa), a, _CMP_NEQ_UQ), _mm256_cmp_pd(_mm256_cvtepi32_pd(qb), b, _CMP_NEQ_UQ)));
+            bad = _mm256_or_pd(bad, _mm256_or_pd(_mm256_or_pd(_mm256_cmp_pd(a, lo, _CMP_LT_OQ), _mm256_cmp_pd(a, hi, _CMP_GT_OQ)),
+                                                 _mm256_or_pd(_mm256_cmp_pd(b, lo, _CMP_LT_OQ), _mm256_cmp_pd(b, hi, _CMP_GT_OQ))));
+            _mm_storeu_si128(reinterpret_cast<__m128i*>(dst + i), _mm_packs_epi32(qa, qb));
+        }
+        if (_mm256_movemask_pd(bad)) return 0;
+    }
+    for (; i < n; ++i) {
+        const double v = src[i];
+        const double c = (v >= -32768.0 && v <= 32767.0) ? v : 0.0;
+        const int16_t q = (int16_t)(int32_t)c;
+        if ((double)q != v) return 0;
+        dst[i] = q;
+    }
+    return 1;
+}
+
 extern "C" int dsmi_pack_pcm_i16(const double* src, int64_t n, int16_t* dst) {
     if (!src || !dst || n < 0) return 0;
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2) return pack_i16_avx2(src, n, dst);
     for (int64_t i0 = 0; i0 < n; i0 += 4096) {
         const int64_t m = std::min<int64_t>(4096, n - i0);
         int bad = 0;

@@ -5,16 +5,17 @@
 #    passes (tools/pmc_collect.sh), the BASELINE configs through the public surface with their kernel stats, the beam counters.
 # Every text artefact starts with the commit it was taken from.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r06}
 COMMIT=${2:-unknown}
 export TMPDIR=/tmp
 O=gpurun_out
 mkdir -p $O
 hdr() { echo "# commit $COMMIT, $(date -u +%Y-%m-%dT%H:%MZ), MI355X (gfx950), tools/final_profiles.sh"; }
 
-# 1. the bench line (defaults: what the driver runs)
+# 1. the bench line: the defaults (96 timed steps), and the driver's own command
 python3 bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 tail -c 600 $O/${TAG}_bench.json | head -c 300; echo
+python3 bench.py --steps 20 --warmup 5 > $O/${TAG}_bench_driver_command.json 2> $O/${TAG}_bench_driver_command.err
 
 # 2. kernel stats + trace of the same timed command (without the CPU baseline and the side paths: their kernels are not the timed ones)
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_trace -- python3 bench.py --no-cpu-baseline --no-side-paths > $O/${TAG}_trace_bench.json 2> $O/${TAG}_trace.log
@@ -40,6 +41,10 @@ for C in 3 4 5; do
     rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_cfg${C} -- python3 tools/run_configs.py $C > $O/${TAG}_cfg${C}.log 2>&1
     S=$(ls $O/${TAG}_cfg${C}/*/*kernel_stats.csv | head -1)
     { hdr; echo "# rocprofv3 --kernel-trace --stats -- python3 tools/run_configs.py $C"; cat $S; } > $O/${TAG}_kernel_stats_config${C}.csv
+    if [ $C = 4 ]; then      # what runs beside config 4's whole-device recurrent launches (the turn lock)
+        F=$(ls $O/${TAG}_cfg${C}/*/*kernel_trace.csv | head -1)
+        { hdr; echo "# tools/exp/overlap_report.py over the kernel trace of tools/run_configs.py 4"; python3 tools/exp/overlap_report.py $F 60; } > $O/${TAG}_config4_overlap.txt
+    fi
     rm -f $O/${TAG}_cfg${C}/*/*kernel_trace.csv
 done
 

@@ -260,9 +260,10 @@ class DanSpeechRecognizer(object):
     def _lanes_that_pay(self, most, clips):
         """Forwards in flight when the caller did not say.  Several forwards side by side pay where the recurrent kernel of
         each holds a fifth of the chip (the ring form: GRU / RNN up to 896 units, LSTM up to 512, one window of up to 64
-        clips) and the dense kernels of the others fill the rest.  A forward of more clips, or a model whose recurrent kernel
-        takes the whole device, fills the chip with two in flight: four measure the same within the noise
-        (profiles/r04_run_configs.txt, configs 4 and 5) and cost two more sets of workspaces."""
+        clips -- ``transcribe_batches`` cuts larger batches to that) and the dense kernels of the others fill the rest.  A model
+        whose recurrent kernel takes the whole device runs two: their recurrent launches take turns (csrc/api.hip, the turn
+        lock) and each forward's GEMM runs beside the other's launch; a third forward only slows those launches down (config 4:
+        33.7 ms per batch with two, 35.0 with three, 37.1 with four; profiles/r06_config4.txt)."""
         hidden, kind = getattr(self.model, "rnn_hidden_size", 0), getattr(self.model, "rnn_type", "gru")
         ring = hidden % 16 == 0 and hidden <= (512 if kind == "lstm" else 896)
         return most if ring and clips <= 64 else min(most, 2)

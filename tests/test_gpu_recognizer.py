@@ -173,6 +173,73 @@ def test_staging_slots_are_sized_by_the_largest_forward_of_the_process():
     assert len(used) >= 4 and all(sl["buf"].numel() >= high for sl in used[1:]), [sl["buf"].numel() for sl in used]
 
 
+def test_short_calls_take_other_kernel_forms_and_say_the_same():
+    """A call of one, two, three or four batches from a LIST (a sized source: the pipeline knows what is to come) runs its forwards
+    on a lone batch's kernels or on two ring windows each (``dsmi_model_set_ring_windows``), a generator of the same batches on the
+    forms of a long call: every result equals the single call's, nothing is recomputed, and the hints are given back at the end."""
+    from danspeech_amd import Recognizer
+    model, sd, cfg = _model("small", 128, 3, seed=12)
+    rec = Recognizer(model=model)
+    eng = rec.danspeech_recognizer
+    clips = [syn.make_clip(i, 9000 + 400 * (i % 5)) for i in range(32)]
+    want = rec.recognize_batch(clips)
+    assert want[:4] == _oracle_greedy(sd, cfg, clips[:4])
+    for n in (1, 2, 3, 4, 6):
+        assert list(rec.recognize_batches([clips] * n)) == [want] * n, n
+        assert list(rec.recognize_batches(clips for _ in range(n))) == [want] * n, n
+    handles = [eng.model._native] + [r[0]._native for r in eng._replicas]
+    assert len(handles) == 4 and [h.recompute_count() for h in handles] == [0, 0, 0, 0]
+    # the two-window form by hand, against the one-window form: the same probabilities within the parity bound
+    from danspeech_amd import _native
+    m = _native.NativeModel(cfg, sd)
+    fe = _native.NativeFrontend()
+    big = clips + clips
+    order = np.argsort([-len(c) for c in big], kind="stable")
+    n = np.array([len(big[i]) for i in order], dtype=np.int64)
+    feat, frames = fe.features(torch.from_numpy(np.concatenate([big[i] for i in order])).cuda(), n)
+    m.set_inflight(4)
+    p1, ol = m.forward(feat, frames)
+    p1 = p1.cpu().numpy()
+    m.set_ring_windows(2)
+    p2, _ = m.forward(feat, frames)
+    p2 = p2.cpu().numpy()
+    m.set_ring_windows(0)
+    assert m.recompute_count() == 0
+    assert max(float(np.abs(p1[b, :ol[b]] - p2[b, :ol[b]]).max()) for b in range(len(big))) < 5e-5
+    m.close(); fe.close()
+
+
+def test_a_ring_model_and_a_whole_device_model_in_flight_together():
+    """Two engines used at once from two threads: one model the ring kernels take (slot-sized windows, ordered by events) and one
+    whose recurrent kernel takes the whole device (turns through the device lock, api.hip) -- the two families are ordered
+    against each other by events in enqueue order.  Every batch equals its engine's single call; no hand-off timed out."""
+    import threading
+    from danspeech_amd import Recognizer
+    ring, _, _ = _model("ring", 128, 2, seed=21)
+    wide, _, _ = _model("wide", 912, 2, seed=22)
+    recs = [Recognizer(model=ring), Recognizer(model=wide)]
+    clips = [syn.make_clip(i, 12000 + 300 * (i % 4)) for i in range(24)]
+    want = [r.recognize_batch(clips) for r in recs]
+    got, errs = [None, None], []
+
+    def run(k):
+        try:
+            torch.cuda.set_device(0)
+            got[k] = list(recs[k].recognize_batches([clips] * 6))
+        except Exception as e:          # (reported below: an assertion in a thread would pass unnoticed)
+            errs.append(repr(e))
+    threads = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errs, errs
+    for k in range(2):
+        assert got[k] == [want[k]] * 6, k
+        eng = recs[k].danspeech_recognizer
+        assert all(h.recompute_count() == 0 for h in [eng.model._native] + [r[0]._native for r in eng._replicas])
+
+
 def test_float64_clips_travel_as_int16_where_that_is_exact():
     """``SpectrogramAudioParser.stage``: float64 clips whose samples are int16 integers (what ``load_audio`` returns for a file,
     reference resources.py:640) are uploaded as int16 -- and give the SAME features, bit for bit, as the float64 upload; one

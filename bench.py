@@ -351,7 +351,9 @@ def main(argv=None):
     def run(steps):
         """`steps` batches through recognize_batches; the transcripts of every step gathered to rank 0."""
         out = None
-        for res in rec.recognize_batches(host_clips for _ in range(steps)):
+        # (a LIST of `steps` batches, as a caller with its clips in hand passes them: the pipeline then knows where the call ends and
+        # deals its last round of forwards evenly over the lanes -- 20 steps are eight forwards of 64 clips and four of 32)
+        for res in rec.recognize_batches([host_clips] * steps):
             if world > 1:
                 with (torch.cuda.stream(gather_stream) if gather_stream is not None else contextlib.nullcontext()):
                     out = parallel.gather_texts(res, positions, B * world, cap, rank, world, dev)
@@ -465,7 +467,10 @@ def main(argv=None):
                                 else "PROFILING RUN, not the metric's entry: Recognizer.recognize_batches(DeviceClips), float64 PCM resident in HBM",
                        "clips_per_gpu": B, "clip_seconds": n_samples / 16000.0, "parallelism": "utterance-dp%d" % world,
                        "forwards_in_flight": P, "clips_per_forward": merge_clips,
-                       "batches_in_flight": P * max(merge_clips // B, 1)},
+                       "batches_in_flight": P * max(merge_clips // B, 1),
+                       "last_round": "the call's last round of forwards is dealt evenly over the lanes (a sized source): the timed call's "
+                                     "launches are of %d clips, its last %s of fewer -- roofline.flops_per_launch and avg_launch_us "
+                                     "are means over all of them" % (merge_clips, "round's") if eng is not None and eng.pipeline_balance_tail else None},
             "roofline": roof,
             # every sampled kernel kind: mean dispatch time, ALGORITHMIC rates (SURVEY 8(d) FLOPs and bytes) and, where a
             # counter pass exists, the HBM/fabric bytes per launch it measured (FETCH_SIZE x2 + WRITE_SIZE) and that rate;

@@ -245,6 +245,7 @@ class DanSpeechRecognizer(object):
     # 16-clip tiles per workgroup, and its cost per clip falls with the tiles it walks)
     pipeline_lanes = 4
     pipeline_merge_clips = 64
+    pipeline_balance_tail = True         # a sized source's last round of forwards is dealt evenly over the lanes (tail_plan)
 
     def _lanes(self, count):
         """The model handles, parsers and streams of the pipeline's forwards in flight: the engine's own and `count - 1` replicas."""
@@ -378,6 +379,26 @@ class DanSpeechRecognizer(object):
                 taken[0] += 1
             return b
 
+        plan = [None, 0]                         # the call's last round, once it is known: batches per forward; forwards put together so far
+
+        def tail_plan(first_len):
+            """A sized source's LAST ROUND of forwards is dealt evenly over the lanes: 20 batches of 32 clips on four lanes are
+            eight forwards of 64 clips and then four of 32 -- not ten of 64, whose last two run on two lanes while the other two
+            stand empty (a 20-batch call: 115 -> @@ ms, profiles/r06_short_calls.txt).  -> batches this forward may merge, or None."""
+            index, plan[1] = plan[1], plan[1] + 1
+            if total is None or merge_clips <= 0 or lanes < 2 or not self.pipeline_balance_tail:
+                return None
+            if plan[0] is None:
+                if index % lanes:                     # rounds start on the first lane
+                    return None
+                full = max(1, merge_clips // max(first_len, 1))
+                rem = total - taken[0] + (1 if held[1] else 0) + 1           # batches not yet in a forward, this one's first included
+                if rem > lanes * full:
+                    return None
+                k = min(lanes, rem)
+                plan[0] = [rem // k + (1 if i < rem % k else 0) for i in range(k)]
+            return plan[0].pop(0) if plan[0] else None
+
         def forwards_to_come(per_forward):
             """Forwards that will follow the one being enqueued (which merged `per_forward` batches), as far as this call can know
             WITHOUT asking the source for anything (a live source must not be waited for here): from the batch count of a sized
@@ -395,17 +416,18 @@ class DanSpeechRecognizer(object):
             first = next_batch()
             if first is end:
                 return None
-            parts, total, on_device = [first], len(first), isinstance(first, DeviceClips)
-            while total and total < merge_clips:
+            parts, nclips, on_device = [first], len(first), isinstance(first, DeviceClips)
+            most = tail_plan(len(first))
+            while nclips and nclips < merge_clips and (most is None or len(parts) < most):
                 nxt = next_batch()
                 if nxt is end:
                     break
-                if isinstance(nxt, DeviceClips) != on_device or total + len(nxt) > merge_clips or \
+                if isinstance(nxt, DeviceClips) != on_device or nclips + len(nxt) > merge_clips or \
                         (on_device and nxt.pcm.dtype != first.pcm.dtype):          # (one sample type per device-resident forward)
                     held[0], held[1] = nxt, True
                     break
                 parts.append(nxt)
-                total += len(nxt)
+                nclips += len(nxt)
             live = [b for b in parts if len(b)]
             if not live:
                 return parts, [], None

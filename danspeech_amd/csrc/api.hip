@@ -44,6 +44,8 @@ EvPair timer_arm(dsmi_model* m, int kind, bool sample, double flops, double byte
     // (DSMI_DEBUG_SAMPLE_EVERY: experiments)
     static const int every = [] { const char* e = exp_env("DSMI_DEBUG_SAMPLE_EVERY"); const int v = e ? std::atoi(e) : 5; return v < 1 ? 1 : v; }();
     if (kind != KK_PERSIST && kind != KK_STEP && (t.launches[kind] - 1) % every != 0) return ev;
+    static const int ring_every = [] { const char* e = exp_env("DSMI_DEBUG_SAMPLE_RING_EVERY"); const int v = e ? std::atoi(e) : 1; return v < 1 ? 1 : v; }();
+    if (kind == KK_PERSIST && (t.launches[kind] - 1) % ring_every != 0) return ev;
     hipEvent_t e[2];
     for (int i = 0; i < 2; ++i) {
         if (!t.free_events.empty()) { e[i] = t.free_events.back(); t.free_events.pop_back(); }
@@ -104,24 +106,50 @@ struct PersistGate { std::mutex mu; hipEvent_t ev[kMaxLanes] = {nullptr, nullptr
 
 // acquire: one wave spins until it has swapped the word from 0 to 1.  (Bounded: after a second or two it goes on regardless -- two persistent
 // kernels that then share the device time out at their hand-offs and their batches are recomputed on the per-step path.)
-__global__ void turn_acquire_kernel(unsigned* turn) {
+// Two forwards that alternate at the lock fall into STEP: both finish their last layer within one launch of each other, both then run
+// their conv layers and first GEMM at the same time -- with no recurrent launch to run beside -- and start their layers together
+// again (config 4: 38.9 ms per batch in step, 33.7 out of it; which of the two a call got was an accident of its start).  So a forward's
+// progress is kept beside the lock (turn[1 + gate lane]: layers done, kIdle when it is not between its first and last layer), and a
+// forward's FIRST acquire also waits until no other forward is in the first half of its layers: the second forward of a call starts
+// its layers when the first is half way, and that offset keeps itself (whoever finishes runs its front end beside the other's second
+// half).  Only with batches in flight; every wait is bounded like the lock's.
+constexpr unsigned kIdle = 0xffffu;
+__global__ void turn_acquire_kernel(unsigned* turn, int me, int first, unsigned half) {
     if (threadIdx.x != 0) return;
-    unsigned spins = 0;
-    while (atomicCAS(turn, 0u, 1u) != 0u && ++spins < (1u << 20)) __builtin_amdgcn_s_sleep(32);
+    for (unsigned spins = 0; spins < (1u << 20); ++spins) {
+        if (atomicCAS(turn, 0u, 1u) == 0u) {
+            bool early = false;
+            if (first)
+                for (int y = 0; y < kMaxLanes; ++y)
+                    early = early || (y != me && __hip_atomic_load(turn + 1 + y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < half);
+            if (!early) {
+                if (first) __hip_atomic_store(turn + 1 + me, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+            __hip_atomic_store(turn, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);      // somebody is in its first half: not yet
+        }
+        __builtin_amdgcn_s_sleep(32);
+    }
+    if (first) __hip_atomic_store(turn + 1 + me, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (gave up waiting: goes on regardless)
 }
-__global__ void turn_release_kernel(unsigned* turn) {
-    if (threadIdx.x == 0) __hip_atomic_store(turn, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+// progress < 0: leave the forward's progress as it is (a launch that is not part of a pipelined forward)
+__global__ void turn_release_kernel(unsigned* turn, int me, int progress) {
+    if (threadIdx.x != 0) return;
+    if (progress >= 0) __hip_atomic_store(turn + 1 + me, (unsigned)progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(turn, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
+
 // slots a launch of `width` (1, 2 or kMaxLanes) takes for a handle whose home slot is `lane`: [first, first + width)
 static int gate_first(int lane, int width) { return width >= kMaxLanes ? 0 : (width == 2 ? 2 * (lane & 1) : (lane % kMaxLanes)); }
 // Under g->mu: make stream `s` wait for the slots this launch needs ...
-static void gate_wait(PersistGate* g, hipStream_t s, int lane, int width) {
+// (layer / layers: where this launch lies in a pipelined forward's recurrent layers -- layers 0: not part of one)
+static void gate_wait(PersistGate* g, hipStream_t s, int lane, int width, int layer = 0, int layers = 0) {
     for (int i = gate_first(lane, width); i < gate_first(lane, width) + width && i < kMaxLanes; ++i)
         if (g->ev[i]) (void)hipStreamWaitEvent(s, g->ev[i], 0);
     for (int i = 0; i < kRingSlots; ++i)
         if (g->ring_ev[i]) (void)hipStreamWaitEvent(s, g->ring_ev[i], 0);
     if (width >= kMaxLanes && g->turn) {      // whole device: behind the slot-sized launches by events, among themselves by the lock
-        hipLaunchKernelGGL(turn_acquire_kernel, dim3(1), dim3(64), 0, s, g->turn);
+        hipLaunchKernelGGL(turn_acquire_kernel, dim3(1), dim3(64), 0, s, g->turn, lane % kMaxLanes, (int)(layers > 0 && layer == 0), (unsigned)((layers + 1) / 2));
         return;
     }
     if (g->full_ev) (void)hipStreamWaitEvent(s, g->full_ev, 0);
@@ -154,9 +182,10 @@ static void ring_gate_record(PersistGate* g, hipStream_t s, int first, int n, in
     }
 }
 // ... and publish the launch on them.
-static void gate_record(PersistGate* g, hipStream_t s, int lane, int width) {
+static void gate_record(PersistGate* g, hipStream_t s, int lane, int width, int layer = 0, int layers = 0) {
     if (width >= kMaxLanes && g->turn) {
-        hipLaunchKernelGGL(turn_release_kernel, dim3(1), dim3(64), 0, s, g->turn);
+        const int progress = layers > 0 ? (layer + 1 < layers ? layer + 1 : (int)kIdle) : -1;
+        hipLaunchKernelGGL(turn_release_kernel, dim3(1), dim3(64), 0, s, g->turn, lane % kMaxLanes, progress);
         if (g->full_ev) (void)hipEventRecord(g->full_ev, s);
         return;
     }
@@ -180,7 +209,8 @@ static PersistGate* persist_gate(int device) {
     if (!(turns && std::string(turns) == "events") && g->full_ev) {
         int cur = -1;
         (void)hipGetDevice(&cur);
-        if (hipSetDevice(device) != hipSuccess || hipMalloc((void**)&g->turn, sizeof(unsigned)) != hipSuccess ||
+        if (hipSetDevice(device) != hipSuccess || hipMalloc((void**)&g->turn, (1 + kMaxLanes) * sizeof(unsigned)) != hipSuccess ||
+            hipMemset(g->turn, 0xff, (1 + kMaxLanes) * sizeof(unsigned)) != hipSuccess ||      // progress words: not in a forward
             hipMemset(g->turn, 0, sizeof(unsigned)) != hipSuccess) g->turn = nullptr;
         if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
     }
@@ -737,9 +767,12 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
             std::lock_guard<std::mutex> lk(gate->mu);       // wait -> launch -> record is atomic against other host threads
             // a half-CU / half-chip kernel takes one lane (a pair of gate slots), anything else the device
             const int width = ((waves == 4 && !duo) || duo_lane) ? 2 : kMaxLanes;
-            gate_wait(gate, s, m->lane, width);
+            // (a pipelined forward's layers: the first launch of layer 0 waits for its place among the forwards, the last launch of a
+            // layer says how far the forward is -- turn_acquire_kernel)
+            const bool lastw = !duo || p0 + window >= total_pairs;
+            gate_wait(gate, s, m->lane, width, p0 == 0 ? l : 1, m->chain_layers);
             ok = duo ? launch_rnn_persist_duo(pl, s) : launch_rnn_persist16(pl, s);
-            gate_record(gate, s, m->lane, width);
+            gate_record(gate, s, m->lane, width, l, lastw ? m->chain_layers : 0);
         }
         if (ok) return;
         // (not reachable for eligible shapes; the x-projection is in the other column order, so redo it)
@@ -936,7 +969,9 @@ static int forward_enqueue(dsmi_model* m, const float* feat, int B, int T, float
             gl.a = m->hbuf[(l - 1) & 1][0]; gl.a2 = m->geom.D == 2 ? m->hbuf[(l - 1) & 1][1] : nullptr;
             gl.alpha = m->rnn[l].bn_a; gl.beta = m->rnn[l].bn_b; gl.lda = m->Hs;
         }
+        m->chain_layers = m->inflight >= 2 ? d.rnn_layers : 0;      // (batches in flight: whole-device launches keep step apart, gate_wait)
         run_rnn_layer(m, l, gl, B, To, l & 1, s);
+        m->chain_layers = 0;
     }
     if (m->profiling) HIP_OK(m, hipEventRecord(m->ev[2], s));
     const int last = (d.rnn_layers - 1) & 1;

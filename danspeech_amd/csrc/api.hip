@@ -106,50 +106,52 @@ struct PersistGate { std::mutex mu; hipEvent_t ev[kMaxLanes] = {nullptr, nullptr
 
 // acquire: one wave spins until it has swapped the word from 0 to 1.  (Bounded: after a second or two it goes on regardless -- two persistent
 // kernels that then share the device time out at their hand-offs and their batches are recomputed on the per-step path.)
-// Two forwards that alternate at the lock fall into STEP: both finish their last layer within one launch of each other, both then run
-// their conv layers and first GEMM at the same time -- with no recurrent launch to run beside -- and start their layers together
-// again (config 4: 38.9 ms per batch in step, 33.7 out of it; which of the two a call got was an accident of its start).  So a forward's
-// progress is kept beside the lock (turn[1 + gate lane]: layers done, kIdle when it is not between its first and last layer), and a
-// forward's FIRST acquire also waits until no other forward is in the first half of its layers: the second forward of a call starts
-// its layers when the first is half way, and that offset keeps itself (whoever finishes runs its front end beside the other's second
-// half).  Only with batches in flight; every wait is bounded like the lock's.
-constexpr unsigned kIdle = 0xffffu;
-__global__ void turn_acquire_kernel(unsigned* turn, int me, int first, unsigned half) {
+// (Measured and not kept, profiles/r06_config4.txt: two forwards that alternate at the lock can fall into step -- both in their conv
+// layers at the same time, with no recurrent launch to run beside.  Holding a forward's first acquire back until the other is half
+// way through its layers keeps them apart, and the stream of batches takes the same time: 35.3 against 35.8 ms per batch over four
+// runs each, inside their spread.)
+__global__ void turn_acquire_kernel(unsigned* turn) {
     if (threadIdx.x != 0) return;
-    for (unsigned spins = 0; spins < (1u << 20); ++spins) {
-        if (atomicCAS(turn, 0u, 1u) == 0u) {
-            bool early = false;
-            if (first)
-                for (int y = 0; y < kMaxLanes; ++y)
-                    early = early || (y != me && __hip_atomic_load(turn + 1 + y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < half);
-            if (!early) {
-                if (first) __hip_atomic_store(turn + 1 + me, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return;
-            }
-            __hip_atomic_store(turn, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);      // somebody is in its first half: not yet
-        }
-        __builtin_amdgcn_s_sleep(32);
+    unsigned spins = 0;
+    while (atomicCAS(turn, 0u, 1u) != 0u && ++spins < (1u << 20)) __builtin_amdgcn_s_sleep(32);
+}
+__global__ void turn_release_kernel(unsigned* turn) {
+    if (threadIdx.x == 0) __hip_atomic_store(turn, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+#ifdef DSMI_EXPERIMENTS
+// Experiment (DSMI_DEBUG_DENSE_TOKENS=K): at most K forwards run a dense kernel (conv2, the x-projection GEMMs) at a time -- four
+// lanes whose GEMMs share the chip fairly finish them together and start their ring windows together (the lanes fall into step);
+// with tokens the GEMMs run one or two at a time on everything the ring windows leave, and the windows start staggered.
+__global__ void dense_enter_kernel(unsigned* sem, unsigned limit) {
+    if (threadIdx.x != 0) return;
+    for (unsigned spins = 0; spins < (1u << 18); ++spins) {
+        const unsigned c = __hip_atomic_load(sem, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (c < limit && atomicCAS(sem, c, c + 1u) == c) return;
+        __builtin_amdgcn_s_sleep(8);
     }
-    if (first) __hip_atomic_store(turn + 1 + me, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (gave up waiting: goes on regardless)
+    atomicAdd(sem, 1u);
 }
-// progress < 0: leave the forward's progress as it is (a launch that is not part of a pipelined forward)
-__global__ void turn_release_kernel(unsigned* turn, int me, int progress) {
-    if (threadIdx.x != 0) return;
-    if (progress >= 0) __hip_atomic_store(turn + 1 + me, (unsigned)progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(turn, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+__global__ void dense_leave_kernel(unsigned* sem) {
+    if (threadIdx.x == 0) atomicSub(sem, 1u);
 }
+static int dense_tokens() {
+    static const int k = [] { const char* e = exp_env("DSMI_DEBUG_DENSE_TOKENS"); return e ? std::atoi(e) : 0; }();
+    return k;
+}
+static unsigned* dense_sem(int device);
+#endif
 
 // slots a launch of `width` (1, 2 or kMaxLanes) takes for a handle whose home slot is `lane`: [first, first + width)
 static int gate_first(int lane, int width) { return width >= kMaxLanes ? 0 : (width == 2 ? 2 * (lane & 1) : (lane % kMaxLanes)); }
 // Under g->mu: make stream `s` wait for the slots this launch needs ...
-// (layer / layers: where this launch lies in a pipelined forward's recurrent layers -- layers 0: not part of one)
-static void gate_wait(PersistGate* g, hipStream_t s, int lane, int width, int layer = 0, int layers = 0) {
+static void gate_wait(PersistGate* g, hipStream_t s, int lane, int width) {
     for (int i = gate_first(lane, width); i < gate_first(lane, width) + width && i < kMaxLanes; ++i)
         if (g->ev[i]) (void)hipStreamWaitEvent(s, g->ev[i], 0);
     for (int i = 0; i < kRingSlots; ++i)
         if (g->ring_ev[i]) (void)hipStreamWaitEvent(s, g->ring_ev[i], 0);
     if (width >= kMaxLanes && g->turn) {      // whole device: behind the slot-sized launches by events, among themselves by the lock
-        hipLaunchKernelGGL(turn_acquire_kernel, dim3(1), dim3(64), 0, s, g->turn, lane % kMaxLanes, (int)(layers > 0 && layer == 0), (unsigned)((layers + 1) / 2));
+        hipLaunchKernelGGL(turn_acquire_kernel, dim3(1), dim3(64), 0, s, g->turn);
         return;
     }
     if (g->full_ev) (void)hipStreamWaitEvent(s, g->full_ev, 0);
@@ -182,10 +184,9 @@ static void ring_gate_record(PersistGate* g, hipStream_t s, int first, int n, in
     }
 }
 // ... and publish the launch on them.
-static void gate_record(PersistGate* g, hipStream_t s, int lane, int width, int layer = 0, int layers = 0) {
+static void gate_record(PersistGate* g, hipStream_t s, int lane, int width) {
     if (width >= kMaxLanes && g->turn) {
-        const int progress = layers > 0 ? (layer + 1 < layers ? layer + 1 : (int)kIdle) : -1;
-        hipLaunchKernelGGL(turn_release_kernel, dim3(1), dim3(64), 0, s, g->turn, lane % kMaxLanes, progress);
+        hipLaunchKernelGGL(turn_release_kernel, dim3(1), dim3(64), 0, s, g->turn);
         if (g->full_ev) (void)hipEventRecord(g->full_ev, s);
         return;
     }
@@ -209,14 +210,20 @@ static PersistGate* persist_gate(int device) {
     if (!(turns && std::string(turns) == "events") && g->full_ev) {
         int cur = -1;
         (void)hipGetDevice(&cur);
-        if (hipSetDevice(device) != hipSuccess || hipMalloc((void**)&g->turn, (1 + kMaxLanes) * sizeof(unsigned)) != hipSuccess ||
-            hipMemset(g->turn, 0xff, (1 + kMaxLanes) * sizeof(unsigned)) != hipSuccess ||      // progress words: not in a forward
-            hipMemset(g->turn, 0, sizeof(unsigned)) != hipSuccess) g->turn = nullptr;
+        if (hipSetDevice(device) != hipSuccess || hipMalloc((void**)&g->turn, 2 * sizeof(unsigned)) != hipSuccess ||          // [1]: experiments, the dense kernels' tokens
+            hipMemset(g->turn, 0, 2 * sizeof(unsigned)) != hipSuccess) g->turn = nullptr;
         if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
     }
     gates[device] = g;
     return g;
 }
+
+#ifdef DSMI_EXPERIMENTS
+static unsigned* dense_sem(int device) {
+    PersistGate* g = persist_gate(device);
+    return g->turn ? g->turn + 1 : nullptr;
+}
+#endif
 
 // true when this process may run persistent kernels on `device`
 static bool persist_process_lock(int device) {
@@ -685,12 +692,15 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
     // the chip belong to the other batches; a lone batch of more than 32 clips spreads its tiles over as many windows side by
     // side as the device holds.  (A lone batch of up to 32 clips keeps the whole-device kernel: the shortest step.)
     int ring_ntw = 0, ring_nwin = 0, ring_slots = 0;
+    bool ring_only8 = m->ring8;      // the eight-wave form on every window: asked for, or a shape the four-wave form does not take
     if (use16 && m->rnn_kernel != 1 && (m->inflight >= 2 || B > 32 || m->rnn_kernel == 2)) {
         const int rcus = rnn_persist_ring_cus(m->geom16);
         ring_slots = rcus > 0 ? std::min(kRingSlots, m->n_cus / rcus) : 0;        // windows the device holds side by side
         static const int slot_cap = [] { const char* e = exp_env("DSMI_DEBUG_RING_SLOTS"); return e ? std::atoi(e) : 0; }();      // (experiments)
         if (slot_cap >= 2 && ring_slots > slot_cap) ring_slots = slot_cap;
-        const int cap = ring_slots >= 2 ? (m->ring8 ? rnn_persist_ring_tiles(m->geom16, B, rcus) : rnn_persist_ring4_tiles(m->geom16, B, rcus)) : 0;
+        const int cap4 = m->ring8 ? 0 : rnn_persist_ring4_tiles(m->geom16, B, rcus);
+        ring_only8 = ring_only8 || cap4 == 0;
+        const int cap = ring_slots >= 2 ? (ring_only8 ? rnn_persist_ring_tiles(m->geom16, B, rcus) : cap4) : 0;
         if (cap > 0) {
             const int ntiles = ceil_div(B, 16);
             // windows side by side: one with batches in flight, up to four for a lone batch -- or what the caller said
@@ -712,7 +722,14 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
     }
     gl.ev = timer_arm(m, gl.mode == GEMM_A_CONV ? KK_GEMM0 : KK_GEMM, true, 2.0 * Dd * GH * gl.K * sumlen,
                       4.0 * ((double)gl.M * gl.K * (gl.a2 ? 2 : 1) + (double)gl.N * gl.K + (double)gl.M * gl.N));
+#ifdef DSMI_EXPERIMENTS
+    unsigned* sem = (dense_tokens() > 0 && m->inflight >= 2) ? dense_sem(m->device) : nullptr;
+    if (sem) hipLaunchKernelGGL(dense_enter_kernel, dim3(1), dim3(64), 0, s, sem, (unsigned)dense_tokens());
+#endif
     launch_gemm(gl, s);
+#ifdef DSMI_EXPERIMENTS
+    if (sem) hipLaunchKernelGGL(dense_leave_kernel, dim3(1), dim3(64), 0, s, sem);
+#endif
     if (use16) {
         RnnPersist16Launch pl;
         pl.g = m->geom16;
@@ -752,7 +769,7 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
             // phantom tiles like real ones (its phase has no branch), the eight-wave form skips them: a window of one or two tiles
             // -- a lone 32-clip batch at the end of a stream -- is 4.3 / 5.4 us per step there against 5.8 / 6.0 (round 5,
             // tools/exp/ring_layer_time.py).  DSMI_RNN_KERNEL=ring8 / ring4: one form everywhere (A/B runs, the forms' own tests).
-            const bool eight = m->ring8 || (!m->ring4 && std::min(ring_ntw, ntiles - t0) <= 2 && rnn_persist_ring_tiles(m->geom16, B, rcus) > 0);
+            const bool eight = ring_only8 || (!m->ring4 && std::min(ring_ntw, ntiles - t0) <= 2 && rnn_persist_ring_tiles(m->geom16, B, rcus) > 0);
             if (eight) pl.ntw = std::min(ring_ntw, rnn_persist_ring_tiles(m->geom16, B, rcus));      // (its own cap: at most two real tiles are left)
             ok = eight ? launch_rnn_persist_ring(pl, s) : launch_rnn_persist_ring4(pl, s);
             ring_gate_record(gate, s, first, nw, rcus);
@@ -767,12 +784,9 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
             std::lock_guard<std::mutex> lk(gate->mu);       // wait -> launch -> record is atomic against other host threads
             // a half-CU / half-chip kernel takes one lane (a pair of gate slots), anything else the device
             const int width = ((waves == 4 && !duo) || duo_lane) ? 2 : kMaxLanes;
-            // (a pipelined forward's layers: the first launch of layer 0 waits for its place among the forwards, the last launch of a
-            // layer says how far the forward is -- turn_acquire_kernel)
-            const bool lastw = !duo || p0 + window >= total_pairs;
-            gate_wait(gate, s, m->lane, width, p0 == 0 ? l : 1, m->chain_layers);
+            gate_wait(gate, s, m->lane, width);
             ok = duo ? launch_rnn_persist_duo(pl, s) : launch_rnn_persist16(pl, s);
-            gate_record(gate, s, m->lane, width, l, lastw ? m->chain_layers : 0);
+            gate_record(gate, s, m->lane, width);
         }
         if (ok) return;
         // (not reachable for eligible shapes; the x-projection is in the other column order, so redo it)
@@ -957,7 +971,14 @@ static int forward_enqueue(dsmi_model* m, const float* feat, int B, int T, float
 
     if (m->profiling) HIP_OK(m, hipEventRecord(m->ev[0], s));
     const float* cx;
+#ifdef DSMI_EXPERIMENTS
+    unsigned* csem = (dense_tokens() > 0 && m->inflight >= 2) ? dense_sem(m->device) : nullptr;
+    if (csem) hipLaunchKernelGGL(dense_enter_kernel, dim3(1), dim3(64), 0, s, csem, (unsigned)dense_tokens());
+#endif
     run_conv(m, feat, B, T, To, ys, s, &cx);
+#ifdef DSMI_EXPERIMENTS
+    if (csem) hipLaunchKernelGGL(dense_leave_kernel, dim3(1), dim3(64), 0, s, csem);
+#endif
     if (m->profiling) HIP_OK(m, hipEventRecord(m->ev[1], s));
 
     for (int l = 0; l < d.rnn_layers; ++l) {
@@ -969,9 +990,7 @@ static int forward_enqueue(dsmi_model* m, const float* feat, int B, int T, float
             gl.a = m->hbuf[(l - 1) & 1][0]; gl.a2 = m->geom.D == 2 ? m->hbuf[(l - 1) & 1][1] : nullptr;
             gl.alpha = m->rnn[l].bn_a; gl.beta = m->rnn[l].bn_b; gl.lda = m->Hs;
         }
-        m->chain_layers = m->inflight >= 2 ? d.rnn_layers : 0;      // (batches in flight: whole-device launches keep step apart, gate_wait)
         run_rnn_layer(m, l, gl, B, To, l & 1, s);
-        m->chain_layers = 0;
     }
     if (m->profiling) HIP_OK(m, hipEventRecord(m->ev[2], s));
     const int last = (d.rnn_layers - 1) & 1;

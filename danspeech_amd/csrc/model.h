@@ -50,7 +50,6 @@ struct dsmi_model {
     dsmi::RnnGeom geom{};
     dsmi::RnnGeom geom16{};       // U = 16 geometry of the second-generation persistent kernel
     bool have16 = false;          // geom16 weights were packed (H % 16 == 0)
-    int chain_layers = 0;         // api.hip: > 0 while forward_enqueue issues a pipelined forward's recurrent layers (their count)
     int ring_windows = 0;         // dsmi_model_set_ring_windows: ring windows per recurrent layer side by side (0: by inflight)
     int inflight = 1;             // dsmi_model_set_inflight: batches the caller keeps in flight on this device (2: throughput variant)
 

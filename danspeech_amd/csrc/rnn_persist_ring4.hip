@@ -626,6 +626,14 @@ int rnn_persist_ring4_tiles(const RnnGeom& g16, int B, int n_cus) {
     const int nkb = ceil_div(g16.H, 32);
     const int nkw = ceil_div(nkb, 2);
     if (nkw > (g16.kind == DSMI_RNN_LSTM ? 8 : 14)) return 0;
+    // Fewer than four k-blocks per wave (H < 224): NOT this kernel.  Round 6 found that in a pipeline -- several windows of
+    // different handles running at once -- a GRU of 64..192 units comes out with the LAST tile of a window wrong now and then
+    // (tools/exp/debug_short_forms.py: garbage transcripts for the clips of tile 3, nondeterministic, from the third call of a
+    // process on; never alone on the chip, never with the eight-wave form, never from 256 units up in any test or bench run).  The
+    // cause has not been found; the shapes are fenced off (tests/test_gpu_recognizer.py::test_small_models_in_the_pipeline).  The
+    // eight-wave form takes them.  DSMI_RNN_KERNEL=ring4 (tests of the form alone on the chip) still reaches them.
+    static const bool forced = [] { const char* e = std::getenv("DSMI_RNN_KERNEL"); return e && std::string(e) == "ring4"; }();
+    if (nkw < 4 && !forced) return 0;
     if (ring4_lds_bytes(g16.kind, nkb) > 160 * 1024) return 0;
     if (((g16.nwg + 1) / 2) * g16.D > n_cus) return 0;
     if ((size_t)g16.D * ceil_div(B, XB) * nkb * 2048 * 2 >= (1ull << 31)) return 0;      // packed state below 2 GiB (store offsets, see OOR)

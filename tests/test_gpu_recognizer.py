@@ -209,6 +209,27 @@ def test_short_calls_take_other_kernel_forms_and_say_the_same():
     m.close(); fe.close()
 
 
+@pytest.mark.parametrize("hidden", [64, 128, 192, 256])
+def test_small_models_in_the_pipeline(hidden):
+    """Round 6 found the four-wave ring kernel wrong for GRUs of fewer than four k-blocks per wave (H < 224) IN A PIPELINE: with
+    several windows of different handles running at once the last tile of a 64-clip window came out wrong now and then (garbage
+    transcripts for its clips, from the third call of a process on; cause not found).  Those shapes now run the eight-wave form
+    (``rnn_persist_ring4_tiles``); this is the scenario that showed it, repeated: every call's every batch equals the single call."""
+    from danspeech_amd import Recognizer
+    model, sd, cfg = _model("small", hidden, 3, seed=12)
+    rec = Recognizer(model=model)
+    eng = rec.danspeech_recognizer
+    eng.pipeline_balance_tail = False                      # (64-clip forwards to the end of a call)
+    clips = [syn.make_clip(i, 9000 + 400 * (i % 5)) for i in range(32)]
+    want = rec.recognize_batch(clips)
+    for n in (6, 8, 6, 8, 6, 8, 6, 8):
+        got = list(rec.recognize_batches([clips] * n))
+        bad = [(k, i) for k in range(n) for i in range(32) if got[k][i] != want[i]]
+        assert not bad, (hidden, n, bad[:8])
+    handles = [eng.model._native] + [r[0]._native for r in eng._replicas]
+    assert [h.recompute_count() for h in handles] == [0] * len(handles)
+
+
 def test_a_ring_model_and_a_whole_device_model_in_flight_together():
     """Two engines used at once from two threads: one model the ring kernels take (slot-sized windows, ordered by events) and one
     whose recurrent kernel takes the whole device (turns through the device lock, api.hip) -- the two families are ordered

@@ -119,10 +119,16 @@ __global__ void turn_release_kernel(unsigned* turn) {
     if (threadIdx.x == 0) __hip_atomic_store(turn, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-#ifdef DSMI_EXPERIMENTS
-// Experiment (DSMI_DEBUG_DENSE_TOKENS=K): at most K forwards run a dense kernel (conv2, the x-projection GEMMs) at a time -- four
-// lanes whose GEMMs share the chip fairly finish them together and start their ring windows together (the lanes fall into step);
-// with tokens the GEMMs run one or two at a time on everything the ring windows leave, and the windows start staggered.
+// ONE forward at a time runs a dense kernel (the conv stack, an x-projection GEMM) when forwards are in flight (round 6).  Four
+// lanes whose GEMMs share the chip fairly all get a quarter of what the ring windows leave, finish together and start their ring
+// windows together: the lanes fall into step, and in step the chip alternates between four GEMMs crawling and four windows holding
+// 200 CUs at half their MFMA rate with 56 idle.  With a token (a counter in device memory beside the turn lock: a one-wave kernel
+// spins until it has taken it, a second gives it back behind the GEMM) a GEMM has everything the windows leave, is done in a
+// quarter of the time, and the next lane's follows: the windows start one after the other and stay out of step.  cfgA, 64-clip
+// forwards on four lanes: 5.30 -> 5.01 ms per 32-clip batch in steady state, 5.73 -> 5.45 over a 20-batch call; two forwards at
+// a time 5.22, three 5.27 (profiles/r06_dense_token.txt).  On only where the caller has given the runtime a hardware queue per
+// stream (GPU_MAX_HW_QUEUES >= 8 in the environment): on a shared queue a lane's give-back could stand behind
+// another lane's spinning take until that gives up.  DSMI_DENSE_TOKENS=0 turns it off (A/B runs).
 __global__ void dense_enter_kernel(unsigned* sem, unsigned limit) {
     if (threadIdx.x != 0) return;
     for (unsigned spins = 0; spins < (1u << 18); ++spins) {
@@ -130,17 +136,21 @@ __global__ void dense_enter_kernel(unsigned* sem, unsigned limit) {
         if (c < limit && atomicCAS(sem, c, c + 1u) == c) return;
         __builtin_amdgcn_s_sleep(8);
     }
-    atomicAdd(sem, 1u);
+    atomicAdd(sem, 1u);      // (gave up waiting: goes on; counted, so that its give-back does not free somebody else's place)
 }
 __global__ void dense_leave_kernel(unsigned* sem) {
     if (threadIdx.x == 0) atomicSub(sem, 1u);
 }
 static int dense_tokens() {
-    static const int k = [] { const char* e = exp_env("DSMI_DEBUG_DENSE_TOKENS"); return e ? std::atoi(e) : 0; }();
+    static const int k = [] {
+        const char* e = std::getenv("DSMI_DENSE_TOKENS");
+        if (e) return std::atoi(e);
+        const char* q = std::getenv("GPU_MAX_HW_QUEUES");
+        return q && std::atoi(q) >= 8 ? 1 : 0;
+    }();
     return k;
 }
 static unsigned* dense_sem(int device);
-#endif
 
 // slots a launch of `width` (1, 2 or kMaxLanes) takes for a handle whose home slot is `lane`: [first, first + width)
 static int gate_first(int lane, int width) { return width >= kMaxLanes ? 0 : (width == 2 ? 2 * (lane & 1) : (lane % kMaxLanes)); }
@@ -210,7 +220,7 @@ static PersistGate* persist_gate(int device) {
     if (!(turns && std::string(turns) == "events") && g->full_ev) {
         int cur = -1;
         (void)hipGetDevice(&cur);
-        if (hipSetDevice(device) != hipSuccess || hipMalloc((void**)&g->turn, 2 * sizeof(unsigned)) != hipSuccess ||          // [1]: experiments, the dense kernels' tokens
+        if (hipSetDevice(device) != hipSuccess || hipMalloc((void**)&g->turn, 2 * sizeof(unsigned)) != hipSuccess ||          // [1]: the dense kernels' token
             hipMemset(g->turn, 0, 2 * sizeof(unsigned)) != hipSuccess) g->turn = nullptr;
         if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
     }
@@ -218,12 +228,10 @@ static PersistGate* persist_gate(int device) {
     return g;
 }
 
-#ifdef DSMI_EXPERIMENTS
 static unsigned* dense_sem(int device) {
     PersistGate* g = persist_gate(device);
     return g->turn ? g->turn + 1 : nullptr;
 }
-#endif
 
 // true when this process may run persistent kernels on `device`
 static bool persist_process_lock(int device) {
@@ -722,14 +730,10 @@ static void run_rnn_layer(dsmi_model* m, int l, GemmLaunch gl, int B, int To, in
     }
     gl.ev = timer_arm(m, gl.mode == GEMM_A_CONV ? KK_GEMM0 : KK_GEMM, true, 2.0 * Dd * GH * gl.K * sumlen,
                       4.0 * ((double)gl.M * gl.K * (gl.a2 ? 2 : 1) + (double)gl.N * gl.K + (double)gl.M * gl.N));
-#ifdef DSMI_EXPERIMENTS
-    unsigned* sem = (dense_tokens() > 0 && m->inflight >= 2) ? dense_sem(m->device) : nullptr;
+    unsigned* sem = (dense_tokens() > 0 && m->inflight >= 2) ? dense_sem(m->device) : nullptr;      // one forward's dense kernel at a time
     if (sem) hipLaunchKernelGGL(dense_enter_kernel, dim3(1), dim3(64), 0, s, sem, (unsigned)dense_tokens());
-#endif
     launch_gemm(gl, s);
-#ifdef DSMI_EXPERIMENTS
     if (sem) hipLaunchKernelGGL(dense_leave_kernel, dim3(1), dim3(64), 0, s, sem);
-#endif
     if (use16) {
         RnnPersist16Launch pl;
         pl.g = m->geom16;
@@ -971,14 +975,10 @@ static int forward_enqueue(dsmi_model* m, const float* feat, int B, int T, float
 
     if (m->profiling) HIP_OK(m, hipEventRecord(m->ev[0], s));
     const float* cx;
-#ifdef DSMI_EXPERIMENTS
-    unsigned* csem = (dense_tokens() > 0 && m->inflight >= 2) ? dense_sem(m->device) : nullptr;
+    unsigned* csem = (dense_tokens() > 0 && m->inflight >= 2) ? dense_sem(m->device) : nullptr;     // (see dense_enter_kernel)
     if (csem) hipLaunchKernelGGL(dense_enter_kernel, dim3(1), dim3(64), 0, s, csem, (unsigned)dense_tokens());
-#endif
     run_conv(m, feat, B, T, To, ys, s, &cx);
-#ifdef DSMI_EXPERIMENTS
     if (csem) hipLaunchKernelGGL(dense_leave_kernel, dim3(1), dim3(64), 0, s, csem);
-#endif
     if (m->profiling) HIP_OK(m, hipEventRecord(m->ev[1], s));
 
     for (int l = 0; l < d.rnn_layers; ++l) {

@@ -13,6 +13,9 @@ B, N = 32, 160000
 sd = syn.make_state_dict(2, "gru", 800, 5, seed=0, **syn.TALKATIVE)
 model = DeepSpeech("cfgA", rnn_hidden_size=800, rnn_layers=5).load_state_dict(sd)
 rec = Recognizer(model=model)
+if os.environ.get("DBG_LANES"):
+    rec.danspeech_recognizer.pipeline_lanes = int(os.environ["DBG_LANES"])
+    rec.danspeech_recognizer._lanes_that_pay = lambda most, clips: most
 if os.environ.get("DSMI_TEST_NO_TAIL"):
     rec.danspeech_recognizer.pipeline_balance_tail = False
 host = [syn.make_clip(i, N) for i in range(B)]

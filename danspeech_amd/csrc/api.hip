@@ -151,6 +151,11 @@ static int dense_tokens() {
     return k;
 }
 static unsigned* dense_sem(int device);
+// (experiments: what runs behind the token -- 0 the conv stack as one and every GEMM, 1 the GEMMs only, 2 every conv layer by itself and every GEMM)
+static int dense_scope() {
+    static const int k = [] { const char* e = exp_env("DSMI_DEBUG_DENSE_SCOPE"); return e ? std::atoi(e) : 0; }();
+    return k;
+}
 
 // slots a launch of `width` (1, 2 or kMaxLanes) takes for a handle whose home slot is `lane`: [first, first + width)
 static int gate_first(int lane, int width) { return width >= kMaxLanes ? 0 : (width == 2 ? 2 * (lane & 1) : (lane % kMaxLanes)); }
@@ -641,6 +646,8 @@ static int run_conv(dsmi_model* m, const float* feat, int B, int T, int To, int 
         for (int i = 0; i < B; ++i) fl += 2.0 * sp.co * m->conv_fo[l] * (double)m->host_out_lens[i] * sp.ci * sp.kf * sp.kt;
         const double by = 4.0 * B * ((double)sp.ci * m->conv_fi[l] * ti + (double)sp.co * m->conv_fo[l] * To);
         const bool next_split = m->conv_mode == 1 && l + 1 < L;       // the consumer is a split-fp16 conv layer
+        unsigned* lsem = (dense_tokens() > 0 && m->inflight >= 2 && dense_scope() == 2) ? dense_sem(m->device) : nullptr;
+        if (lsem) hipLaunchKernelGGL(dense_enter_kernel, dim3(1), dim3(64), 0, s, lsem, (unsigned)dense_tokens());
         if (x_sp) {
             ConvSplitLaunch c;
             c.x_sp = x_sp; c.wp_sp = m->conv[l].wp_sp; c.bias = m->conv[l].bias; c.bn_a = m->conv[l].bn_a; c.bn_b = m->conv[l].bn_b;
@@ -662,6 +669,7 @@ static int run_conv(dsmi_model* m, const float* feat, int B, int T, int To, int 
             else launch_conv(c, s);
             x = c.y; x_sp = c.y_sp;
         }
+        if (lsem) hipLaunchKernelGGL(dense_leave_kernel, dim3(1), dim3(64), 0, s, lsem);
         ti = To; xs = ys;
     }
     *out = x;
@@ -975,7 +983,7 @@ static int forward_enqueue(dsmi_model* m, const float* feat, int B, int T, float
 
     if (m->profiling) HIP_OK(m, hipEventRecord(m->ev[0], s));
     const float* cx;
-    unsigned* csem = (dense_tokens() > 0 && m->inflight >= 2) ? dense_sem(m->device) : nullptr;     // (see dense_enter_kernel)
+    unsigned* csem = (dense_tokens() > 0 && m->inflight >= 2 && dense_scope() == 0) ? dense_sem(m->device) : nullptr;     // (see dense_enter_kernel)
     if (csem) hipLaunchKernelGGL(dense_enter_kernel, dim3(1), dim3(64), 0, s, csem, (unsigned)dense_tokens());
     run_conv(m, feat, B, T, To, ys, s, &cx);
     if (csem) hipLaunchKernelGGL(dense_leave_kernel, dim3(1), dim3(64), 0, s, csem);

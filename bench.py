@@ -371,25 +371,31 @@ def main(argv=None):
     # needed two: a process's second call paid a blocking first upload on each replica lane -- the first copy a process hands a DMA
     # engine holds the caller until it is done; the engine now meets its engines when its lanes are set up
     # (DanSpeechRecognizer._warm_copy_engines, profiles/r06_second_call_stall.txt)
-    warmup_each = max(args.warmup, 16 if not dry else 0)
+    # (+ steps % 8: the call's last round of forwards then has the shape of the timed call's -- 20 timed steps end in four 32-clip
+    # forwards, and a forward of a size the process has not seen costs its first call tensors of new sizes: 27 ms in a 20-step call)
+    warmup_each = max(args.warmup, 16 if not dry else 0) + (args.steps % 8 if not dry else 0)
     out = None
     for _ in range(max(args.warmup_calls, 1)):
         out = run(warmup_each) or out
     warmup_done = warmup_each * max(args.warmup_calls, 1)
     if eng is not None:
         handles = [eng.model._native] + [r[0]._native for r in eng._replicas]
-    if not args.no_kernel_sampling:
-        for h in handles:
-            h.set_profiling(2)
-            h.reset_kernel_stats()
+    # Per-dispatch timestamps on ONE of the forwards' lanes: a stamped launch is a hipExtLaunchKernelGGL with two events and costs the
+    # enqueueing thread ~0.2 ms; with every lane stamped (60 recurrent + a dozen dense launches in a 20-step call) that was 0.65 ms per
+    # step of the region being timed (6.35 against 5.71, r6z).  The lanes are dealt the forwards in turn and run the same kernels: one
+    # lane's launches are a quarter of every kind's, and the launch counts below are scaled by the number of lanes.
+    sampled = handles[:1] if not args.no_kernel_sampling else []
+    for h in sampled:
+        h.set_profiling(2)
+        h.reset_kernel_stats()
     sync()
     t0 = time.perf_counter()
     out = run(args.steps) or out
     sync()
     dt = time.perf_counter() - t0
     stats = {}
-    if not args.no_kernel_sampling:
-        for h in handles:                        # merge the per-handle samples
+    if sampled:
+        for h in sampled:                        # merge the sampled handles' figures
             for k, v in h.kernel_stats().items():
                 a = stats.setdefault(k, dict(launches=0, samples=0, _us=0.0, _fl=0.0, _by=0.0))
                 a["launches"] += v["launches"]; a["samples"] += v["samples"]
@@ -400,6 +406,7 @@ def main(argv=None):
             a["avg_us"] = a["_us"] / max(a["samples"], 1)
             a["flops_per_launch"] = a["_fl"] / max(a["launches"], 1)
             a["bytes_per_launch"] = a["_by"] / max(a["launches"], 1)
+            a["launches"] *= len(handles) / float(len(sampled))
     # ---- side measurement, after the timed region: the same entry over enough steps that the pipeline's fill and drain (four forwards
     # of two batches) are a few per cent of it, with the board power sampled beside it.  Never `value`.
     steady = None
@@ -452,6 +459,8 @@ def main(argv=None):
                         traffic_source=PMC_TRAFFIC.get("_source", "profiles/pmc_traffic.json (builder's counter pass of an earlier tree, "
                                                                    "not measured in this run)"),
                         avg_launch_us=round(s["avg_us"], 3), launches_per_step=round(s["launches"] / args.steps, 3),
+                        sampled_launches=int(s["samples"]), sampling="every launch of this kernel on one of the %d lanes (the lanes are dealt the "
+                        "forwards in turn); launch counts scaled by the lanes" % max(len(handles), 1),
                         flops_per_launch=s["flops_per_launch"],
                         kernel_time_share={k: round(v / sum(tot.values()), 4) for k, v in sorted(tot.items())})
         result = {

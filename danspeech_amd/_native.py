@@ -95,6 +95,7 @@ _PROTOS = {
     "dsmi_model_set_inflight": (C.c_int, [_vp, C.c_int]),
     "dsmi_model_set_ring_windows": (C.c_int, [_vp, C.c_int]),
     "dsmi_pack_pcm_i16": (C.c_int, [_vp, C.c_int64, _vp]),
+    "dsmi_upload": (C.c_int, [C.c_int, _vp, _vp, C.c_int64, _vp]),
     "dsmi_conv_stack": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
     "dsmi_rnn_layer": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
     "dsmi_greedy": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),

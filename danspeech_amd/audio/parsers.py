@@ -149,6 +149,15 @@ class SpectrogramAudioParser(AudioParser):
         slot["high"] = high
         return slot
 
+    def _upload(self, dst, src_pinned, stream):
+        """Pinned host bytes -> device bytes on ``stream`` by ``dsmi_upload`` (a kernel that reads the pinned buffer over the bus): the
+        pipeline's uploads do not go through hipMemcpyAsync, whose first copies on a process's streams hold the calling thread for
+        6-12 ms each (profiles/r06_second_call_stall.txt)."""
+        from .. import _native
+        rc = _native.lib().dsmi_upload(int(self.device), dst.data_ptr(), src_pinned.data_ptr(), int(src_pinned.numel()), int(stream.cuda_stream))
+        if rc != 0:
+            raise _native.DsmiError(rc, "dsmi_upload failed")
+
     def stage(self, recordings):
         """list of 1-D arrays -> ``StagedClips``: the clips copied back to back into a pinned buffer (two buffers, used
         alternately) and their upload started on the copy stream.  Touches no stream but the copy stream."""
@@ -213,9 +222,8 @@ class SpectrogramAudioParser(AudioParser):
                 # the lane's stream is known: the upload goes into it from HERE (the staging thread), behind the lane's running
                 # forward and ahead of this one's kernels -- it starts the moment that forward ends, and a hipMemcpyAsync that
                 # holds its caller (see DanSpeechRecognizer.transcribe_batches) holds this thread, not the one that feeds the lanes
-                with torch.cuda.stream(up):
-                    pcm = slot["dev"][:nbytes]
-                    pcm.copy_(slot["buf"][:nbytes], non_blocking=True)
+                pcm = slot["dev"][:nbytes]
+                self._upload(pcm, slot["buf"][:nbytes], up)
                 return StagedClips(pcm, n, dtype.itemsize, None, slot)
             return StagedClips(slot["buf"][:nbytes], n, dtype.itemsize, None, slot)
         if getattr(self, "share_copy_stream", False):
@@ -247,7 +255,7 @@ class SpectrogramAudioParser(AudioParser):
         main = torch.cuda.current_stream(self.device)
         if not staged.pcm.is_cuda:                               # staged only: the upload runs here, on the forward's own stream
             dev = staged.slot["dev"][:staged.pcm.numel()]
-            dev.copy_(staged.pcm, non_blocking=True)
+            self._upload(dev, staged.pcm, main)
             staged = StagedClips(dev, staged.n_samples, staged.itemsize, None, staged.slot)
         if staged.done is not None:
             main.wait_event(staged.done)

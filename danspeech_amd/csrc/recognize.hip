@@ -150,6 +150,26 @@ extern "C" int dsmi_pack_pcm_i16(const double* src, int64_t n, int16_t* dst) {
     return 1;
 }
 
+// See include/dsmi.h: the upload as a kernel.  64 workgroups (a quarter of the CUs, a wave's 1-KiB reads in flight on each) read the
+// pinned buffer 16 bytes per lane and write device memory; a tail of fewer than 16 bytes goes 2 bytes at a time.
+using up_u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+__global__ __launch_bounds__(256) void upload_kernel(up_u32x4* __restrict__ dst, const up_u32x4* __restrict__ src, size_t n16, size_t tail2) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = __builtin_nontemporal_load(src + i);
+    if (blockIdx.x == 0 && threadIdx.x < tail2)
+        reinterpret_cast<uint16_t*>(dst + n16)[threadIdx.x] = reinterpret_cast<const uint16_t*>(src + n16)[threadIdx.x];
+}
+
+extern "C" int dsmi_upload(int device, void* dst_dev, const void* src_pinned, int64_t bytes, void* stream) {
+    if (!dst_dev || !src_pinned || bytes < 0 || (bytes & 1) || ((uintptr_t)dst_dev & 15) || ((uintptr_t)src_pinned & 15)) return DSMI_ERR_INVALID;
+    if (bytes == 0) return DSMI_OK;
+    if (hipSetDevice(device) != hipSuccess) return DSMI_ERR_HIP;
+    const size_t n16 = (size_t)bytes / 16, tail2 = ((size_t)bytes % 16) / 2;
+    const int grid = (int)std::min<size_t>(64, std::max<size_t>(1, (n16 + 255) / 256));
+    hipLaunchKernelGGL(upload_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (up_u32x4*)dst_dev, (const up_u32x4*)src_pinned, n16, tail2);
+    return hipGetLastError() == hipSuccess ? DSMI_OK : DSMI_ERR_HIP;
+}
+
 // Stage, upload, spectrograms, network: everything up to the probabilities, asynchronous on the session's stream.
 extern "C" int dsmi_recognize_enqueue(dsmi_session* s, const void* const* clips_host, const int64_t* n_samples_host, int pcm_dtype, int B) {
     if (!s) return DSMI_ERR_INVALID;

@@ -140,6 +140,12 @@ int dsmi_features(dsmi_frontend* f, const void* pcm_dev, int pcm_dtype, const in
  * when one is not (dst is then unspecified and the caller uploads the float64 samples).  Used by the staging of
  * dsmi_recognize_enqueue and of the Python pipeline. */
 int dsmi_pack_pcm_i16(const double* src, int64_t n, int16_t* dst);
+/* Staged clips -> device memory by a KERNEL that reads the pinned host buffer over the bus (src_pinned: hipHostMalloc'ed / pinned by
+ * the caller's framework, i.e. mapped into the device's address space; bytes a multiple of 2), asynchronous on `stream`.  The
+ * batch pipeline uploads with it instead of hipMemcpyAsync: the runtime hands a copy to a DMA engine, and the first copies a
+ * process's streams give the engines hold the calling thread for 6-12 ms each -- well into a process's second call
+ * (profiles/r06_second_call_stall.txt).  device: where dst_dev lives. */
+int dsmi_upload(int device, void* dst_dev, const void* src_pinned, int64_t bytes, void* stream);
 int dsmi_features_stream(dsmi_frontend* f, const void* pcm_dev, int pcm_dtype, int64_t n_samples, double* state3,
                          float* feat_dev, int t_stride, int32_t* frames_host, void* stream);
 

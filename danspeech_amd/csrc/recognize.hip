@@ -227,7 +227,9 @@ extern "C" int dsmi_recognize_enqueue(dsmi_session* s, const void* const* clips_
     if (!as_i16) fill(false);
     const size_t up = as_i16 ? bytes / 4 : bytes;
     if (!grow(s, &s->pcm, &s->pcm_cap, up)) return sfail(s, DSMI_ERR_NOMEM, "hipMalloc failed");
-    if (hipMemcpyAsync(s->pcm, s->pin, up, hipMemcpyHostToDevice, s->stream) != hipSuccess) return sfail(s, DSMI_ERR_HIP, "upload failed");
+    // (by kernel, as the Python pipeline does: see dsmi_upload; an odd byte count -- 8-bit samples -- goes through the copy engine)
+    if ((up & 1) ? hipMemcpyAsync(s->pcm, s->pin, up, hipMemcpyHostToDevice, s->stream) != hipSuccess
+                 : dsmi_upload(s->device, s->pcm, s->pin, (int64_t)up, s->stream) != DSMI_OK) return sfail(s, DSMI_ERR_HIP, "upload failed");
     return run_from_device(s, s->pcm, n.data(), as_i16 ? DSMI_PCM_I16 : pcm_dtype, B);
 }
 

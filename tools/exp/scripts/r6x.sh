@@ -1,6 +1,7 @@
 #!/bin/bash
 export TMPDIR=/tmp
 cd /root/repo
+timeout 1700 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|error|Error|assert" | tail -6 | tee gpurun_out/r06_gpu_tests.txt
 bash tools/final_profiles.sh r06 $1 > gpurun_out/r6x_final.log 2>&1
 python3 - <<PY
 import json
@@ -10,6 +11,4 @@ for f in ("gpurun_out/r06_bench.json", "gpurun_out/r06_bench_driver_command.json
     print("   other:", {k: v.get("ms_per_batch") for k, v in (d.get("other_configs") or {}).items() if isinstance(v, dict)})
 PY
 cat gpurun_out/r06_run_configs.txt
-python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-side-paths 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('driver command again:', d['ms_per_step'])"
-python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-side-paths 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('driver command again:', d['ms_per_step'])"
 timeout 300 python -c 'import __graft_entry__ as g; g.smoke()' 2>&1 | tail -1

@@ -8,7 +8,9 @@
 set -u
 TAG=${1:-r02}
 export TMPDIR=/tmp
-CMD="python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-side-paths --no-kernel-sampling"
+# (8 timed steps behind a 16-step warm-up call: every forward of the process carries 64 clips -- a step count that is not a multiple of 8
+# ends in a round of 32-clip forwards, whose launches would be averaged into the per-launch figures)
+CMD="python3 bench.py --steps 8 --warmup 8 --no-cpu-baseline --no-side-paths --no-kernel-sampling"
 for G in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES" "GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_MFMA"; do
     N=$(echo $G | cut -d' ' -f1)
     rocprofv3 --pmc $G --output-format csv -d gpurun_out/${TAG}_pmc_${N} -- $CMD > gpurun_out/${TAG}_pmc_${N}.log 2>&1 || echo "pass $N failed (see gpurun_out/${TAG}_pmc_${N}.log)"

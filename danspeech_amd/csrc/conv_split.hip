@@ -68,7 +68,10 @@ __device__ __forceinline__ void store_split4(uint16_t* y_sp, size_t bf_index, in
 
 // One workgroup = one 32-channel output tile (the 96-channel third layer runs its tiles as separate workgroups); one
 // accumulator per MFMA tile, 76 KB of LDS (eight staged input rows, see "staging" below), 136 registers: two workgroups per CU.
-template <bool SPLIT_OUT>
+// XPIPE: a tap's eight x fragments are read from LDS during the MFMAs of the tap before it (a second set of 32 registers), one read
+// per three MFMAs, instead of in front of their own MFMAs -- where each tap began with two exposed LDS round trips that only the
+// SIMD's other wave could cover.
+template <bool SPLIT_OUT, bool XPIPE = true>
 __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvSplitArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char csm[];
     _Float16* Xs = reinterpret_cast<_Float16*>(csm);  // [2 families][4 slots][2 planes][WIN][PITCH]
@@ -177,14 +180,59 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvSplitArgs p) {
                 for (int tt = 0; tt < 4; ++tt)
                     acc[c][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[c][pp == 0 ? 1 : 0], xf[tt][pp == 1 ? 1 : 0], acc[c][tt], 0, 0, 0);
     };
+    // ---- the pipelined form of a tap
+    auto read_x = [&](const _Float16* xrow, int kt, f16x8 (&xf)[4][NPL]) {
+        const int st0 = kt + l15;                           // (16 tt does not move the swizzle: one base, immediates)
+        const _Float16* base = xrow + st0 * PITCH + ((l4 ^ ((st0 >> 1) & 3)) * 8);
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) xf[tt][pl] = *reinterpret_cast<const f16x8*>(base + pl * ROWPLANE + tt * 16 * PITCH);
+    };
+    auto tap_p = [&](const _Float16* xrow, int kf, int kt, auto slot_c, const f16x8 (&xf)[4][NPL], f16x8 (&xn)[4][NPL], bool more) {
+        constexpr int slot = decltype(slot_c)::value;
+        const int q = kf * KT + kt;
+        f16x8 wf[2][NPL];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) wf[c][pl] = wq[slot][c][pl];
+        load_w(min(q + 2, NQ - 1), wq[slot]);
+        if (more) read_x(xrow, kt + 1, xn);
+#pragma unroll
+        for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt)
+                    acc[c][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[c][pp == 0 ? 1 : 0], xf[tt][pp == 1 ? 1 : 0], acc[c][tt], 0, 0, 0);
+        if (more) {
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // one LDS read
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);     // three MFMAs
+            }
+        }
+    };
     auto taps = [&](const _Float16* xrow, int kf, auto first_slot) {
         constexpr int S0 = decltype(first_slot)::value;
+        if constexpr (XPIPE) {
+            f16x8 xa[4][NPL], xb[4][NPL];
+            read_x(xrow, 0, xa);
 #pragma unroll 1
-        for (int kt = 0; kt + 1 < KT; kt += 2) {
-            tap(xrow, kf, kt, std::integral_constant<int, S0>{});
-            tap(xrow, kf, kt + 1, std::integral_constant<int, S0 ^ 1>{});
+            for (int kt = 0; kt + 1 < KT; kt += 2) {
+                tap_p(xrow, kf, kt, std::integral_constant<int, S0>{}, xa, xb, true);
+                tap_p(xrow, kf, kt + 1, std::integral_constant<int, S0 ^ 1>{}, xb, xa, true);
+            }
+            tap_p(xrow, kf, KT - 1, std::integral_constant<int, S0>{}, xa, xb, false);
+        } else {
+#pragma unroll 1
+            for (int kt = 0; kt + 1 < KT; kt += 2) {
+                tap(xrow, kf, kt, std::integral_constant<int, S0>{});
+                tap(xrow, kf, kt + 1, std::integral_constant<int, S0 ^ 1>{});
+            }
+            tap(xrow, kf, KT - 1, std::integral_constant<int, S0>{});
         }
-        tap(xrow, kf, KT - 1, std::integral_constant<int, S0>{});
     };
 
     // KT is odd, so the first tap's ring slot alternates with kf: the kernel rows are walked in pairs (straight-line code for an
@@ -282,6 +330,16 @@ void launch_conv_split(const ConvSplitLaunch& c, hipStream_t s) {
     const size_t lds = (size_t)NSLOT * NPL * ROWPLANE * 2;   // 75,776 B: two workgroups per CU
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_f16x3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_f16x3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+#ifdef DSMI_EXPERIMENTS       // the form that reads a tap's fragments in front of its own MFMAs (rounds 3-5), for A/B runs
+    static const bool plain = [] { const char* e = exp_env("DSMI_DEBUG_CONV_XPIPE"); return e && std::atoi(e) == 0; }();
+    if (plain) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_f16x3_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_f16x3_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (c.y_sp) DSMI_LAUNCH((conv_f16x3_kernel<true, false>), grid, dim3(256), lds, s, c.ev, a);
+        else DSMI_LAUNCH((conv_f16x3_kernel<false, false>), grid, dim3(256), lds, s, c.ev, a);
+        return;
+    }
+#endif
     if (c.y_sp) DSMI_LAUNCH((conv_f16x3_kernel<true>), grid, dim3(256), lds, s, c.ev, a);
     else DSMI_LAUNCH((conv_f16x3_kernel<false>), grid, dim3(256), lds, s, c.ev, a);
 }

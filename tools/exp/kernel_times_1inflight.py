@@ -7,8 +7,9 @@ from danspeech_amd import _native, synthetic as syn
 cfg = dict(conv_layers=2, rnn_type="gru", rnn_hidden_size=800, rnn_layers=5, bidirectional=True, context=20)
 sd = syn.make_state_dict(2, "gru", 800, 5, seed=0, **syn.TALKATIVE)
 m = _native.NativeModel(cfg, sd)
-x = torch.from_numpy(syn.make_features(32, 1001)).cuda()
-lens = np.full(32, 1001, dtype=np.int32)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+x = torch.from_numpy(syn.make_features(B, 1001)).cuda()
+lens = np.full(B, 1001, dtype=np.int32)
 for _ in range(3):
     m.forward(x, lens)
 m.set_profiling(2); m.reset_kernel_stats()

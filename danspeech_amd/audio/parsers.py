@@ -4,7 +4,6 @@
 float32 torch tensor; the STFT runs in libdsmi.so (float64 DFT on the GPU, features.hip) and the
 tensor stays on the device (the engine's ``.to(device)`` is then a no-op).
 """
-import os
 
 import numpy as np
 
@@ -216,8 +215,6 @@ class SpectrogramAudioParser(AudioParser):
             if slot["dev"] is None or slot["dev"].numel() < nbytes:
                 slot["dev"] = torch.empty(max(nbytes, slot["high"]), dtype=torch.uint8, device="cuda:%d" % self.device)
             up = getattr(self, "upload_stream", None)
-            if os.environ.get("DSMI_TEST_LATE_UPLOAD"):
-                up = None
             if up is not None:
                 # the lane's stream is known: the upload goes into it from HERE (the staging thread), behind the lane's running
                 # forward and ahead of this one's kernels -- it starts the moment that forward ends, and a hipMemcpyAsync that

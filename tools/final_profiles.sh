@@ -36,7 +36,7 @@ json.dump(d, open(p, "w"), indent=1, sort_keys=True)
 PY
 
 # 4. the other BASELINE configs through the public surface, and the kernel stats of each
-{ hdr; python3 tools/run_configs.py 2 3 4 5 2>&1 | grep -v "amdgpu.ids\|Using device\|updated"; } > $O/${TAG}_run_configs.txt
+{ hdr; python3 tools/run_configs.py 2 3 4 5 6 2>&1 | grep -v "amdgpu.ids\|Using device\|updated"; } > $O/${TAG}_run_configs.txt
 for C in 3 4 5; do
     rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_cfg${C} -- python3 tools/run_configs.py $C > $O/${TAG}_cfg${C}.log 2>&1
     S=$(ls $O/${TAG}_cfg${C}/*/*kernel_stats.csv | head -1)

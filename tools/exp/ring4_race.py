@@ -15,7 +15,8 @@ equal = len(sys.argv) > 4 and sys.argv[4] == "equal"
 cfg = dict(conv_layers=2, rnn_type=os.environ.get("DBG_KIND", "gru"), rnn_hidden_size=H, rnn_layers=int(os.environ.get("DBG_LAYERS", "3")), bidirectional=True, context=20)
 sd = syn.make_state_dict(2, cfg["rnn_type"], H, cfg["rnn_layers"], seed=12, fc_gain=8.0)
 NB = int(os.environ.get("DBG_B", "64"))
-clips = ([syn.make_clip(i, 9800 if equal else 9000 + 400 * (i % 5)) for i in range(32)] * 2)[:NB]
+L0 = int(os.environ.get("DBG_LEN", "9000"))     # samples of the shortest clip (9000: ~30 output frames)
+clips = ([syn.make_clip(i, L0 + 800 if equal else L0 + 400 * (i % 5)) for i in range(32)] * 2)[:NB]
 order = np.argsort([-len(c) for c in clips], kind="stable")
 n = np.array([len(clips[i]) for i in order], dtype=np.int64)
 fe = _native.NativeFrontend()

@@ -283,7 +283,22 @@ def main(argv=None):
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
     rccl = None
-    if world > 1:
+    # (DSMI_BENCH_FORCE_GROUP=1: the process group, the barrier, the reduction and the gather stream of the N > 1 path with ONE rank --
+    # the boxes of this pool have one GPU; tests/test_gpu_rccl_one_rank.py)
+    multi = world > 1 or bool(os.environ.get("DSMI_BENCH_FORCE_GROUP"))
+    if multi and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    line_fd = None
+    if multi and not dry:
+        # RCCL writes notes of its own to the C-level stdout ("Librccl path : ...", buffered until the process ends: BEHIND the JSON
+        # line).  The line is this command's stdout; everything else that is written to descriptor 1 from here on goes to stderr.
+        sys.stdout.flush()
+        line_fd = os.dup(1)
+        os.dup2(2, 1)
+    if multi:
         if dry:
             dist.init_process_group("gloo")
         else:
@@ -346,7 +361,7 @@ def main(argv=None):
     # the gather gets a stream of its own: RCCL orders a collective behind everything already queued on the stream it is issued
     # from, and the pipeline's first stream always holds a forward that was enqueued ahead (8 ms of somebody else's work)
     import contextlib
-    gather_stream = torch.cuda.Stream(device=local) if (world > 1 and not dry) else None
+    gather_stream = torch.cuda.Stream(device=local) if (multi and not dry) else None
 
     def run(steps):
         """`steps` batches through recognize_batches; the transcripts of every step gathered to rank 0."""
@@ -354,7 +369,7 @@ def main(argv=None):
         # (a LIST of `steps` batches, as a caller with its clips in hand passes them: the pipeline then knows where the call ends and
         # deals its last round of forwards evenly over the lanes -- 20 steps are eight forwards of 64 clips and four of 32)
         for res in rec.recognize_batches([host_clips] * steps):
-            if world > 1:
+            if multi:
                 with (torch.cuda.stream(gather_stream) if gather_stream is not None else contextlib.nullcontext()):
                     out = parallel.gather_texts(res, positions, B * world, cap, rank, world, dev)
             else:
@@ -362,7 +377,7 @@ def main(argv=None):
         return out
 
     def sync():
-        if world > 1:
+        if multi:
             dist.barrier()
         if not dry:
             torch.cuda.synchronize()
@@ -428,7 +443,7 @@ def main(argv=None):
     P = (1 + len(eng._replicas)) if eng is not None else 2           # forwards in flight, each of up to pipeline_merge_clips clips
     merge_clips = max(eng.pipeline_merge_clips, B) if eng is not None else B
 
-    if world > 1:
+    if multi:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -521,8 +536,12 @@ def main(argv=None):
         if not args.strict_f32_child and not args.no_other_configs:
             result["other_configs"] = other_configs_children()
     if rank == 0:
-        print(json.dumps(result), flush=True)
-    if world > 1:
+        if line_fd is None:
+            print(json.dumps(result), flush=True)
+        else:
+            sys.stdout.flush()
+            os.write(line_fd, (json.dumps(result) + "\n").encode())
+    if multi:
         dist.destroy_process_group()
     if failed:
         sys.exit(2)           # a throughput line from a computation that failed its own check must not read as a result

@@ -59,3 +59,22 @@ def test_rccl_collectives_of_one_rank_beside_the_engine():
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     r = subprocess.run([sys.executable, "-c", SCRIPT % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "RCCL-ONE-RANK-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+@pytest.mark.gpu
+def test_bench_with_its_process_group_forced_on_one_rank():
+    """bench.py's N > 1 plumbing -- init_process_group("nccl", device_id=...), the barriers around the timed region, the MAX
+    reduction of the time, the gather stream -- with one rank: the line carries `rccl` and the same parity check as ever."""
+    import json
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, DSMI_BENCH_FORCE_GROUP="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "8", "--warmup", "4", "--no-side-paths",
+                        "--no-other-configs"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["rccl"]["world_size_seen"] == 1 and line["rccl"]["backend"] == "nccl"
+    assert line["n_gpus"] == 1 and line["steps"] == 8 and line["value"] > 0
+    assert line["parity_checked"] is True

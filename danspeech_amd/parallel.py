@@ -26,6 +26,15 @@ def plan_shards(lengths, world):
     return [order[r::world] for r in range(world)]
 
 
+# tests/test_gpu_rccl_one_rank.py: with a process group of ONE rank every function here still goes through its collectives
+# (a one-GPU box can then run the same calls, payload types and devices over RCCL that N ranks would)
+_ALWAYS_COLLECTIVE = False
+
+
+def _alone(world):
+    return world == 1 and not _ALWAYS_COLLECTIVE
+
+
 def _torch_dtype(np_dtype):
     import torch
     return {np.dtype(np.int16): torch.int16, np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64}[np.dtype(np_dtype)]
@@ -42,7 +51,7 @@ def scatter_clips(all_clips, per_rank, n_samples, rank, world, device, dtype=np.
     every rank returns its [per_rank, n_samples] shard on ``device``."""
     import torch
     import torch.distributed as dist
-    if world == 1:
+    if _alone(world):
         return torch.from_numpy(np.ascontiguousarray(all_clips, dtype=dtype)).to(device)
     out = torch.empty((per_rank, n_samples), dtype=_torch_dtype(dtype), device=device)
     chunks = None
@@ -59,7 +68,7 @@ def gather_token_ids(seqs, rank, world, device, cap):
     is known to every rank); column 0 is the length.  Returns the list on rank 0, None elsewhere."""
     import torch
     import torch.distributed as dist
-    if world == 1:
+    if _alone(world):
         return [np.asarray(s) for s in seqs]
     buf = np.zeros((len(seqs), cap + 1), dtype=np.int32)
     for i, s in enumerate(seqs):
@@ -89,20 +98,20 @@ def scatter_ragged(clips, rank, world, device):
         kinds = {np.asarray(c).dtype for c in clips}
         dtype = kinds.pop() if len(kinds) == 1 and next(iter(kinds)) in _PCM_CODES else np.dtype(np.float64)
         head[0], head[1] = len(clips), _PCM_CODES[dtype]
-    if world > 1:
+    if not _alone(world):
         dist.broadcast(head, src=0)
     count, dtype = int(head[0]), _PCM_TYPES[int(head[1])]
     lens = torch.zeros(max(count, 1), dtype=torch.int64, device=device)
     if rank == 0 and count:
         lens[:count] = torch.tensor([len(c) for c in clips], dtype=torch.int64)
-    if world > 1:
+    if not _alone(world):
         dist.broadcast(lens, src=0)
     lengths = lens[:count].cpu().numpy()
     shards = plan_shards(lengths, world)
     totals = [int(lengths[s].sum()) for s in shards]
     width = max(max(totals), 1)
     mine = torch.empty(width, dtype=_torch_dtype(dtype), device=device)
-    if world == 1:
+    if _alone(world):
         mine[:totals[0]] = torch.from_numpy(np.concatenate([np.asarray(clips[i], dtype=dtype) for i in shards[0]])) if count else mine[:0]
     else:
         payload = None
@@ -136,7 +145,7 @@ def gather_texts(texts, indices, count, cap, rank, world, device, beams=1):
             buf[row, k, 0], buf[row, k, 1] = i, len(codes)
             buf[row, k, 2:2 + len(codes)] = codes
     t = torch.from_numpy(buf).to(device)
-    if world == 1:
+    if _alone(world):
         outs = [t]
     else:
         outs = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
@@ -179,7 +188,7 @@ def recognize_sharded(engine, clips, rank, world, device, frames_cap=None, show_
     cap = frames_cap if frames_cap is not None else int(lengths.max() // 160 + 1) if len(lengths) else 1
     beams = 1
     longest = max([len(t) for r in results for t in ([r] if not show_all else r)] + [0])
-    if world > 1:
+    if not _alone(world):
         word = torch.tensor([1 if err is not None else 0, max([len(r) for r in results] + [1]) if show_all else 1, longest],
                             dtype=torch.int64, device=device)
         dist.all_reduce(word, op=dist.ReduceOp.MAX)
